@@ -1,0 +1,182 @@
+/*
+ * openintel_hip.h -- C ABI of libopenintel_hip.so (MI355X / gfx950, hand-written HIP).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, int status codes, no
+ * exceptions across the ABI, no framework types.  A Rust `extern "C"` block (or
+ * ctypes) binds these symbols directly; see INTEGRATION.md for the Rust shim that
+ * implements the reference's port trait on top of them.
+ *
+ * Reference interfaces replaced (paths relative to the openintel repo):
+ *
+ *   oi_lexicon_analyze*      <- trait PostAnalyzer::analyze
+ *                               src/domain/ports/post_analyzer.rs:7-11, implemented by
+ *                               LexiconAnalyzer   src/adapters/analyzer/lexicon.rs:53-87
+ *                               (called at src/application/analyze.rs:62-63)
+ *   oi_social_summary*       <- SpeculationEngine::social_summary
+ *                               src/domain/engine/speculation_engine.rs:70-125
+ *   oi_index_* / oi_search*  <- NO reference interface exists: the
+ *   oi_rrf_fuse / oi_merge_lists  reference has no retrieval port.  New, builder-defined
+ *                               API styled after the reference's ports (borrowed inputs,
+ *                               caller-owned outputs, DomainError-style failures).
+ *
+ * Conventions
+ *   - Every function returns OI_OK (0) or a negative oi_status.  oi_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *     A Rust shim maps nonzero -> DomainError::SourceFailure{name:"hip-analyzer",..}
+ *     (src/domain/error.rs:16-17).
+ *   - `location` arguments say where the caller's buffers live: OI_HOST or OI_DEVICE
+ *     (HBM of the ctx's device).  With OI_DEVICE the call is asynchronous on the ctx
+ *     stream (oi_set_stream / oi_synchronize); with OI_HOST it returns after the
+ *     results are in the caller's buffers.
+ *   - The library never keeps a caller pointer past return, except
+ *     oi_index_set_embeddings(OI_DEVICE), which borrows the corpus matrix (30 GB at
+ *     10M x 768 is not copied) until oi_index_destroy.
+ *   - An oi_ctx serialises calls internally (one mutex): safe to share between host
+ *     threads, as the reference's `Send + Sync` port requires.
+ */
+#ifndef OPENINTEL_HIP_H
+#define OPENINTEL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OI_ABI_VERSION 1
+
+typedef enum {
+    OI_OK = 0,
+    OI_ERR_INVALID_ARG = -1,
+    OI_ERR_HIP = -2,           /* a HIP runtime call failed; message has the hipError */
+    OI_ERR_ANALYZER_MISMATCH = -3, /* mirrors DomainError::AnalyzerMismatch, error.rs:13-14 */
+    OI_ERR_STATE = -5,         /* call order violated (e.g. search before finalize) */
+    OI_ERR_NO_DEVICE = -6,     /* no gfx950 device / HIP runtime unusable */
+    OI_ERR_UNSUPPORTED = -7,   /* shape outside what the kernels are built for */
+    OI_ERR_OVERFLOW = -8       /* an internal candidate pool overflowed (bug guard) */
+} oi_status;
+
+enum { OI_HOST = 0, OI_DEVICE = 1 };
+
+/* Limits of the kernels in this build. */
+#define OI_MAX_DEPTH 1024u      /* per-list depth k' and final k */
+#define OI_MAX_DIM 1024u        /* embedding dimension (multiple of 4) */
+#define OI_BM25_BLOCK_DOCS 32768u /* docs per BM25 LDS accumulator block */
+
+typedef struct oi_ctx oi_ctx;
+typedef struct oi_index oi_index;
+
+int oi_abi_version(void);
+const char *oi_last_error(void);
+
+int oi_create(int device_ordinal, oi_ctx **out);
+void oi_destroy(oi_ctx *ctx);
+/* `hip_stream` is a hipStream_t (NULL = the default stream). */
+int oi_set_stream(oi_ctx *ctx, void *hip_stream);
+int oi_synchronize(oi_ctx *ctx);
+
+/* ------------------------------------------------------------------------- */
+/* PostAnalyzer path (reference-pinned)                                        */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * One (polarity, speculative) per post, index-aligned with the input
+ * (post_analyzer.rs:9).  Post i is text_blob[offsets[i] .. offsets[i+1]), valid
+ * UTF-8 (the shim gathers SocialPost.text into one blob: posts are not contiguous
+ * in the reference, social_post.rs:25-27).  Infallible in the reference; here it
+ * fails only on device errors.
+ */
+int oi_lexicon_analyze(oi_ctx *ctx, const uint8_t *text_blob, const uint64_t *offsets,
+                       uint64_t n_posts, double *polarity_out, uint8_t *speculative_out);
+
+/* Same, buffers already in HBM; asynchronous on the ctx stream. */
+int oi_lexicon_analyze_device(oi_ctx *ctx, const uint8_t *d_text_blob, const uint64_t *d_offsets,
+                              uint64_t n_posts, uint64_t blob_bytes, double *d_polarity_out,
+                              uint8_t *d_speculative_out);
+
+/* Raw sums of SpeculationEngine::social_summary (speculation_engine.rs:76-97).
+ * Integer fields are exact.  polarity_sum is a fixed-shape tree sum (bitwise
+ * reproducible run to run) and differs from the reference's input-order sum by
+ * at most n * 2^-53 * max|partial sum|; see DESIGN.md. */
+typedef struct {
+    uint64_t total;
+    uint64_t by_source[2]; /* [reddit, bluesky]  source_kind.rs:5-8 */
+    uint64_t bullish, bearish, neutral, spec_count;
+    double polarity_sum;
+} oi_social_counters;
+
+/* sources[i]: 0 = reddit, 1 = bluesky.  n_posts != n_signals ->
+ * OI_ERR_ANALYZER_MISMATCH (speculation_engine.rs:29-34). */
+int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts,
+                      const double *polarity, const uint8_t *speculative, uint64_t n_signals,
+                      double bull_bear_threshold, int location, oi_social_counters *out_host);
+
+/* ------------------------------------------------------------------------- */
+/* Hybrid retrieval (builder-defined; parity unpinned vs the reference)        */
+/* ------------------------------------------------------------------------- */
+
+/* A shard of the corpus: rows [doc_id_base, doc_id_base + n_docs) of the global
+ * collection.  Result doc ids are global (doc_id_base + local row). */
+int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint32_t vocab,
+                    uint32_t doc_id_base, oi_index **out);
+void oi_index_destroy(oi_index *idx);
+
+/* rows: n_docs x dim f32, row-major.  normalize != 0: L2-normalise each row (in
+ * place when OI_DEVICE).  OI_DEVICE borrows the pointer; OI_HOST copies to HBM. */
+int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize);
+
+/* Forward index: doc d owns term_ids[doc_offsets[d] .. doc_offsets[d+1]),
+ * every id < vocab.  Stages the postings and computes local statistics. */
+int oi_index_set_forward(oi_index *idx, const uint32_t *term_ids, const uint64_t *doc_offsets,
+                         int location);
+/* Local document frequencies (vocab entries, host) and token count: what a
+ * multi-shard caller all-reduces before oi_index_finalize. */
+int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df_out_host);
+/* Fix the collection statistics (global N, token count, df; df NULL = local) and
+ * build the blocked inverted index with precomputed BM25 impacts. */
+int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
+                      const uint32_t *global_df_host);
+
+/*
+ * Per-shard ranked lists for a batch of queries.
+ *   query_vecs      n_queries x dim f32 (normalised by the caller if cosine is wanted)
+ *   query_terms     concatenated term ids; query q owns [q_term_offsets[q], q_term_offsets[q+1])
+ * Outputs, each n_queries x depth, row q sorted by (score desc, doc id asc),
+ * first counts[q] entries valid:
+ *   cosine list: dot(query, row);  BM25 list: only docs with score > 0.
+ */
+int oi_search_lists(oi_index *idx, const float *query_vecs, const uint32_t *query_terms,
+                    const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth,
+                    int location, float *cos_scores, uint32_t *cos_docs, uint32_t *cos_counts,
+                    float *bm25_scores, uint32_t *bm25_docs, uint32_t *bm25_counts);
+
+/* Merge per-shard lists ([n_shards][n_queries][depth], counts [n_shards][n_queries])
+ * into the global top-`depth` per query (the step after the RCCL all-gather). */
+int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *docs, const uint32_t *counts,
+                   uint32_t n_shards, uint32_t n_queries, uint32_t depth, int location,
+                   float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+
+/* Reciprocal-rank fusion of two ranked lists per query (row stride `depth`):
+ * rrf(d) = sum over lists containing d of 1/(60 + rank), rank from 1; output top-k
+ * by (rrf desc, doc id asc), row stride k. */
+int oi_rrf_fuse(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a,
+                const uint32_t *docs_b, const uint32_t *counts_b, uint32_t n_queries,
+                uint32_t depth, uint32_t k, int location, float *scores_out, uint32_t *docs_out,
+                uint32_t *counts_out);
+
+/* oi_search_lists + oi_rrf_fuse on one shard: the whole hybrid query. */
+int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_terms,
+              const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
+              int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+
+/* Timing hooks for bench.py: when enabled, HIP events are recorded on the ctx stream
+ * around every kernel launch, grouped by tag ("cosine", "bm25", "select", "rrf",
+ * "lexicon", "social_summary").  oi_profile_read returns the summed duration (ms) of
+ * the launches with that tag and their count since the last reset. */
+int oi_profile_reset(oi_ctx *ctx, int enable);
+int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENINTEL_HIP_H */

@@ -1,0 +1,22 @@
+"""openintel_amd -- MI355X-native hot path for Kloudy-Sky/openintel's per-post analysis, plus the
+hybrid retrieval path (cosine + BM25 + RRF) BASELINE.json names.
+
+Everything that computes runs in libopenintel_hip.so (hand-written HIP for gfx950) behind the
+C ABI of include/openintel_hip.h; this package is the host-side mirror of the reference's
+port/adapter interface.  There is no CPU fallback: without the library or a gfx950 device the
+calls raise.
+"""
+from . import _lib
+from .analyzer import HipLexiconAnalyzer, PostAnalyzer, pack_posts
+from .context import HipContext
+from .domain import (Alignment, AnalyzerMismatch, Confidence, DomainError, EngineConfig, MarketSnapshot,
+                     PostSignal, PostText, SocialPost, SourceFailure, SourceKind, Ticker)
+from .engine import SpeculationEngine
+from .retriever import HybridIndex, PostRetriever, SearchResult, merge_lists, pack_query_terms, rrf_fuse
+
+__all__ = [
+    "HipContext", "HipLexiconAnalyzer", "PostAnalyzer", "pack_posts", "SpeculationEngine", "HybridIndex",
+    "PostRetriever", "SearchResult", "merge_lists", "rrf_fuse", "pack_query_terms", "Alignment",
+    "AnalyzerMismatch", "Confidence", "DomainError", "EngineConfig", "MarketSnapshot", "PostSignal", "PostText",
+    "SocialPost", "SourceFailure", "SourceKind", "Ticker",
+]

@@ -1,0 +1,108 @@
+"""ctypes binding of libopenintel_hip.so (include/openintel_hip.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is visible the
+calls raise.  `python -m openintel_amd.build` (or `__graft_entry__.build()`) compiles it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libopenintel_hip.so")
+
+OI_HOST, OI_DEVICE = 0, 1
+OI_MAX_DEPTH = 1024
+OI_MAX_DIM = 1024
+OI_BM25_BLOCK_DOCS = 32768
+
+OI_ERR_INVALID_ARG = -1
+OI_ERR_HIP = -2
+OI_ERR_ANALYZER_MISMATCH = -3
+OI_ERR_STATE = -5
+OI_ERR_NO_DEVICE = -6
+OI_ERR_UNSUPPORTED = -7
+OI_ERR_OVERFLOW = -8
+
+
+class OiError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("libopenintel_hip error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class SocialCounters(C.Structure):
+    _fields_ = [
+        ("total", C.c_uint64),
+        ("by_source", C.c_uint64 * 2),
+        ("bullish", C.c_uint64),
+        ("bearish", C.c_uint64),
+        ("neutral", C.c_uint64),
+        ("spec_count", C.c_uint64),
+        ("polarity_sum", C.c_double),
+    ]
+
+
+_P = C.c_void_p
+_U32, _U64, _I = C.c_uint32, C.c_uint64, C.c_int
+
+# name -> (restype, argtypes); every symbol include/openintel_hip.h declares
+SIGNATURES = {
+    "oi_abi_version": (_I, []),
+    "oi_last_error": (C.c_char_p, []),
+    "oi_create": (_I, [_I, C.POINTER(_P)]),
+    "oi_destroy": (None, [_P]),
+    "oi_set_stream": (_I, [_P, _P]),
+    "oi_synchronize": (_I, [_P]),
+    "oi_lexicon_analyze": (_I, [_P, _P, _P, _U64, _P, _P]),
+    "oi_lexicon_analyze_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P]),
+    "oi_social_summary": (_I, [_P, _P, _U64, _P, _P, _U64, C.c_double, _I, C.POINTER(SocialCounters)]),
+    "oi_index_create": (_I, [_P, _U64, _U32, _U32, _U32, C.POINTER(_P)]),
+    "oi_index_destroy": (None, [_P]),
+    "oi_index_set_embeddings": (_I, [_P, _P, _I, _I]),
+    "oi_index_set_forward": (_I, [_P, _P, _P, _I]),
+    "oi_index_local_stats": (_I, [_P, C.POINTER(_U64), _P]),
+    "oi_index_finalize": (_I, [_P, _U64, _U64, _P]),
+    "oi_search_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P, _P, _P, _P, _P, _P]),
+    "oi_merge_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
+    "oi_rrf_fuse": (_I, [_P, _P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
+    "oi_search": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
+    "oi_profile_reset": (_I, [_P, _I]),
+    "oi_profile_read": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_U64)]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libopenintel_hip.so is not built (%s). Run `python -m openintel_amd.build`. "
+            "openintel_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().oi_last_error()
+        raise OiError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def ptr(x):
+    """Device or host address of a torch tensor / numpy array / None."""
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(x.ctypes.data)

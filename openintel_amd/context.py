@@ -1,0 +1,52 @@
+"""HipContext -- owns an oi_ctx (device, stream, workspaces) of libopenintel_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+from . import _lib
+
+
+class HipContext:
+    """One per process/GPU.  Thread-safe: the library serialises calls on a ctx."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.oi_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream) -> None:
+        """`stream`: a hipStream_t as int, or a torch.cuda.Stream (its .cuda_stream is used)."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _lib.check(self.lib.oi_set_stream(self.handle, C.c_void_p(int(raw) if raw else None)))
+
+    def use_torch_current_stream(self) -> None:
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device))
+
+    def synchronize(self) -> None:
+        _lib.check(self.lib.oi_synchronize(self.handle))
+
+    # ---- HIP-event kernel timing (bench.py)
+    def profile_reset(self, enable: bool = True) -> None:
+        _lib.check(self.lib.oi_profile_reset(self.handle, 1 if enable else 0))
+
+    def profile_read(self, tag: str):
+        ms, n = C.c_double(), C.c_uint64()
+        _lib.check(self.lib.oi_profile_read(self.handle, tag.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.oi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,567 @@
+// api.hip -- the extern "C" surface of libopenintel_hip.so (see include/openintel_hip.h).
+#include <algorithm>
+
+#include "oi_internal.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void oi_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *oi_last_error(void) { return g_err; }
+extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
+
+// ---------------------------------------------------------------- buffers
+int DevBuf::ensure(size_t bytes) {
+    if (bytes <= cap && p) return OI_OK;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = (bytes + 255) & ~(size_t)255;
+    if (want == 0) want = 256;
+    OI_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return OI_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+// ---------------------------------------------------------------- profiling hooks
+void oi_ctx::prof_begin(const char *tag) {
+    ProfSpan s;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    (void)hipEventRecord(s.a, stream);
+    prof[tag].push_back(s);
+}
+void oi_ctx::prof_end(const char *tag) {
+    auto it = prof.find(tag);
+    if (it == prof.end() || it->second.empty()) return;
+    (void)hipEventRecord(it->second.back().b, stream);
+}
+
+extern "C" int oi_profile_reset(oi_ctx *ctx, int enable) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    for (auto &kv : ctx->prof)
+        for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    ctx->prof.clear();
+    ctx->prof_enabled = enable != 0;
+    return OI_OK;
+}
+
+extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out) {
+    if (!ctx || !kernel_tag) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    uint64_t n = 0;
+    auto it = ctx->prof.find(kernel_tag);
+    if (it != ctx->prof.end())
+        for (auto &s : it->second) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { total += ms; ++n; }
+        }
+    if (total_ms_out) *total_ms_out = total;
+    if (launches_out) *launches_out = n;
+    return OI_OK;
+}
+
+// ---------------------------------------------------------------- ctx
+extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
+    if (!out) { oi_set_error("oi_create: out is null"); return OI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        oi_set_error("oi_create: no HIP device visible (this library has no CPU fallback)");
+        return OI_ERR_NO_DEVICE;
+    }
+    OI_REQUIRE(device_ordinal >= 0 && device_ordinal < n, "oi_create: device %d of %d", device_ordinal, n);
+    OI_HIP_CHECK(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    OI_HIP_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        oi_set_error("oi_create: device %d is %s; this library is built for gfx950 only", device_ordinal,
+                     prop.gcnArchName);
+        return OI_ERR_NO_DEVICE;
+    }
+    oi_ctx *c = new oi_ctx();
+    c->device = device_ordinal;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->stream = nullptr;
+    *out = c;
+    return OI_OK;
+}
+
+extern "C" void oi_destroy(oi_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    oi_profile_reset(ctx, 0);
+    for (auto &kv : ctx->ws) kv.second.release();
+    delete ctx;
+}
+
+extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return OI_OK;
+}
+
+static int check_overflow_locked(oi_ctx *ctx) {
+    DevBuf &st = ctx->buf("state_flag");
+    if (!st.p) return OI_OK;
+    uint32_t f = 0;
+    OI_HIP_CHECK(hipMemcpyAsync(&f, st.p, sizeof(f), hipMemcpyDeviceToHost, ctx->stream));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (f) {
+        OI_HIP_CHECK(hipMemsetAsync(st.p, 0, 16, ctx->stream));
+        oi_set_error("internal candidate pool overflowed");
+        return OI_ERR_OVERFLOW;
+    }
+    return OI_OK;
+}
+
+extern "C" int oi_synchronize(oi_ctx *ctx) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return check_overflow_locked(ctx);
+}
+
+// ---------------------------------------------------------------- PostAnalyzer path
+extern "C" int oi_lexicon_analyze_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets,
+                                         uint64_t n, uint64_t blob_bytes, double *d_pol, uint8_t *d_spec) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(d_offsets && d_pol && d_spec && (d_blob || blob_bytes == 0), "lexicon: null buffer");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    return oi_launch_lexicon(ctx, d_blob, d_offsets, n, blob_bytes, d_pol, d_spec);
+}
+
+extern "C" int oi_lexicon_analyze(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                                  double *pol_out, uint8_t *spec_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(offsets && pol_out && spec_out, "lexicon: null buffer");
+    OI_REQUIRE(offsets[0] == 0, "lexicon: offsets[0] must be 0");
+    const uint64_t bytes = offsets[n];
+    OI_REQUIRE(blob || bytes == 0, "lexicon: null text blob");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf &b = ctx->buf("lex_blob"), &o = ctx->buf("lex_off"), &p = ctx->buf("lex_pol"), &s = ctx->buf("lex_spec");
+    OI_CHECK(b.ensure(bytes + 64));
+    OI_CHECK(o.ensure(sizeof(uint64_t) * (n + 1)));
+    OI_CHECK(p.ensure(sizeof(double) * n));
+    OI_CHECK(s.ensure(n));
+    if (bytes) OI_HIP_CHECK(hipMemcpyAsync(b.p, blob, bytes, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(o.p, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    OI_CHECK(oi_launch_lexicon(ctx, b.as<uint8_t>(), o.as<uint64_t>(), n, bytes, p.as<double>(), s.as<uint8_t>()));
+    OI_HIP_CHECK(hipMemcpyAsync(pol_out, p.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(spec_out, s.p, n, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
+}
+
+extern "C" int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts, const double *polarity,
+                                 const uint8_t *speculative, uint64_t n_signals, double tau, int location,
+                                 oi_social_counters *out) {
+    if (!ctx || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (n_signals != n_posts) { // speculation_engine.rs:29-34
+        oi_set_error("analyzer returned %llu signals for %llu posts", (unsigned long long)n_signals,
+                     (unsigned long long)n_posts);
+        return OI_ERR_ANALYZER_MISMATCH;
+    }
+    const uint64_t n = n_posts;
+    if (n == 0) { memset(out, 0, sizeof(*out)); return OI_OK; }
+    OI_REQUIRE(polarity && speculative, "social_summary: null buffer");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (location == OI_DEVICE) return oi_launch_social_summary(ctx, sources, polarity, speculative, n, tau, out);
+    hipStream_t st = ctx->stream;
+    DevBuf &s = ctx->buf("sum_src"), &p = ctx->buf("sum_pol"), &f = ctx->buf("sum_spec");
+    OI_CHECK(p.ensure(sizeof(double) * n));
+    OI_CHECK(f.ensure(n));
+    OI_HIP_CHECK(hipMemcpyAsync(p.p, polarity, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(f.p, speculative, n, hipMemcpyHostToDevice, st));
+    const uint8_t *dsrc = nullptr;
+    if (sources) {
+        OI_CHECK(s.ensure(n));
+        OI_HIP_CHECK(hipMemcpyAsync(s.p, sources, n, hipMemcpyHostToDevice, st));
+        dsrc = s.as<uint8_t>();
+    }
+    return oi_launch_social_summary(ctx, dsrc, p.as<double>(), f.as<uint8_t>(), n, tau, out);
+}
+
+// ---------------------------------------------------------------- index
+extern "C" int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint32_t vocab, uint32_t doc_id_base,
+                               oi_index **out) {
+    if (!ctx || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    OI_REQUIRE(n_docs > 0 && n_docs + doc_id_base <= 0xFFFFFFFFull, "index: doc ids must fit in 32 bits");
+    OI_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= OI_MAX_DIM, "index: dim=%u must be a multiple of 4 in [4,%u]", dim,
+               OI_MAX_DIM);
+    OI_REQUIRE(vocab > 0, "index: vocab must be > 0");
+    oi_index *idx = new oi_index();
+    idx->ctx = ctx;
+    idx->n_docs = n_docs;
+    idx->dim = dim;
+    idx->vocab = vocab;
+    idx->doc_id_base = doc_id_base;
+    *out = idx;
+    return OI_OK;
+}
+
+extern "C" void oi_index_destroy(oi_index *idx) {
+    if (!idx) return;
+    {
+        std::lock_guard<std::mutex> g(idx->ctx->mu);
+        (void)hipSetDevice(idx->ctx->device);
+        (void)hipStreamSynchronize(idx->ctx->stream);
+        if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
+        idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
+        idx->postings.release(); idx->cell_start.release(); idx->idf.release();
+    }
+    delete idx;
+}
+
+extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize) {
+    if (!idx || !rows) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (idx->rows_owned && idx->rows) { (void)hipFree(idx->rows); idx->rows = nullptr; idx->rows_owned = false; }
+    const size_t bytes = (size_t)idx->n_docs * idx->dim * sizeof(float);
+    if (location == OI_DEVICE) {
+        OI_REQUIRE(((uintptr_t)rows & 15u) == 0, "index: embedding matrix must be 16-byte aligned");
+        idx->rows = rows;
+    } else {
+        void *p = nullptr;
+        OI_HIP_CHECK(hipMalloc(&p, bytes));
+        idx->rows = reinterpret_cast<float *>(p);
+        idx->rows_owned = true;
+        OI_HIP_CHECK(hipMemcpyAsync(idx->rows, rows, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (normalize) OI_CHECK(oi_launch_l2_normalize(ctx, idx->rows, idx->n_docs, idx->dim));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OI_OK;
+}
+
+extern "C" int oi_index_set_forward(oi_index *idx, const uint32_t *term_ids, const uint64_t *doc_offsets,
+                                    int location) {
+    if (!idx || !doc_offsets) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (location == OI_DEVICE) return oi_bm25_stage_forward(idx, term_ids, doc_offsets);
+    const uint64_t total = doc_offsets[idx->n_docs];
+    DevBuf t, o;
+    OI_CHECK(t.ensure(sizeof(uint32_t) * (total ? total : 1)));
+    OI_CHECK(o.ensure(sizeof(uint64_t) * (idx->n_docs + 1)));
+    if (total) OI_HIP_CHECK(hipMemcpyAsync(t.p, term_ids, sizeof(uint32_t) * total, hipMemcpyHostToDevice, ctx->stream));
+    OI_HIP_CHECK(hipMemcpyAsync(o.p, doc_offsets, sizeof(uint64_t) * (idx->n_docs + 1), hipMemcpyHostToDevice,
+                                ctx->stream));
+    int rc = oi_bm25_stage_forward(idx, t.as<uint32_t>(), o.as<uint64_t>());
+    (void)hipStreamSynchronize(ctx->stream);
+    t.release();
+    o.release();
+    return rc;
+}
+
+extern "C" int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df_out_host) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (total_tokens_out) *total_tokens_out = idx->total_tokens;
+    if (df_out_host) {
+        OI_HIP_CHECK(hipMemcpyAsync(df_out_host, idx->df_local.p, sizeof(uint32_t) * idx->vocab,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return OI_OK;
+}
+
+extern "C" int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
+                                 const uint32_t *global_df_host) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }
+    if (idx->finalized) { oi_set_error("index: already finalized"); return OI_ERR_STATE; }
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    return oi_bm25_finalize(idx, global_n_docs, global_total_tokens, global_df_host);
+}
+
+// ---------------------------------------------------------------- search
+namespace {
+
+struct Pools {
+    PoolView cos, bm;
+};
+
+// One contiguous state block: [overflow flag(16 B)] [counts cos][tau cos][counts bm][tau bm]
+int prepare_pools(oi_ctx *ctx, uint32_t B, uint32_t cos_cap, uint32_t bm_cap, Pools *out) {
+    DevBuf &flag = ctx->buf("state_flag");
+    if (!flag.p) {
+        OI_CHECK(flag.ensure(16));
+        OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, ctx->stream));
+    }
+    DevBuf &st = ctx->buf("pool_state");
+    OI_CHECK(st.ensure(sizeof(uint32_t) * 4 * (size_t)B));
+    OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * 4 * (size_t)B, ctx->stream));
+    DevBuf &pc = ctx->buf("pool_cos"), &pb = ctx->buf("pool_bm");
+    OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_cap));
+    OI_CHECK(pb.ensure(sizeof(uint64_t) * (size_t)B * bm_cap));
+    uint32_t *s = st.as<uint32_t>();
+    out->cos = PoolView{pc.as<uint64_t>(), s, s + B, cos_cap, cos_cap, flag.as<uint32_t>()};
+    out->bm = PoolView{pb.as<uint64_t>(), s + 2 * (size_t)B, s + 3 * (size_t)B, bm_cap, bm_cap, flag.as<uint32_t>()};
+    return OI_OK;
+}
+
+// Device-side ranked lists for a batch; all pointers device.
+int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, const uint32_t *d_qo, uint32_t B,
+                        uint32_t depth, float *cos_s, uint32_t *cos_d, uint32_t *cos_c, float *bm_s,
+                        uint32_t *bm_d, uint32_t *bm_c) {
+    oi_ctx *ctx = idx->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = idx->n_docs;
+    // ---- pool capacities
+    // cosine: the corpus is scored in chunks; a chunk can append at most its row count, so a
+    // chunk of (cap - depth) rows can never overflow a pool that starts with <= depth entries.
+    uint64_t cos_cap = 1ull << 20;
+    const uint64_t budget = (1ull << 30) / 8 / B; // <= 1 GiB of pools
+    if (cos_cap > budget) cos_cap = budget;
+    if (cos_cap < 4ull * depth + 4096) cos_cap = 4ull * depth + 4096;
+    if (cos_cap > n + depth) cos_cap = n + depth;
+    // BM25: every doc block contributes at most `depth` candidates per query
+    const uint64_t bm_cap = (uint64_t)(idx->n_blocks ? idx->n_blocks : 1) * depth;
+    Pools P;
+    OI_CHECK(prepare_pools(ctx, B, (uint32_t)cos_cap, (uint32_t)bm_cap, &P));
+
+    // ---- cosine list
+    if (cos_s) {
+        OI_REQUIRE(idx->rows, "search: embeddings not set");
+        const uint32_t Bp = oi_cosine_query_padding(B);
+        const float *q = d_qv;
+        if (Bp != B) {
+            DevBuf &qp = ctx->buf("q_padded");
+            OI_CHECK(qp.ensure(sizeof(float) * (size_t)Bp * idx->dim));
+            OI_HIP_CHECK(hipMemsetAsync(qp.p, 0, sizeof(float) * (size_t)Bp * idx->dim, st));
+            OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
+            q = qp.as<float>();
+        }
+        const uint64_t max_chunk = cos_cap - depth;
+        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+        uint64_t r = 0;
+        while (r < n) {
+            if (chunk > max_chunk) chunk = max_chunk;
+            const uint64_t e = std::min(n, r + chunk);
+            OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
+            const bool last = e == n;
+            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+            r = e;
+            chunk *= 8;
+        }
+    }
+    // ---- BM25 list
+    if (bm_s) {
+        OI_REQUIRE(idx->finalized, "search: index not finalized");
+        OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm));
+        OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, false, bm_s, bm_d, bm_c, depth));
+    }
+    return OI_OK;
+}
+
+struct QueryStage {
+    const float *qv;
+    const uint32_t *qt, *qo;
+};
+
+int stage_queries(oi_index *idx, const float *qv, const uint32_t *qt, const uint32_t *qo, uint32_t B, int location,
+                  QueryStage *out) {
+    oi_ctx *ctx = idx->ctx;
+    if (location == OI_DEVICE) { *out = QueryStage{qv, qt, qo}; return OI_OK; }
+    hipStream_t st = ctx->stream;
+    DevBuf &a = ctx->buf("q_vecs"), &b = ctx->buf("q_terms"), &c = ctx->buf("q_offs");
+    const uint32_t nt = qo[B];
+    OI_CHECK(a.ensure(sizeof(float) * (size_t)B * idx->dim));
+    OI_CHECK(b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
+    OI_CHECK(c.ensure(sizeof(uint32_t) * (B + 1)));
+    OI_HIP_CHECK(hipMemcpyAsync(a.p, qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyHostToDevice, st));
+    if (nt) OI_HIP_CHECK(hipMemcpyAsync(b.p, qt, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(c.p, qo, sizeof(uint32_t) * (B + 1), hipMemcpyHostToDevice, st));
+    *out = QueryStage{a.as<float>(), b.as<uint32_t>(), c.as<uint32_t>()};
+    return OI_OK;
+}
+
+int check_search_args(oi_index *idx, const float *qv, const uint32_t *qt, const uint32_t *qo, uint32_t B,
+                      uint32_t depth) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(qv && qo && (qt || true), "search: null query buffer");
+    OI_REQUIRE(B >= 1 && B <= 4096, "search: n_queries=%u outside [1,4096]", B);
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "search: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
+    return OI_OK;
+}
+
+} // namespace
+
+extern "C" int oi_search_lists(oi_index *idx, const float *qv, const uint32_t *qt, const uint32_t *qo, uint32_t B,
+                               uint32_t depth, int location, float *cos_s, uint32_t *cos_d, uint32_t *cos_c,
+                               float *bm_s, uint32_t *bm_d, uint32_t *bm_c) {
+    OI_CHECK(check_search_args(idx, qv, qt, qo, B, depth));
+    OI_REQUIRE(cos_s && cos_d && cos_c && bm_s && bm_d && bm_c, "search_lists: null output buffer");
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    QueryStage q;
+    OI_CHECK(stage_queries(idx, qv, qt, qo, B, location, &q));
+    if (location == OI_DEVICE)
+        return search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, cos_s, cos_d, cos_c, bm_s, bm_d, bm_c);
+    hipStream_t st = ctx->stream;
+    const size_t L = (size_t)B * depth;
+    DevBuf &o = ctx->buf("lists_out");
+    OI_CHECK(o.ensure(L * 16 + (size_t)B * 8 + 64));
+    float *d_cs = o.as<float>();
+    uint32_t *d_cd = reinterpret_cast<uint32_t *>(d_cs + L);
+    float *d_bs = reinterpret_cast<float *>(d_cd + L);
+    uint32_t *d_bd = reinterpret_cast<uint32_t *>(d_bs + L);
+    uint32_t *d_cc = d_bd + L, *d_bc = d_cc + B;
+    OI_HIP_CHECK(hipMemsetAsync(o.p, 0, L * 16 + (size_t)B * 8, st));
+    OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, d_cs, d_cd, d_cc, d_bs, d_bd, d_bc));
+    OI_HIP_CHECK(hipMemcpyAsync(cos_s, d_cs, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(cos_d, d_cd, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(bm_s, d_bs, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(bm_d, d_bd, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(cos_c, d_cc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(bm_c, d_bc, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return check_overflow_locked(ctx);
+}
+
+extern "C" int oi_rrf_fuse(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a, const uint32_t *docs_b,
+                           const uint32_t *counts_b, uint32_t B, uint32_t depth, uint32_t k, int location,
+                           float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(docs_a && counts_a && docs_b && counts_b && scores_out && docs_out && counts_out, "rrf: null buffer");
+    if (B == 0) return OI_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (location == OI_DEVICE)
+        return oi_launch_rrf(ctx, docs_a, counts_a, docs_b, counts_b, B, depth, k, scores_out, docs_out, counts_out);
+    hipStream_t st = ctx->stream;
+    const size_t L = (size_t)B * depth, K = (size_t)B * k;
+    DevBuf &w = ctx->buf("rrf_io");
+    OI_CHECK(w.ensure((2 * L + 2 * (size_t)B + 2 * K + B) * 4 + 64));
+    uint32_t *d_a = w.as<uint32_t>(), *d_b = d_a + L, *d_ca = d_b + L, *d_cb = d_ca + B;
+    float *d_so = reinterpret_cast<float *>(d_cb + B);
+    uint32_t *d_do = reinterpret_cast<uint32_t *>(d_so + K), *d_co = d_do + K;
+    OI_HIP_CHECK(hipMemcpyAsync(d_a, docs_a, L * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(d_b, docs_b, L * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(d_ca, counts_a, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(d_cb, counts_b, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemsetAsync(d_so, 0, (2 * K + B) * 4, st));
+    OI_CHECK(oi_launch_rrf(ctx, d_a, d_ca, d_b, d_cb, B, depth, k, d_so, d_do, d_co));
+    OI_HIP_CHECK(hipMemcpyAsync(scores_out, d_so, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(docs_out, d_do, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
+}
+
+extern "C" int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *docs, const uint32_t *counts,
+                              uint32_t n_shards, uint32_t B, uint32_t depth, int location, float *scores_out,
+                              uint32_t *docs_out, uint32_t *counts_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(scores && docs && counts && scores_out && docs_out && counts_out, "merge: null buffer");
+    OI_REQUIRE(n_shards >= 1 && n_shards <= 1024, "merge: n_shards=%u outside [1,1024]", n_shards);
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "merge: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
+    if (B == 0) return OI_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t cap = n_shards * depth;
+    DevBuf &flag = ctx->buf("state_flag");
+    if (!flag.p) {
+        OI_CHECK(flag.ensure(16));
+        OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, st));
+    }
+    DevBuf &pk = ctx->buf("merge_pool"), &pc = ctx->buf("merge_counts");
+    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * cap));
+    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)B));
+    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), nullptr, cap, cap, flag.as<uint32_t>()};
+    const size_t Lin = (size_t)n_shards * B * depth, Cin = (size_t)n_shards * B, L = (size_t)B * depth;
+    if (location == OI_DEVICE) {
+        OI_CHECK(oi_launch_lists_to_pool(ctx, scores, docs, counts, n_shards, B, depth, pool));
+        return oi_launch_select(ctx, pool, B, depth, false, scores_out, docs_out, counts_out, depth);
+    }
+    DevBuf &w = ctx->buf("merge_io");
+    OI_CHECK(w.ensure((2 * Lin + Cin + 2 * L + B) * 4 + 64));
+    float *d_s = w.as<float>();
+    uint32_t *d_d = reinterpret_cast<uint32_t *>(d_s + Lin), *d_c = d_d + Lin;
+    float *d_so = reinterpret_cast<float *>(d_c + Cin);
+    uint32_t *d_do = reinterpret_cast<uint32_t *>(d_so + L), *d_co = d_do + L;
+    OI_HIP_CHECK(hipMemcpyAsync(d_s, scores, Lin * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(d_d, docs, Lin * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(d_c, counts, Cin * 4, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemsetAsync(d_so, 0, (2 * L + B) * 4, st));
+    OI_CHECK(oi_launch_lists_to_pool(ctx, d_s, d_d, d_c, n_shards, B, depth, pool));
+    OI_CHECK(oi_launch_select(ctx, pool, B, depth, false, d_so, d_do, d_co, depth));
+    OI_HIP_CHECK(hipMemcpyAsync(scores_out, d_so, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(docs_out, d_do, L * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
+}
+
+extern "C" int oi_search(oi_index *idx, const float *qv, const uint32_t *qt, const uint32_t *qo, uint32_t B,
+                         uint32_t depth, uint32_t k, int location, float *scores_out, uint32_t *docs_out,
+                         uint32_t *counts_out) {
+    OI_CHECK(check_search_args(idx, qv, qt, qo, B, depth));
+    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH, "search: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
+    OI_REQUIRE(scores_out && docs_out && counts_out, "search: null output buffer");
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    QueryStage q;
+    OI_CHECK(stage_queries(idx, qv, qt, qo, B, location, &q));
+    const size_t L = (size_t)B * depth, K = (size_t)B * k;
+    DevBuf &o = ctx->buf("search_lists");
+    OI_CHECK(o.ensure(L * 16 + (size_t)B * 8 + 64));
+    float *d_cs = o.as<float>();
+    uint32_t *d_cd = reinterpret_cast<uint32_t *>(d_cs + L);
+    float *d_bs = reinterpret_cast<float *>(d_cd + L);
+    uint32_t *d_bd = reinterpret_cast<uint32_t *>(d_bs + L);
+    uint32_t *d_cc = d_bd + L, *d_bc = d_cc + B;
+    OI_HIP_CHECK(hipMemsetAsync(d_cc, 0, (size_t)B * 8, st));
+    OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, d_cs, d_cd, d_cc, d_bs, d_bd, d_bc));
+    if (location == OI_DEVICE)
+        return oi_launch_rrf(ctx, d_cd, d_cc, d_bd, d_bc, B, depth, k, scores_out, docs_out, counts_out);
+    DevBuf &f = ctx->buf("search_out");
+    OI_CHECK(f.ensure((2 * K + B) * 4 + 64));
+    float *d_so = f.as<float>();
+    uint32_t *d_do = reinterpret_cast<uint32_t *>(d_so + K), *d_co = d_do + K;
+    OI_HIP_CHECK(hipMemsetAsync(f.p, 0, (2 * K + B) * 4, st));
+    OI_CHECK(oi_launch_rrf(ctx, d_cd, d_cc, d_bd, d_bc, B, depth, k, d_so, d_do, d_co));
+    OI_HIP_CHECK(hipMemcpyAsync(scores_out, d_so, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(docs_out, d_do, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return check_overflow_locked(ctx);
+}

@@ -1,0 +1,394 @@
+// bm25.hip -- blocked inverted index with precomputed BM25 impacts + term-at-a-time query.
+//
+// Builder-defined (the reference has no BM25).  Parameters:
+//   k1 = 1.2, b = 0.75, idf_t = (float) ln(1 + (N - df + 0.5)/(df + 0.5))   (double, then rounded)
+//   Kd  = k1 * ((1 - b) + b * (dl / avgdl))          every op rounded to f32
+//   w   = (tf * (k1 + 1)) / (tf + Kd)                every op rounded to f32  ("impact")
+//   score(d) = sum over query terms, in query order, of idf_t * w(t, d)      f32 adds from +0
+// Every f32 op is written with an explicit round-to-nearest intrinsic so no flag can
+// fuse or reorder it: scores are bit-identical to the CPU oracle's.
+//
+// Layout.  Docs are cut into blocks of R = 32768 consecutive ids.  Postings are sorted by
+// (block, term, doc) and stored as {doc_in_block u32, impact f32}; cell_start[block*V + term]
+// is where that (block, term) run begins.  A query workgroup owns one doc block: its R f32
+// accumulators live in LDS (128 KiB), each query term's run is streamed once with coalesced
+// 8-byte loads, and a doc appears at most once per run, so accumulation needs no atomics and
+// has a fixed order.  Candidates leave the block as 64-bit rank keys into the query's pool.
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "oi_device.h"
+#include "oi_internal.h"
+
+#define BM_R OI_BM25_BLOCK_DOCS
+#define BM_R_LOG2 15
+#define BM_THREADS 1024
+#define BM_K1 1.2f
+#define BM_B 0.75f
+
+struct Posting {
+    uint32_t dib;  // doc index within its block
+    float impact;
+};
+
+// key = block (17 bits) | term (32 bits) | doc_in_block (15 bits)
+__device__ __forceinline__ uint64_t bm_key(uint64_t doc, uint32_t term) {
+    return ((doc >> BM_R_LOG2) << 47) | ((uint64_t)term << BM_R_LOG2) | (doc & (BM_R - 1));
+}
+
+// ------------------------------------------------------------------ index build
+__global__ void bm_make_keys_kernel(const uint32_t *terms, const uint64_t *offsets, uint64_t n_docs,
+                                    uint32_t vocab, uint64_t *keys, uint32_t *doc_len, uint32_t *bad) {
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_docs;
+         d += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t lo = offsets[d], hi = offsets[d + 1];
+        doc_len[d] = (uint32_t)(hi - lo);
+        for (uint64_t i = lo; i < hi; ++i) {
+            const uint32_t t = terms[i];
+            if (t >= vocab) *bad = 1u;
+            keys[i] = bm_key(d, t);
+        }
+    }
+}
+
+__global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t vocab, uint32_t *df,
+                                uint32_t *cell_count) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = uniq[i];
+        const uint32_t term = (uint32_t)(k >> BM_R_LOG2);
+        const uint64_t block = k >> 47;
+        atomicAdd(&df[term], 1u);
+        atomicAdd(&cell_count[block * vocab + term], 1u);
+    }
+}
+
+__global__ void bm_impact_kernel(const uint64_t *uniq, const uint32_t *tf, uint64_t n,
+                                 const uint32_t *doc_len, float avgdl, Posting *postings) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = uniq[i];
+        const uint32_t dib = (uint32_t)(k & (BM_R - 1));
+        const uint64_t doc = ((k >> 47) << BM_R_LOG2) | dib;
+        const float ratio = __fdiv_rn((float)doc_len[doc], avgdl);
+        const float kd = __fmul_rn(BM_K1, __fadd_rn(1.0f - BM_B, __fmul_rn(BM_B, ratio)));
+        const float ftf = (float)tf[i];
+        Posting p;
+        p.dib = dib;
+        p.impact = __fdiv_rn(__fmul_rn(ftf, BM_K1 + 1.0f), __fadd_rn(ftf, kd));
+        postings[i] = p;
+    }
+}
+
+int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets) {
+    oi_ctx *ctx = idx->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t n = idx->n_docs;
+    uint64_t total = 0;
+    OI_HIP_CHECK(hipMemcpyAsync(&total, d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    OI_REQUIRE(total < 0xFFFFFFFFull, "bm25: %llu tokens in one shard (limit 2^32-1)", (unsigned long long)total);
+    idx->total_tokens = total;
+    idx->n_blocks = (uint32_t)((n + BM_R - 1) / BM_R);
+    OI_REQUIRE(idx->n_blocks < (1u << 17), "bm25: too many doc blocks");
+    OI_REQUIRE((uint64_t)idx->n_blocks * idx->vocab < 0xFFFFFFFFull, "bm25: blocks x vocab exceeds 2^32");
+
+    OI_CHECK(idx->doc_len.ensure(sizeof(uint32_t) * (n ? n : 1)));
+    OI_CHECK(idx->df_local.ensure(sizeof(uint32_t) * idx->vocab));
+    OI_HIP_CHECK(hipMemsetAsync(idx->df_local.p, 0, sizeof(uint32_t) * idx->vocab, st));
+    idx->n_postings = 0;
+    if (total == 0) {
+        if (n) OI_HIP_CHECK(hipMemsetAsync(idx->doc_len.p, 0, sizeof(uint32_t) * n, st));
+        idx->forward_set = true;
+        idx->finalized = false;
+        return OI_OK;
+    }
+    DevBuf keys, keys_sorted, temp, flag, runs;
+    OI_CHECK(keys.ensure(sizeof(uint64_t) * total));
+    OI_CHECK(keys_sorted.ensure(sizeof(uint64_t) * total));
+    OI_CHECK(flag.ensure(16));
+    OI_CHECK(runs.ensure(16));
+    OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, st));
+    {
+        uint64_t blocks = (n + 255) / 256;
+        if (blocks > 65535) blocks = 65535;
+        hipLaunchKernelGGL(bm_make_keys_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_terms, d_offsets, n,
+                           idx->vocab, keys.as<uint64_t>(), idx->doc_len.as<uint32_t>(), flag.as<uint32_t>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    size_t temp_bytes = 0;
+    OI_HIP_CHECK(rocprim::radix_sort_keys(nullptr, temp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(),
+                                          (size_t)total, 0u, 64u, st));
+    OI_CHECK(temp.ensure(temp_bytes ? temp_bytes : 16));
+    OI_HIP_CHECK(rocprim::radix_sort_keys(temp.p, temp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(),
+                                          (size_t)total, 0u, 64u, st));
+    // run-length encode: unique (block, term, doc) keys, run length = term frequency
+    OI_CHECK(idx->uniq_keys.ensure(sizeof(uint64_t) * total));
+    OI_CHECK(idx->tf.ensure(sizeof(uint32_t) * total));
+    size_t temp2 = 0;
+    OI_HIP_CHECK(rocprim::run_length_encode(nullptr, temp2, keys_sorted.as<uint64_t>(), (unsigned int)total,
+                                            idx->uniq_keys.as<uint64_t>(), idx->tf.as<uint32_t>(),
+                                            runs.as<uint32_t>(), st));
+    OI_CHECK(temp.ensure(temp2 ? temp2 : 16));
+    OI_HIP_CHECK(rocprim::run_length_encode(temp.p, temp2, keys_sorted.as<uint64_t>(), (unsigned int)total,
+                                            idx->uniq_keys.as<uint64_t>(), idx->tf.as<uint32_t>(),
+                                            runs.as<uint32_t>(), st));
+    uint32_t h_runs = 0, h_bad = 0;
+    OI_HIP_CHECK(hipMemcpyAsync(&h_runs, runs.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(&h_bad, flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    keys.release(); keys_sorted.release(); temp.release(); flag.release(); runs.release();
+    OI_REQUIRE(!h_bad, "bm25: a term id is >= vocab (%u)", idx->vocab);
+    idx->n_postings = h_runs;
+
+    // local df and the (block, term) cell histogram
+    const uint64_t cells = (uint64_t)idx->n_blocks * idx->vocab;
+    OI_CHECK(idx->cell_start.ensure(sizeof(uint32_t) * (cells + 1)));
+    OI_HIP_CHECK(hipMemsetAsync(idx->cell_start.p, 0, sizeof(uint32_t) * (cells + 1), st));
+    {
+        uint64_t blocks = (idx->n_postings + 255) / 256;
+        if (blocks > 65535) blocks = 65535;
+        hipLaunchKernelGGL(bm_count_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),
+                           idx->n_postings, idx->vocab, idx->df_local.as<uint32_t>(),
+                           idx->cell_start.as<uint32_t>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    // exclusive scan in place -> cell_start[c] = first posting of cell c; last entry = n_postings
+    size_t temp3 = 0;
+    DevBuf t3;
+    OI_HIP_CHECK(rocprim::exclusive_scan(nullptr, temp3, idx->cell_start.as<uint32_t>(),
+                                         idx->cell_start.as<uint32_t>(), 0u, (size_t)(cells + 1),
+                                         rocprim::plus<uint32_t>(), st));
+    OI_CHECK(t3.ensure(temp3 ? temp3 : 16));
+    OI_HIP_CHECK(rocprim::exclusive_scan(t3.p, temp3, idx->cell_start.as<uint32_t>(),
+                                         idx->cell_start.as<uint32_t>(), 0u, (size_t)(cells + 1),
+                                         rocprim::plus<uint32_t>(), st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    t3.release();
+    idx->forward_set = true;
+    idx->finalized = false;
+    return OI_OK;
+}
+
+int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, const uint32_t *global_df_host) {
+    oi_ctx *ctx = idx->ctx;
+    hipStream_t st = ctx->stream;
+    OI_REQUIRE(global_n >= idx->n_docs && global_n > 0, "bm25: global_n_docs < local n_docs");
+    std::vector<uint32_t> df(idx->vocab);
+    if (global_df_host) memcpy(df.data(), global_df_host, sizeof(uint32_t) * idx->vocab);
+    else {
+        OI_HIP_CHECK(hipMemcpyAsync(df.data(), idx->df_local.p, sizeof(uint32_t) * idx->vocab,
+                                    hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    std::vector<float> idf(idx->vocab);
+    const double N = (double)global_n;
+    for (uint32_t t = 0; t < idx->vocab; ++t) {
+        const double d = (double)df[t];
+        idf[t] = (float)std::log(1.0 + (N - d + 0.5) / (d + 0.5));
+    }
+    OI_CHECK(idx->idf.ensure(sizeof(float) * idx->vocab));
+    OI_HIP_CHECK(hipMemcpyAsync(idx->idf.p, idf.data(), sizeof(float) * idx->vocab, hipMemcpyHostToDevice, st));
+    const float avgdl = (float)((double)global_tokens / (double)global_n);
+    if (idx->n_postings) {
+        OI_CHECK(idx->postings.ensure(sizeof(Posting) * idx->n_postings));
+        uint64_t blocks = (idx->n_postings + 255) / 256;
+        if (blocks > 65535) blocks = 65535;
+        hipLaunchKernelGGL(bm_impact_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),
+                           idx->tf.as<uint32_t>(), idx->n_postings, idx->doc_len.as<uint32_t>(), avgdl,
+                           idx->postings.as<Posting>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    OI_HIP_CHECK(hipStreamSynchronize(st)); // idf vector goes out of scope
+    idx->uniq_keys.release();
+    idx->tf.release();
+    idx->finalized = true;
+    return OI_OK;
+}
+
+// ------------------------------------------------------------------ query
+// Called by wave 0 (all 64 lanes).  Finds the bin holding the kk-th entry counted from the
+// TOP bin down; *above = entries in higher bins.  nbins is a multiple of 64.
+__device__ void bm_find_kth_from_top(const uint32_t *hist, uint32_t nbins, uint32_t kk, uint32_t *bin_out,
+                                     uint32_t *above_out) {
+    const uint32_t lane = threadIdx.x & 63, per = nbins >> 6;
+    const uint32_t top = nbins - lane * per; // lane 0 owns the highest bins [top-per, top)
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < per; ++i) mine += hist[top - 1 - i];
+    uint32_t incl = mine; // inclusive scan over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t v = __shfl_up(incl, o, OI_WAVE);
+        if ((int)lane >= o) incl += v;
+    }
+    const unsigned long long ball = __ballot(incl >= kk);
+    const uint32_t owner = ball ? (uint32_t)__builtin_ctzll(ball) : 63u;
+    if (lane == owner) {
+        uint32_t cum = incl - mine;
+        uint32_t b = top - 1;
+        for (uint32_t i = 0; i < per; ++i, --b) {
+            const uint32_t c = hist[b];
+            if (cum + c >= kk || i == per - 1) break;
+            cum += c;
+        }
+        *bin_out = b;
+        *above_out = cum;
+    }
+}
+
+__global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
+    const Posting *__restrict__ postings, const uint32_t *__restrict__ cell_start,
+    const float *__restrict__ idf, uint32_t vocab, uint32_t doc_id_base, const uint32_t *__restrict__ q_terms,
+    const uint32_t *__restrict__ q_offsets, uint32_t n_queries, uint32_t depth, uint64_t *pools,
+    uint32_t *pool_counts, uint64_t pool_stride, uint32_t pool_cap, uint32_t *overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *acc = reinterpret_cast<float *>(smem);                       // BM_R
+    uint32_t *hist = reinterpret_cast<uint32_t *>(acc + BM_R);          // 2048
+    uint64_t *list = reinterpret_cast<uint64_t *>(hist + 2048);         // OI_MAX_DEPTH
+    uint32_t *scan = reinterpret_cast<uint32_t *>(list + OI_MAX_DEPTH); // 16 wave totals + scratch
+    uint32_t *sh = scan + 32;                                           // [0] touched [1] list_cnt [2] base [3] bin [4] above
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t blk = blockIdx.x;
+    const uint64_t cell0 = (uint64_t)blk * vocab;
+    const uint32_t doc0 = doc_id_base + blk * BM_R;
+
+    for (uint32_t i = tid; i < BM_R / 4; i += BM_THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (uint32_t q = blockIdx.y; q < n_queries; q += gridDim.y) {
+        if (tid < 8) sh[tid] = 0;
+        __syncthreads();
+        const uint32_t t_begin = q_offsets[q], t_end = q_offsets[q + 1];
+        // ---- accumulate, one term at a time (fixed order; a doc occurs once per run)
+        for (uint32_t ti = t_begin; ti < t_end; ++ti) {
+            const uint32_t t = q_terms[ti];
+            if (t >= vocab) continue;
+            const uint32_t s = cell_start[cell0 + t], e = cell_start[cell0 + t + 1];
+            if (s == e) continue;
+            const float w = idf[t];
+            uint32_t fresh = 0;
+            for (uint32_t i = s + tid; i < e; i += BM_THREADS) {
+                const Posting p = postings[i];
+                const float old = acc[p.dib];
+                acc[p.dib] = __fadd_rn(old, __fmul_rn(w, p.impact));
+                fresh += old == 0.0f;
+            }
+            if (fresh) atomicAdd(&sh[0], fresh);
+            __syncthreads();
+        }
+        const uint32_t touched = sh[0];
+        if (touched == 0) { __syncthreads(); continue; }
+
+        if (touched <= depth) {
+            // ---- sparse emit: walk the same runs again; the first run to reach a doc takes it
+            for (uint32_t ti = t_begin; ti < t_end; ++ti) {
+                const uint32_t t = q_terms[ti];
+                if (t >= vocab) continue;
+                const uint32_t s = cell_start[cell0 + t], e = cell_start[cell0 + t + 1];
+                if (s == e) continue;
+                for (uint32_t i = s + tid; i < e; i += BM_THREADS) {
+                    const uint32_t dib = postings[i].dib;
+                    const float v = acc[dib];
+                    if (v != 0.0f) {
+                        acc[dib] = 0.0f;
+                        list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + dib);
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            // ---- dense: exact local top-`depth` by radix select over the LDS accumulators.
+            // Scores are > 0, so their bit patterns order like the floats.
+            uint32_t kk = depth, prefix = 0;
+            // pass A: bits 31..21, pass B: bits 20..10, pass C: bits 9..0
+            for (int pass = 0; pass < 3; ++pass) {
+                const uint32_t nb = pass == 2 ? 1024u : 2048u;
+                for (uint32_t i = tid; i < 2048; i += BM_THREADS) hist[i] = 0;
+                __syncthreads();
+#pragma unroll 4
+                for (uint32_t i = tid; i < BM_R; i += BM_THREADS) {
+                    const uint32_t bits = __float_as_uint(acc[i]);
+                    if (bits == 0) continue;
+                    if (pass == 0) atomicAdd(&hist[bits >> 21], 1u);
+                    else if (pass == 1) { if ((bits >> 21) == prefix) atomicAdd(&hist[(bits >> 10) & 2047u], 1u); }
+                    else { if ((bits >> 10) == prefix) atomicAdd(&hist[bits & 1023u], 1u); }
+                }
+                __syncthreads();
+                if (wv == 0) bm_find_kth_from_top(hist, nb, kk, &sh[3], &sh[4]);
+                __syncthreads();
+                prefix = pass == 2 ? ((prefix << 10) | sh[3]) : ((prefix << 11) | sh[3]);
+                kk -= sh[4];
+                __syncthreads();
+            }
+            const uint32_t T = prefix;   // bits of the depth-th largest score
+            const uint32_t n_ties = kk;  // how many docs scoring exactly T to keep: lowest ids first
+            // every thread owns 32 consecutive docs so that ties are taken in doc order
+            const uint32_t base = tid * (BM_R / BM_THREADS);
+            uint32_t eq = 0;
+#pragma unroll 4
+            for (uint32_t i = 0; i < BM_R / BM_THREADS; ++i) eq += __float_as_uint(acc[base + i]) == T;
+            uint32_t incl = eq;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t v = __shfl_up(incl, o, OI_WAVE);
+                if ((int)lane >= o) incl += v;
+            }
+            if (lane == 63) scan[wv] = incl;
+            __syncthreads();
+            uint32_t before = incl - eq;
+            for (uint32_t w2 = 0; w2 < wv; ++w2) before += scan[w2];
+#pragma unroll 2
+            for (uint32_t i = 0; i < BM_R / BM_THREADS; ++i) {
+                const float v = acc[base + i];
+                const uint32_t bits = __float_as_uint(v);
+                bool take = bits > T;
+                if (bits == T) { take = before < n_ties; ++before; }
+                if (take) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + base + i);
+                acc[base + i] = 0.0f;
+            }
+            __syncthreads();
+        }
+        // ---- flush this block's candidates to the query's pool (one reservation per block)
+        const uint32_t cnt = sh[1];
+        if (tid == 0) sh[2] = atomicAdd(&pool_counts[q], cnt);
+        __syncthreads();
+        const uint32_t base_out = sh[2];
+        uint64_t *pool = pools + (uint64_t)q * pool_stride;
+        for (uint32_t i = tid; i < cnt; i += BM_THREADS) {
+            if (base_out + i < pool_cap) pool[base_out + i] = list[i];
+            else *overflow = 1u;
+        }
+        __syncthreads();
+    }
+}
+
+#define BM_SMEM (BM_R * 4 + 2048 * 4 + OI_MAX_DEPTH * 8 + 32 * 4 + 8 * 4)
+
+int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
+                   uint32_t n_queries, uint32_t depth, const PoolView &pool) {
+    oi_ctx *ctx = idx->ctx;
+    if (n_queries == 0 || idx->n_postings == 0 || idx->n_blocks == 0) return OI_OK;
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "bm25: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_block_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, BM_SMEM));
+        attr_set = true;
+    }
+    // one workgroup per CU is resident (128 KiB of LDS); split the batch so the grid has
+    // about 4 workgroups per CU when the corpus has few blocks
+    uint32_t ysplit = (uint32_t)((4ull * ctx->num_cus + idx->n_blocks - 1) / idx->n_blocks);
+    if (ysplit < 1) ysplit = 1;
+    if (ysplit > n_queries) ysplit = n_queries;
+    ProfScope ps(ctx, "bm25");
+    hipLaunchKernelGGL(bm25_block_kernel, dim3(idx->n_blocks, ysplit), dim3(BM_THREADS), BM_SMEM, ctx->stream,
+                       idx->postings.as<Posting>(), idx->cell_start.as<uint32_t>(), idx->idf.as<float>(),
+                       idx->vocab, idx->doc_id_base, d_q_terms, d_q_offsets, n_queries, depth, pool.keys,
+                       pool.counts, pool.stride, pool.cap, pool.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

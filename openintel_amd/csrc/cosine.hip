@@ -1,0 +1,249 @@
+// cosine.hip -- brute-force dot-product scoring of a query batch against corpus rows,
+// fused with a threshold filter: only scores >= the per-query running threshold are
+// appended to that query's candidate pool, so the N x B score matrix never exists.
+//
+// Builder-defined (the reference has no embeddings).
+//
+//   cosine_gemv_filter<NQ>   B <= 8 : HBM-bound.  One wave per row, 16-byte loads,
+//                            queries in registers, butterfly reduction.
+//   cosine_mfma_filter<NQT>  B  > 8 : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled.
+//                            (v1 tile kernel; the K-split register-resident kernel is in
+//                            cosine_ksplit.hip)
+#include "oi_device.h"
+#include "oi_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ GEMV (B <= 8)
+template <int NQ>
+__global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restrict__ rows, uint64_t row_begin,
+                                                           uint64_t row_end, uint32_t dim,
+                                                           const float *__restrict__ queries,
+                                                           uint32_t doc_id_base, uint64_t *pools,
+                                                           uint32_t *pool_counts, const uint32_t *tau_keys,
+                                                           uint64_t pool_stride, uint32_t pool_cap,
+                                                           uint32_t *overflow) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t nvec = dim >> 2; // float4 per row
+    // this lane's slice of every query, kept in registers (dim <= 1024 -> <= 4 float4 per query)
+    float4 qv[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = lane + 64u * c;
+            qv[q][c] = v < nvec ? reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim)[v]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    uint32_t tau = 0;
+    if (lane < NQ) tau = tau_keys[lane];
+
+    for (uint64_t r = row_begin + wave; r < row_end; r += n_waves) {
+        const float4 *row = reinterpret_cast<const float4 *>(rows + r * dim);
+        float4 x[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t v = lane + 64u * c;
+            x[c] = v < nvec ? row[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a = fmaf(x[c].x, qv[q][c].x, a);
+                a = fmaf(x[c].y, qv[q][c].y, a);
+                a = fmaf(x[c].z, qv[q][c].z, a);
+                a = fmaf(x[c].w, qv[q][c].w, a);
+            }
+            a = oi_wave_sum(a);
+            if ((int)lane == q) mine = a;
+        }
+        if (lane < NQ && mine == mine && oi_f32_key(mine) >= tau)
+            oi_pool_append(pools + (uint64_t)lane * pool_stride, pool_counts + lane, pool_cap, overflow,
+                           oi_rank_key(mine, doc_id_base + (uint32_t)r));
+    }
+}
+
+// ------------------------------------------------------------------ MFMA tile kernel (v1)
+// Workgroup = 4 waves; tile = 128 rows x (32*NQT) queries; K stepped by 32 through LDS.
+// Wave w owns rows [32w, 32w+32) of the tile and all query tiles.
+// MFMA 32x32x2 operand map: lane l supplies A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] in accumulator register r.
+#define CM_ROWS 128
+#define CM_BK 32
+#define CM_LD (CM_BK + 1) // +1 float: conflict-free ds_read_b32 down a column
+
+template <int NQT>
+__global__ __launch_bounds__(256) void cosine_mfma_filter(const float *__restrict__ rows, uint64_t row_begin,
+                                                           uint64_t row_end, uint32_t dim,
+                                                           const float *__restrict__ queries, // [32*NQT][dim], zero padded
+                                                           uint32_t n_queries, uint32_t doc_id_base,
+                                                           uint64_t *pools, uint32_t *pool_counts,
+                                                           const uint32_t *tau_keys, uint64_t pool_stride,
+                                                           uint32_t pool_cap, uint32_t *overflow) {
+    __shared__ float sA[CM_ROWS * CM_LD];
+    __shared__ float sQ[32 * NQT * CM_LD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t li = lane & 31, lh = lane >> 5;
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + CM_ROWS - 1) / CM_ROWS;
+
+    uint32_t tau[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32u * t + li;
+        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+    }
+
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t r0 = row_begin + tile * CM_ROWS;
+        f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        for (uint32_t k0 = 0; k0 < dim; k0 += CM_BK) {
+            __syncthreads();
+            // stage A: 128 rows x 32 floats = 1024 float4; thread -> 4 of them
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t f = tid + 256u * i; // float4 index
+                const uint32_t rr = f >> 3, cc = (f & 7u) << 2;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r0 + rr < row_end && k0 + cc < dim)
+                    v = *reinterpret_cast<const float4 *>(rows + (r0 + rr) * dim + k0 + cc);
+                float *d = sA + rr * CM_LD + cc;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            // stage Q: 32*NQT rows x 32 floats
+#pragma unroll
+            for (int i = 0; i < NQT; ++i) {
+                const uint32_t f = tid + 256u * i;
+                const uint32_t rr = f >> 3, cc = (f & 7u) << 2;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + cc < dim) v = *reinterpret_cast<const float4 *>(queries + (uint64_t)rr * dim + k0 + cc);
+                float *d = sQ + rr * CM_LD + cc;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < CM_BK; kk += 2) {
+                const float a = sA[(32u * w + li) * CM_LD + kk + lh];
+#pragma unroll
+                for (int t = 0; t < NQT; ++t) {
+                    const float b = sQ[(32u * t + li) * CM_LD + kk + lh];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue: this lane holds column (query) li of each query tile, 16 rows
+#pragma unroll
+        for (int t = 0; t < NQT; ++t) {
+            const uint32_t q = 32u * t + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint64_t row = r0 + 32u * w + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float s = acc[t][r];
+                if (row < row_end && s == s && oi_f32_key(s) >= tau[t])
+                    oi_pool_append(pools + (uint64_t)q * pool_stride, pool_counts + q, pool_cap, overflow,
+                                   oi_rank_key(s, doc_id_base + (uint32_t)row));
+            }
+        }
+    }
+}
+
+uint32_t oi_cosine_query_padding(uint32_t n_queries) {
+    if (n_queries <= 8) return n_queries;
+    return (n_queries + 31u) & ~31u;
+}
+
+int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end,
+                           uint32_t dim, const float *d_queries, uint32_t n_queries,
+                           uint32_t n_queries_padded, uint32_t doc_id_base, const PoolView &pool) {
+    if (row_end <= row_begin || n_queries == 0) return OI_OK;
+    OI_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= OI_MAX_DIM, "cosine: dim=%u must be a multiple of 4 in [4,%u]",
+               dim, OI_MAX_DIM);
+    const uint64_t n_rows = row_end - row_begin;
+    ProfScope ps(ctx, "cosine");
+    if (n_queries <= 8) {
+        // ~8 waves per SIMD-quad worth of rows in flight; grid capped at 8 blocks per CU
+        uint64_t blocks = (n_rows + 3) / 4;
+        const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+        if (blocks > cap) blocks = cap;
+        dim3 g((uint32_t)blocks), b(256);
+#define OI_GEMV(NQ)                                                                                     \
+    hipLaunchKernelGGL(cosine_gemv_filter<NQ>, g, b, 0, ctx->stream, rows, row_begin, row_end, dim,     \
+                       d_queries, doc_id_base, pool.keys, pool.counts, pool.tau_keys, pool.stride,      \
+                       pool.cap, pool.overflow)
+        // queries beyond n_queries are not readable: dispatch on the exact count
+        switch (n_queries) {
+            case 1: OI_GEMV(1); break;
+            case 2: OI_GEMV(2); break;
+            case 3: OI_GEMV(3); break;
+            case 4: OI_GEMV(4); break;
+            case 5: OI_GEMV(5); break;
+            case 6: OI_GEMV(6); break;
+            case 7: OI_GEMV(7); break;
+            default: OI_GEMV(8); break;
+        }
+#undef OI_GEMV
+        OI_HIP_CHECK(hipGetLastError());
+        return OI_OK;
+    }
+    OI_REQUIRE(n_queries_padded % 32 == 0 && n_queries_padded >= n_queries, "cosine: bad query padding");
+    const uint64_t n_tiles = (n_rows + CM_ROWS - 1) / CM_ROWS;
+    uint64_t blocks = n_tiles;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 4;
+    if (blocks > cap) blocks = cap;
+    for (uint32_t q0 = 0; q0 < n_queries_padded; q0 += 64) {
+        const uint32_t left = n_queries_padded - q0;
+        const uint32_t nq_here = (n_queries - q0) < 64 ? (n_queries - q0) : 64;
+        PoolView p = pool;
+        p.keys += (uint64_t)q0 * pool.stride;
+        p.counts += q0;
+        p.tau_keys += q0;
+        const float *qptr = d_queries + (uint64_t)q0 * dim;
+        if (left >= 64)
+            hipLaunchKernelGGL(cosine_mfma_filter<2>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows,
+                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys, p.counts, p.tau_keys,
+                               p.stride, p.cap, p.overflow);
+        else
+            hipLaunchKernelGGL(cosine_mfma_filter<1>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows,
+                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys, p.counts, p.tau_keys,
+                               p.stride, p.cap, p.overflow);
+        OI_HIP_CHECK(hipGetLastError());
+        if (q0 + 64 >= n_queries) break;
+    }
+    return OI_OK;
+}
+
+// ------------------------------------------------------------------ row normalisation
+__global__ __launch_bounds__(256) void l2_normalize_kernel(float *rows, uint64_t n, uint32_t dim) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n; r += n_waves) {
+        float *x = rows + r * dim;
+        float ss = 0.f;
+        for (uint32_t k = lane; k < dim; k += 64) ss = fmaf(x[k], x[k], ss);
+        ss = oi_wave_sum(ss);
+        if (ss == 0.f) continue;
+        const float inv = 1.0f / sqrtf(ss);
+        for (uint32_t k = lane; k < dim; k += 64) x[k] = x[k] * inv;
+    }
+}
+
+int oi_launch_l2_normalize(oi_ctx *ctx, float *rows, uint64_t n, uint32_t dim) {
+    if (n == 0) return OI_OK;
+    uint64_t blocks = (n + 3) / 4;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, n, dim);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

@@ -1,0 +1,423 @@
+// lexicon.hip -- the reference's per-post path on gfx950.
+//
+//   LexiconAnalyzer::score        openintel src/adapters/analyzer/lexicon.rs:53-73
+//   LexiconAnalyzer::analyze      openintel src/adapters/analyzer/lexicon.rs:82-87
+//   Polarity::new                 openintel src/domain/values/polarity.rs:8-14
+//   SpeculationEngine::social_summary (the two reduction loops)
+//                                 openintel src/domain/engine/speculation_engine.rs:76-97
+//
+// Byte-parallel HBM scan: a workgroup owns 256 consecutive posts; their bytes are
+// one contiguous span of the blob, streamed through LDS in 4 KiB sub-tiles with
+// 16-byte coalesced loads (lane = 16 bytes).  Each lane finds the tokens that START
+// in its 16 bytes with SWAR byte tests, cuts them at post boundaries, and looks each
+// one up in a 256-slot perfect-hash table of the 42 lexicon words held in LDS.  Hit
+// counts accumulate per post in LDS (integer atomics: exact, order-free); the
+// polarity division happens once per post, in f64, exactly as the reference does.
+//
+// Unicode: the reference lowercases with str::to_lowercase and then splits on every
+// char that is not ASCII alphanumeric.  Only three mappings can put an ASCII char
+// into the lowercased text: A-Z -> a-z, U+212A (E2 84 AA) -> 'k', U+0130 (C4 B0) ->
+// 'i' + U+0307.  All other non-ASCII bytes separate tokens.  A lane whose window holds
+// a 0xAA or 0xB0 byte takes a (rare) exact per-char path.
+#include "oi_device.h"
+#include "oi_internal.h"
+
+#define LEX_THREADS 256
+#define LEX_PPT 256   // posts per workgroup tile
+#define LEX_SUB 4096  // bytes per sub-tile = LEX_THREADS * 16
+#define LEX_SLOTS 256
+
+struct LexEntry {
+    uint32_t k0, k1;   // chars 0-3, 4-7 (lowercase ASCII, zero padded)
+    uint32_t c8_len;   // char 8 | len << 8
+    uint32_t flags;    // 1 bull, 2 bear, 4 jargon; 0 = empty slot
+};
+
+__device__ __forceinline__ uint32_t lex_hash(uint32_t k0, uint32_t k1, uint32_t c8_len, uint32_t mult) {
+    uint32_t x = k0 * 0x9E3779B1u ^ k1 * 0x85EBCA77u ^ c8_len * 0xC2B2AE3Du;
+    x ^= x >> 15;
+    return (x * mult) >> 24;
+}
+
+// ---- SWAR helpers on 4 packed bytes -------------------------------------------
+// 0x80 in every byte whose value is in [lo, hi]; bytes >= 0x80 never match.
+__device__ __forceinline__ uint32_t swar_range(uint32_t w7, uint32_t lo, uint32_t hi) {
+    // w7 has every byte < 0x80, so the adds below never carry across bytes
+    uint32_t ge = w7 + (0x80u - lo) * 0x01010101u;
+    uint32_t gt = w7 + (0x7Fu - hi) * 0x01010101u;
+    return ge & ~gt & 0x80808080u;
+}
+// ASCII-lowercase the bytes of w; *alnum gets 0x80 per byte that is [0-9a-z] afterwards.
+__device__ __forceinline__ uint32_t swar_lower_alnum(uint32_t w, uint32_t *alnum) {
+    const uint32_t hi = w & 0x80808080u;
+    const uint32_t w7 = w & 0x7F7F7F7Fu;
+    const uint32_t up = swar_range(w7, 'A', 'Z') & ~hi;
+    const uint32_t lw = w | (up >> 2); // 0x80 >> 2 == 0x20
+    const uint32_t l7 = lw & 0x7F7F7F7Fu;
+    *alnum = (swar_range(l7, 'a', 'z') | swar_range(l7, '0', '9')) & ~hi;
+    return lw;
+}
+// bit i = byte i's 0x80 flag
+__device__ __forceinline__ uint32_t swar_movemask(uint32_t flags80) {
+    return (((flags80 >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu;
+}
+__device__ __forceinline__ bool swar_has_byte(uint32_t w, uint32_t b) {
+    uint32_t x = w ^ (b * 0x01010101u);
+    return ((x - 0x01010101u) & ~x & 0x80808080u) != 0;
+}
+__device__ __forceinline__ uint32_t byte_mask(uint32_t nbytes) { // low nbytes bytes, 0..4
+    return nbytes >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nbytes)) - 1u);
+}
+
+struct LexShared {
+    LexEntry table[LEX_SLOTS];
+    uint64_t off[LEX_PPT + 1];
+    uint32_t bull[LEX_PPT], bear[LEX_PPT], spec[LEX_PPT];
+    uint32_t text[(LEX_SUB + 32) / 4]; // [sb-16, sb+LEX_SUB+16)
+};
+
+__device__ __forceinline__ void lex_lookup(const LexShared &s, uint32_t mult, uint32_t k0, uint32_t k1,
+                                           uint32_t c8, uint32_t len, uint32_t post, LexShared &sw) {
+    const uint32_t c8_len = c8 | (len << 8);
+    const LexEntry e = s.table[lex_hash(k0, k1, c8_len, mult)];
+    if (e.flags != 0 && e.k0 == k0 && e.k1 == k1 && e.c8_len == c8_len) {
+        if (e.flags & 1u) atomicAdd(&sw.bull[post], 1u);
+        if (e.flags & 2u) atomicAdd(&sw.bear[post], 1u);
+        if (e.flags & 4u) atomicOr(&sw.spec[post], 1u);
+    }
+}
+
+// Exact per-char path for positions [lo, hi) of post range; reads the blob directly.
+__device__ bool lex_is_alnum(uint32_t c) {
+    return (c - 'a' < 26u) || (c - '0' < 10u);
+}
+__device__ void lex_slow_chunk(const uint8_t *blob, uint64_t lo, uint64_t hi, uint32_t j,
+                               LexShared &s, uint32_t mult) {
+    for (uint64_t pos = lo; pos < hi; ++pos) {
+        while (pos >= s.off[j + 1]) ++j;
+        const uint64_t pstart = s.off[j], pend = s.off[j + 1];
+        uint32_t b = blob[pos];
+        if ((b & 0xC0u) == 0x80u) continue; // continuation byte: not the start of a char
+        // first lowercased char of the char at pos
+        uint32_t first;
+        if (b < 0x80u) first = (b - 'A' < 26u) ? b + 32u : b;
+        else if (b == 0xE2u && pos + 2 < pend && blob[pos + 1] == 0x84u && blob[pos + 2] == 0xAAu) first = 'k';
+        else if (b == 0xC4u && pos + 1 < pend && blob[pos + 1] == 0xB0u) first = 'i';
+        else first = 0;
+        if (!lex_is_alnum(first)) continue;
+        if (pos > pstart) { // last lowercased char of the previous char
+            uint64_t p = pos - 1;
+            while (p > pstart && (blob[p] & 0xC0u) == 0x80u) --p;
+            uint32_t pb = blob[p], last;
+            if (pb < 0x80u) last = (pb - 'A' < 26u) ? pb + 32u : pb;
+            else if (pb == 0xE2u && p + 3 == pos && blob[p + 1] == 0x84u && blob[p + 2] == 0xAAu) last = 'k';
+            else last = 0; // includes U+0130 -> 'i' U+0307: the last char is the combining dot
+            if (lex_is_alnum(last)) continue;
+        }
+        // token start: walk its chars
+        uint32_t len = 0, k0 = 0, k1 = 0, c8 = 0;
+        uint64_t p = pos;
+        while (p < pend) {
+            uint32_t c, adv;
+            bool ends = false;
+            uint32_t bb = blob[p];
+            if (bb < 0x80u) { c = (bb - 'A' < 26u) ? bb + 32u : bb; adv = 1; }
+            else if (bb == 0xE2u && p + 2 < pend && blob[p + 1] == 0x84u && blob[p + 2] == 0xAAu) { c = 'k'; adv = 3; }
+            else if (bb == 0xC4u && p + 1 < pend && blob[p + 1] == 0xB0u) { c = 'i'; adv = 2; ends = true; }
+            else break;
+            if (!lex_is_alnum(c)) break;
+            if (len < 4) k0 |= c << (8 * len);
+            else if (len < 8) k1 |= c << (8 * (len - 4));
+            else if (len == 8) c8 = c;
+            ++len;
+            p += adv;
+            if (ends) break;
+        }
+        if (len <= 9) lex_lookup(s, mult, k0, k1, c8, len, j, s);
+    }
+}
+
+__global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
+                                                              uint64_t n, uint64_t blob_bytes,
+                                                              const LexEntry *table, uint32_t mult,
+                                                              double *pol_out, uint8_t *spec_out) {
+    __shared__ __attribute__((aligned(16))) LexShared s;
+    const uint32_t tid = threadIdx.x;
+    reinterpret_cast<uint4 *>(s.table)[tid] = reinterpret_cast<const uint4 *>(table)[tid];
+
+    const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * LEX_PPT;
+        const uint32_t np = (uint32_t)((n - p0) < LEX_PPT ? (n - p0) : LEX_PPT);
+        __syncthreads(); // previous tile fully written out
+        if (tid <= np) s.off[tid] = offsets[p0 + tid];
+        if (tid == 0 && np == LEX_PPT) s.off[LEX_PPT] = offsets[p0 + LEX_PPT];
+        s.bull[tid] = 0; s.bear[tid] = 0; s.spec[tid] = 0;
+        __syncthreads();
+        const uint64_t byte_begin = s.off[0], byte_end = s.off[np];
+
+        for (uint64_t sb = byte_begin & ~(uint64_t)15; sb < byte_end; sb += LEX_SUB) {
+            // ---- stage [sb-16, sb+LEX_SUB+16) -> LDS, 16 B per lane, zeros outside the blob
+            {
+                const uint64_t a = sb + (uint64_t)tid * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a + 16 <= blob_bytes) v = *reinterpret_cast<const uint4 *>(blob + a);
+                else if (a < blob_bytes) {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t i = 0; a + i < blob_bytes; ++i) w[i >> 2] |= (uint32_t)blob[a + i] << (8 * (i & 3));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                reinterpret_cast<uint4 *>(s.text)[1 + tid] = v;
+                if (tid < 2) {
+                    // halo: tid 0 -> 16 bytes before sb, tid 1 -> 16 bytes after the sub-tile
+                    const bool left = tid == 0;
+                    uint4 h = make_uint4(0, 0, 0, 0);
+                    if (left) {
+                        if (sb >= 16) h = *reinterpret_cast<const uint4 *>(blob + sb - 16);
+                    } else {
+                        const uint64_t r = sb + LEX_SUB;
+                        if (r + 16 <= blob_bytes) h = *reinterpret_cast<const uint4 *>(blob + r);
+                        else if (r < blob_bytes) {
+                            uint32_t w[4] = {0, 0, 0, 0};
+                            for (uint32_t i = 0; r + i < blob_bytes; ++i) w[i >> 2] |= (uint32_t)blob[r + i] << (8 * (i & 3));
+                            h = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                    reinterpret_cast<uint4 *>(s.text)[left ? 0 : 1 + LEX_THREADS] = h;
+                }
+            }
+            __syncthreads();
+
+            const uint64_t c0 = sb + (uint64_t)tid * 16;
+            const uint64_t lo = c0 > byte_begin ? c0 : byte_begin;
+            const uint64_t hi = (c0 + 16) < byte_end ? (c0 + 16) : byte_end;
+            if (lo < hi) {
+                // post containing lo: largest j with off[j] <= lo
+                uint32_t jl = 0, jr = np; // invariant off[jl] <= lo < off[jr]
+                while (jr - jl > 1) {
+                    uint32_t mid = (jl + jr) >> 1;
+                    if (s.off[mid] <= lo) jl = mid; else jr = mid;
+                }
+                uint32_t j = jl;
+                // window words: bytes [c0-4, c0+32)
+                const uint32_t wbase = tid * 4 + 3;
+                uint32_t W[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) W[i] = s.text[wbase + i];
+                bool special = false;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) special = special || swar_has_byte(W[i], 0xAAu) || swar_has_byte(W[i], 0xB0u);
+                if (special) {
+                    lex_slow_chunk(blob, lo, hi, j, s, mult);
+                } else {
+                    // alnum bit per byte of [c0-1, c0+16): bit 0 = byte c0-1
+                    uint32_t am[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) { uint32_t a80; (void)swar_lower_alnum(W[i], &a80); am[i] = swar_movemask(a80); }
+                    const uint32_t cand = am[1] | (am[2] << 4) | (am[3] << 8) | (am[4] << 12); // bytes c0..c0+15
+                    const uint32_t prev = ((am[0] >> 3) & 1u) | (cand << 1);
+                    uint32_t starts = cand & ~prev;
+                    // a post's first byte starts a token whatever precedes it
+                    {
+                        uint32_t jj = j;
+                        uint64_t e = s.off[jj + 1];
+                        while (e < hi) {
+                            if (e >= c0) starts |= cand & (1u << (uint32_t)(e - c0));
+                            ++jj;
+                            e = s.off[jj + 1];
+                        }
+                        if (s.off[j] >= c0 && s.off[j] < hi) starts |= cand & (1u << (uint32_t)(s.off[j] - c0));
+                    }
+                    // keep [lo, hi)
+                    starts &= ~((1u << (uint32_t)(lo - c0)) - 1u);
+                    if (hi - c0 < 16) starts &= (1u << (uint32_t)(hi - c0)) - 1u;
+                    while (starts) {
+                        const uint32_t b = __builtin_ctz(starts);
+                        starts &= starts - 1;
+                        const uint64_t pos = c0 + b;
+                        while (pos >= s.off[j + 1]) ++j;
+                        const uint64_t pend = s.off[j + 1];
+                        // 12 bytes from pos, out of LDS (dynamic index)
+                        const uint32_t bi = b + 4, wi = wbase + (bi >> 2), sh = bi & 3u;
+                        const uint32_t x0 = s.text[wi], x1 = s.text[wi + 1], x2 = s.text[wi + 2], x3 = s.text[wi + 3];
+                        uint32_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh);
+                        uint32_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+                        uint32_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh);
+                        uint32_t a0, a1, a2;
+                        t0 = swar_lower_alnum(t0, &a0);
+                        t1 = swar_lower_alnum(t1, &a1);
+                        t2 = swar_lower_alnum(t2, &a2);
+                        const uint32_t m12 = swar_movemask(a0) | (swar_movemask(a1) << 4) | (swar_movemask(a2) << 8);
+                        uint32_t len = __builtin_ctz(~m12); // >= 1, <= 12
+                        const uint64_t room = pend - pos;
+                        if ((uint64_t)len > room) len = (uint32_t)room;
+                        if (len <= 9) {
+                            const uint32_t k0 = t0 & byte_mask(len);
+                            const uint32_t k1 = len > 4 ? (t1 & byte_mask(len - 4)) : 0u;
+                            const uint32_t c8 = len == 9 ? (t2 & 0xFFu) : 0u;
+                            lex_lookup(s, mult, k0, k1, c8, len, j, s);
+                        }
+                    }
+                }
+            }
+            __syncthreads(); // LDS text is restaged next iteration
+        }
+        // ---- one PostSignal per post (lexicon.rs:62-72; Polarity::new is the identity on [-1,1])
+        if (tid < np) {
+            const double bh = (double)s.bull[tid], rh = (double)s.bear[tid];
+            const double p = (bh + rh == 0.0) ? 0.0 : (bh - rh) / (bh + rh);
+            pol_out[p0 + tid] = p;
+            spec_out[p0 + tid] = (uint8_t)(s.spec[tid] != 0);
+        }
+    }
+}
+
+// ---- host: word table ------------------------------------------------------------
+// openintel src/adapters/analyzer/lexicon.rs:9-44 (`calls`/`squeeze` are bull+jargon, `puts` bear+jargon)
+static const char *const kBull[] = {"moon", "calls", "long", "buy", "bullish", "squeeze", "breakout",
+                                    "rocket", "pump", "rip", "green", "up", "rally", "bull"};
+static const char *const kBear[] = {"puts", "short", "sell", "bearish", "dump", "crash", "drilling",
+                                    "bagholder", "rug", "red", "down", "tank", "bear"};
+static const char *const kJargon[] = {"calls", "puts", "0dte", "yolo", "leaps", "theta", "gamma", "squeeze",
+                                      "otm", "itm", "strike", "iv", "delta", "vega", "contracts"};
+
+static uint32_t host_lex_hash(uint32_t k0, uint32_t k1, uint32_t c8_len, uint32_t mult) {
+    uint32_t x = k0 * 0x9E3779B1u ^ k1 * 0x85EBCA77u ^ c8_len * 0xC2B2AE3Du;
+    x ^= x >> 15;
+    return (x * mult) >> 24;
+}
+
+static bool build_lex_table(LexEntry *table, uint32_t *mult_out) {
+    struct Word { uint32_t k0, k1, c8_len, flags; };
+    std::vector<Word> words;
+    auto add = [&](const char *w, uint32_t flag) {
+        size_t len = strlen(w);
+        Word x{0, 0, 0, flag};
+        for (size_t i = 0; i < len; ++i) {
+            uint32_t c = (uint8_t)w[i];
+            if (i < 4) x.k0 |= c << (8 * i);
+            else if (i < 8) x.k1 |= c << (8 * (i - 4));
+            else x.c8_len |= c;
+        }
+        x.c8_len |= (uint32_t)len << 8;
+        for (auto &o : words)
+            if (o.k0 == x.k0 && o.k1 == x.k1 && o.c8_len == x.c8_len) { o.flags |= flag; return; }
+        words.push_back(x);
+    };
+    for (auto w : kBull) add(w, 1);
+    for (auto w : kBear) add(w, 2);
+    for (auto w : kJargon) add(w, 4);
+    // smallest odd multiplier that makes the hash perfect over the 39 distinct words
+    for (uint32_t mult = 1; mult < (1u << 24); mult += 2) {
+        memset(table, 0, sizeof(LexEntry) * LEX_SLOTS);
+        bool ok = true;
+        for (auto &w : words) {
+            LexEntry &e = table[host_lex_hash(w.k0, w.k1, w.c8_len, mult)];
+            if (e.flags) { ok = false; break; }
+            e.k0 = w.k0; e.k1 = w.k1; e.c8_len = w.c8_len; e.flags = w.flags;
+        }
+        if (ok) { *mult_out = mult; return true; }
+    }
+    return false;
+}
+
+int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                      uint64_t blob_bytes, double *d_pol, uint8_t *d_spec) {
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "lexicon: text blob must be 16-byte aligned in HBM");
+    static LexEntry h_table[LEX_SLOTS];
+    static uint32_t h_mult = 0;
+    static bool built = false;
+    if (!built) {
+        if (!build_lex_table(h_table, &h_mult)) { oi_set_error("lexicon: no perfect hash found"); return OI_ERR_STATE; }
+        built = true;
+    }
+    DevBuf &tb = ctx->buf("lex_table");
+    if (!tb.p) {
+        OI_CHECK(tb.ensure(sizeof(h_table)));
+        OI_HIP_CHECK(hipMemcpyAsync(tb.p, h_table, sizeof(h_table), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;
+    const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u; // 2 WGs of 4 waves resident per CU, 4 deep
+    const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
+    ProfScope ps(ctx, "lexicon");
+    hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                       blob_bytes, tb.as<LexEntry>(), h_mult, d_pol, d_spec);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// ---- social summary ---------------------------------------------------------------
+// speculation_engine.rs:76-97: source histogram, polarity sum, bull/bear/neutral by
+// threshold tau, speculative count.  Integer sums are exact; the f64 sum is a fixed
+// tree: per-thread strided partial -> wave shuffle tree -> per-block partial, and the
+// host adds the <= 1024 block partials in block order.
+#define SUM_THREADS 256
+#define SUM_MAX_BLOCKS 1024
+struct SumPartial {
+    unsigned long long src0, src1, bull, bear, neu, spec;
+    double psum;
+    double pad;
+};
+
+__global__ __launch_bounds__(SUM_THREADS) void social_summary_kernel(const uint8_t *sources, const double *pol,
+                                                                      const uint8_t *spec, uint64_t n, double tau,
+                                                                      SumPartial *partials) {
+    uint32_t src1 = 0, bull = 0, bear = 0, neu = 0, sp = 0, cnt = 0;
+    double psum = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * SUM_THREADS + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SUM_THREADS) {
+        const double v = pol[i];
+        psum += v;
+        if (v > tau) ++bull; else if (v < -tau) ++bear; else ++neu;
+        sp += spec[i] != 0;
+        if (sources) src1 += sources[i] != 0;
+        ++cnt;
+    }
+    __shared__ uint32_t s_u[6][SUM_THREADS / OI_WAVE];
+    __shared__ double s_d[SUM_THREADS / OI_WAVE];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t v6[6] = {cnt, src1, bull, bear, neu, sp};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { uint32_t r = oi_wave_sum(v6[k]); if (lane == 0) s_u[k][w] = r; }
+    double d = oi_wave_sum(psum);
+    if (lane == 0) s_d[w] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t[6] = {0, 0, 0, 0, 0, 0};
+        double ds = 0.0;
+        for (int ww = 0; ww < SUM_THREADS / OI_WAVE; ++ww) {
+            for (int k = 0; k < 6; ++k) t[k] += s_u[k][ww];
+            ds += s_d[ww];
+        }
+        SumPartial p;
+        p.src0 = sources ? t[0] - t[1] : 0; p.src1 = t[1]; p.bull = t[2]; p.bear = t[3]; p.neu = t[4]; p.spec = t[5];
+        p.psum = ds; p.pad = 0.0;
+        partials[blockIdx.x] = p;
+    }
+}
+
+int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol,
+                             const uint8_t *d_spec, uint64_t n, double tau, oi_social_counters *out) {
+    memset(out, 0, sizeof(*out));
+    out->total = n;
+    if (n == 0) return OI_OK;
+    uint64_t blocks = (n + (uint64_t)SUM_THREADS * 8 - 1) / ((uint64_t)SUM_THREADS * 8);
+    if (blocks > SUM_MAX_BLOCKS) blocks = SUM_MAX_BLOCKS;
+    DevBuf &pb = ctx->buf("sum_partials");
+    OI_CHECK(pb.ensure(sizeof(SumPartial) * SUM_MAX_BLOCKS));
+    {
+        ProfScope ps(ctx, "social_summary");
+        hipLaunchKernelGGL(social_summary_kernel, dim3((uint32_t)blocks), dim3(SUM_THREADS), 0, ctx->stream,
+                           d_sources, d_pol, d_spec, n, tau, pb.as<SumPartial>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    std::vector<SumPartial> h(blocks);
+    OI_HIP_CHECK(hipMemcpyAsync(h.data(), pb.p, sizeof(SumPartial) * blocks, hipMemcpyDeviceToHost, ctx->stream));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (uint64_t b = 0; b < blocks; ++b) {
+        out->by_source[0] += h[b].src0; out->by_source[1] += h[b].src1;
+        out->bullish += h[b].bull; out->bearish += h[b].bear; out->neutral += h[b].neu;
+        out->spec_count += h[b].spec; out->polarity_sum += h[b].psum;
+    }
+    return OI_OK;
+}

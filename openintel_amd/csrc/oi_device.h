@@ -1,0 +1,50 @@
+// oi_device.h -- device-side helpers shared by the gfx950 kernels (wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#define OI_WAVE 64
+
+// Order-preserving map f32 -> u32 (ascending).  -0.0 is folded into +0.0 first so
+// that equal scores compare equal; NaN must be rejected by the caller.
+__device__ __forceinline__ uint32_t oi_f32_key(float s) {
+    s += 0.0f;
+    uint32_t b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float oi_key_f32(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(b);
+}
+// 64-bit rank key: larger = ranks earlier (higher score, then LOWER doc id).
+__device__ __forceinline__ uint64_t oi_rank_key(float s, uint32_t doc) {
+    return ((uint64_t)oi_f32_key(s) << 32) | (uint64_t)(~doc);
+}
+__device__ __forceinline__ uint32_t oi_rank_key_doc(uint64_t k) { return ~(uint32_t)k; }
+__device__ __forceinline__ float oi_rank_key_score(uint64_t k) { return oi_key_f32((uint32_t)(k >> 32)); }
+
+__device__ __forceinline__ float oi_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OI_WAVE);
+    return v;
+}
+__device__ __forceinline__ double oi_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OI_WAVE);
+    return v;
+}
+__device__ __forceinline__ uint32_t oi_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OI_WAVE);
+    return v;
+}
+
+// Append one entry to a candidate pool; entries past `cap` are dropped and flagged.
+__device__ __forceinline__ void oi_pool_append(uint64_t *pool, uint32_t *count, uint32_t cap,
+                                               uint32_t *overflow, uint64_t key) {
+    uint32_t pos = atomicAdd(count, 1u);
+    if (pos < cap) pool[pos] = key;
+    else *overflow = 1u;
+}

@@ -1,0 +1,149 @@
+// oi_internal.h -- shared host-side plumbing of libopenintel_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "openintel_hip.h"
+
+// ---------------------------------------------------------------- errors
+void oi_set_error(const char *fmt, ...);
+
+#define OI_HIP_CHECK(expr)                                                                   \
+    do {                                                                                     \
+        hipError_t oi_e_ = (expr);                                                           \
+        if (oi_e_ != hipSuccess) {                                                           \
+            oi_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(oi_e_), __FILE__, \
+                         __LINE__);                                                          \
+            return OI_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define OI_CHECK(expr)              \
+    do {                            \
+        int oi_rc_ = (expr);        \
+        if (oi_rc_ != OI_OK) return oi_rc_; \
+    } while (0)
+
+#define OI_REQUIRE(cond, ...)         \
+    do {                              \
+        if (!(cond)) {                \
+            oi_set_error(__VA_ARGS__); \
+            return OI_ERR_INVALID_ARG; \
+        }                             \
+    } while (0)
+
+// ---------------------------------------------------------------- buffers
+// Grow-only device buffer: the hot path never calls hipMalloc once warmed up.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int ensure(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfSpan {
+    hipEvent_t a, b;
+};
+
+struct oi_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::map<std::string, DevBuf> ws; // named workspaces
+    bool prof_enabled = false;
+    std::map<std::string, std::vector<ProfSpan>> prof;
+    std::vector<hipEvent_t> event_pool;
+
+    DevBuf &buf(const char *name) { return ws[name]; }
+    void prof_begin(const char *tag);
+    void prof_end(const char *tag);
+};
+
+struct ProfScope {
+    oi_ctx *c;
+    const char *tag;
+    ProfScope(oi_ctx *ctx, const char *t) : c(ctx), tag(t) {
+        if (c->prof_enabled) c->prof_begin(tag);
+    }
+    ~ProfScope() {
+        if (c->prof_enabled) c->prof_end(tag);
+    }
+};
+
+// ---------------------------------------------------------------- index
+struct oi_index {
+    oi_ctx *ctx = nullptr;
+    uint64_t n_docs = 0;
+    uint32_t dim = 0, vocab = 0, doc_id_base = 0;
+
+    // embeddings
+    float *rows = nullptr; // device
+    bool rows_owned = false;
+
+    // staged forward index (between set_forward and finalize)
+    bool forward_set = false, finalized = false;
+    uint64_t total_tokens = 0;  // local
+    uint64_t n_postings = 0;    // unique (doc, term) pairs
+    uint32_t n_blocks = 0;      // ceil(n_docs / OI_BM25_BLOCK_DOCS)
+    DevBuf uniq_keys;           // u64 (block | term | doc_in_block), sorted
+    DevBuf tf;                  // u32 per unique key
+    DevBuf doc_len;             // u32 per doc
+    DevBuf df_local;            // u32 per term
+
+    // finalized inverted index
+    DevBuf postings;   // {u32 doc_in_block, f32 impact} per unique key, (block, term, doc) order
+    DevBuf cell_start; // u32 [n_blocks * vocab + 1]
+    DevBuf idf;        // f32 per term
+};
+
+// ---------------------------------------------------------------- kernels (host launchers)
+// lexicon.hip
+int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                      uint64_t blob_bytes, double *d_pol, uint8_t *d_spec);
+int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol,
+                             const uint8_t *d_spec, uint64_t n, double tau,
+                             oi_social_counters *out_host);
+// select.hip
+struct PoolView {
+    uint64_t *keys;      // [n_queries][stride]
+    uint32_t *counts;    // [n_queries]
+    uint32_t *tau_keys;  // [n_queries] orderable-u32 threshold (0 = accept all)
+    uint64_t stride;     // entries between consecutive queries' pools
+    uint32_t cap;        // usable entries per pool
+    uint32_t *overflow;  // single device word, set nonzero on overflow
+};
+int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
+                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride);
+int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
+                            const uint32_t *counts, uint32_t n_shards, uint32_t n_queries,
+                            uint32_t depth, const PoolView &pool);
+int oi_launch_rrf(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a, const uint32_t *docs_b,
+                  const uint32_t *counts_b, uint32_t n_queries, uint32_t depth, uint32_t k,
+                  float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+// cosine.hip
+int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end,
+                           uint32_t dim, const float *d_queries_padded, uint32_t n_queries,
+                           uint32_t n_queries_padded, uint32_t doc_id_base, const PoolView &pool);
+int oi_launch_l2_normalize(oi_ctx *ctx, float *rows, uint64_t n, uint32_t dim);
+uint32_t oi_cosine_query_padding(uint32_t n_queries);
+// bm25.hip
+int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets);
+int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, const uint32_t *global_df_host);
+int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
+                   uint32_t n_queries, uint32_t depth, const PoolView &pool);

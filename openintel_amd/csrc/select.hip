@@ -1,0 +1,250 @@
+// select.hip -- candidate-pool top-k selection, list merge and reciprocal-rank fusion.
+//
+// Every ranked list in this library is a set of 64-bit rank keys
+//   key = orderable(score) << 32 | ~doc_id        (oi_device.h)
+// so "score descending, doc id ascending" is plain descending u64 order and keys of
+// distinct docs are distinct.  One workgroup (1024 threads = 16 waves) owns one query.
+#include "oi_device.h"
+#include "oi_internal.h"
+
+#define SEL_THREADS 1024
+#define SEL_MAX 1024  // == OI_MAX_DEPTH
+
+// In-LDS bitonic sort, descending, P a power of two <= 2048, all SEL_THREADS threads call.
+__device__ void bitonic_sort_desc(uint64_t *a, uint32_t P) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < (P >> 1); t += SEL_THREADS) {
+                uint32_t lo = 2 * t - (t & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool desc = ((lo & size) == 0);
+                uint64_t x = a[lo], y = a[hi];
+                if ((x < y) == desc) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Top-k of pool q.  Radix select (8 passes of 8 bits, early exit once the k-th key is
+// alone in its bin) + gather + bitonic sort.  compact: the pool is rewritten to hold
+// exactly the selected keys, so the next corpus chunk appends after them.
+__global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
+    uint64_t *pools, uint32_t *pool_counts, uint32_t *tau_keys, uint64_t pool_stride,
+    uint32_t pool_cap, uint32_t *overflow, uint32_t k, int compact, float *out_scores,
+    uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint64_t sel[2 * SEL_MAX];
+    __shared__ uint32_t s_cnt, s_kk, s_bin_cnt;
+    __shared__ uint64_t s_prefix;
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint64_t *pool = pools + (uint64_t)q * pool_stride;
+    uint32_t n = pool_counts[q];
+    if (n > pool_cap) {
+        if (tid == 0) *overflow = 1u;
+        n = pool_cap;
+    }
+    uint32_t m; // number selected
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    if (n <= k) {
+        for (uint32_t i = tid; i < n; i += SEL_THREADS) sel[i] = pool[i];
+        m = n;
+    } else {
+        if (tid == 0) { s_prefix = 0; s_kk = k; }
+        int shift = 56;
+        for (;; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const uint64_t prefix = s_prefix;
+            for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+                uint64_t key = pool[i];
+                if (shift == 56 || (key >> (shift + 8)) == prefix)
+                    atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t kk = s_kk, cum = 0;
+                int d = 255;
+                for (; d > 0; --d) {
+                    uint32_t c = hist[d];
+                    if (cum + c >= kk) break;
+                    cum += c;
+                }
+                s_prefix = (prefix << 8) | (uint64_t)d;
+                s_kk = kk - cum;
+                s_bin_cnt = hist[d];
+            }
+            __syncthreads();
+            if (s_bin_cnt == 1 || shift == 0) break;
+        }
+        // every key whose top bits are >= prefix is selected: exactly k of them
+        const uint64_t prefix = s_prefix;
+        for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+            uint64_t key = pool[i];
+            if ((key >> shift) >= prefix) {
+                uint32_t pos = atomicAdd(&s_cnt, 1u);
+                if (pos < SEL_MAX) sel[pos] = key;
+            }
+        }
+        __syncthreads();
+        m = s_cnt < k ? s_cnt : k;
+    }
+    uint32_t P = 2;
+    while (P < m) P <<= 1;
+    for (uint32_t i = m + tid; i < P; i += SEL_THREADS) sel[i] = 0; // lowest possible key
+    __syncthreads();
+    bitonic_sort_desc(sel, P);
+
+    if (out_scores) {
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) {
+            uint64_t key = sel[i];
+            out_scores[(uint64_t)q * out_stride + i] = oi_rank_key_score(key);
+            out_docs[(uint64_t)q * out_stride + i] = oi_rank_key_doc(key);
+        }
+        if (tid == 0) out_counts[q] = m;
+    }
+    if (compact) {
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = sel[i];
+        if (tid == 0) {
+            pool_counts[q] = m;
+            if (m == k && tau_keys) {
+                // k docs at or above this score exist: a valid lower bound for the final
+                // k-th score, so later chunks may drop anything strictly below it.
+                uint32_t t = (uint32_t)(sel[k - 1] >> 32);
+                if (t > tau_keys[q]) tau_keys[q] = t;
+            }
+        }
+    }
+}
+
+int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
+                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+    if (n_queries == 0) return OI_OK;
+    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
+    ProfScope ps(ctx, "select");
+    hipLaunchKernelGGL(select_topk_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, pool.keys,
+                       pool.counts, pool.tau_keys, pool.stride, pool.cap, pool.overflow, k, compact ? 1 : 0,
+                       out_scores, out_docs, out_counts, out_stride);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// [n_shards][n_queries][depth] lists -> one pool per query (keys rebuilt from score/doc).
+__global__ void lists_to_pool_kernel(const float *scores, const uint32_t *docs, const uint32_t *counts,
+                                     uint32_t n_shards, uint32_t n_queries, uint32_t depth,
+                                     uint64_t *pools, uint32_t *pool_counts, uint64_t pool_stride) {
+    const uint32_t q = blockIdx.x;
+    uint64_t *pool = pools + (uint64_t)q * pool_stride;
+    uint32_t base = 0;
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        uint32_t c = counts[(uint64_t)s * n_queries + q];
+        if (c > depth) c = depth;
+        const uint64_t src = ((uint64_t)s * n_queries + q) * depth;
+        for (uint32_t i = threadIdx.x; i < c; i += blockDim.x)
+            pool[base + i] = oi_rank_key(scores[src + i], docs[src + i]);
+        base += c;
+    }
+    if (threadIdx.x == 0) pool_counts[q] = base;
+}
+
+int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
+                            const uint32_t *counts, uint32_t n_shards, uint32_t n_queries,
+                            uint32_t depth, const PoolView &pool) {
+    if (n_queries == 0) return OI_OK;
+    OI_REQUIRE((uint64_t)n_shards * depth <= pool.cap, "merge: pool too small");
+    hipLaunchKernelGGL(lists_to_pool_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, scores, docs,
+                       counts, n_shards, n_queries, depth, pool.keys, pool.counts, pool.stride);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// Reciprocal-rank fusion of two ranked lists per query.
+//   rrf(d) = [d in A at rank i] 1/(60+i)  +  [d in B at rank j] 1/(60+j)     (f32, A before B)
+// LDS hash table over list A's doc ids; union built in LDS; bitonic sort; top-k out.
+#define RRF_HASH 4096
+__global__ __launch_bounds__(SEL_THREADS) void rrf_kernel(const uint32_t *docs_a, const uint32_t *counts_a,
+                                                          const uint32_t *docs_b, const uint32_t *counts_b,
+                                                          uint32_t depth, uint32_t k, float *scores_out,
+                                                          uint32_t *docs_out, uint32_t *counts_out) {
+    __shared__ uint32_t h_doc[RRF_HASH];
+    __shared__ uint32_t h_idx[RRF_HASH]; // rank index in A + 1, 0 = empty
+    __shared__ uint32_t a_match[SEL_MAX]; // rank index in B + 1 of the same doc, 0 = none
+    __shared__ uint64_t u[2 * SEL_MAX];
+    __shared__ uint32_t s_extra;
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint32_t na = counts_a[q], nb = counts_b[q];
+    if (na > depth) na = depth;
+    if (nb > depth) nb = depth;
+    const uint32_t *da = docs_a + (uint64_t)q * depth, *db = docs_b + (uint64_t)q * depth;
+
+    for (uint32_t i = tid; i < RRF_HASH; i += SEL_THREADS) h_idx[i] = 0;
+    for (uint32_t i = tid; i < SEL_MAX; i += SEL_THREADS) a_match[i] = 0;
+    if (tid == 0) s_extra = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < na; i += SEL_THREADS) {
+        uint32_t d = da[i];
+        uint32_t h = (d * 2654435761u) >> 20; // 12 bits
+        for (;;) {
+            uint32_t prev = atomicCAS(&h_idx[h], 0u, i + 1);
+            if (prev == 0) { h_doc[h] = d; break; }
+            h = (h + 1) & (RRF_HASH - 1);
+        }
+    }
+    __syncthreads();
+    // list B: look each doc up in A; unmatched docs become their own union entries
+    for (uint32_t j = tid; j < nb; j += SEL_THREADS) {
+        uint32_t d = db[j];
+        uint32_t h = (d * 2654435761u) >> 20;
+        uint32_t hit = 0;
+        for (;;) {
+            uint32_t ix = h_idx[h];
+            if (ix == 0) break;
+            if (h_doc[h] == d) { hit = ix; break; }
+            h = (h + 1) & (RRF_HASH - 1);
+        }
+        if (hit) a_match[hit - 1] = j + 1;
+        else {
+            uint32_t pos = atomicAdd(&s_extra, 1u);
+            float c = 1.0f / (60.0f + (float)(j + 1));
+            u[na + pos] = oi_rank_key(c, d);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < na; i += SEL_THREADS) {
+        float s = 1.0f / (60.0f + (float)(i + 1));
+        uint32_t j1 = a_match[i];
+        if (j1) s = s + 1.0f / (60.0f + (float)j1);
+        u[i] = oi_rank_key(s, da[i]);
+    }
+    __syncthreads();
+    const uint32_t m = na + s_extra;
+    uint32_t P = 2;
+    while (P < m) P <<= 1;
+    for (uint32_t i = m + tid; i < P; i += SEL_THREADS) u[i] = 0;
+    __syncthreads();
+    bitonic_sort_desc(u, P);
+    const uint32_t out = m < k ? m : k;
+    for (uint32_t i = tid; i < out; i += SEL_THREADS) {
+        scores_out[(uint64_t)q * k + i] = oi_rank_key_score(u[i]);
+        docs_out[(uint64_t)q * k + i] = oi_rank_key_doc(u[i]);
+    }
+    if (tid == 0) counts_out[q] = out;
+}
+
+int oi_launch_rrf(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a, const uint32_t *docs_b,
+                  const uint32_t *counts_b, uint32_t n_queries, uint32_t depth, uint32_t k,
+                  float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    if (n_queries == 0) return OI_OK;
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "rrf: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
+    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH, "rrf: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
+    ProfScope ps(ctx, "rrf");
+    hipLaunchKernelGGL(rrf_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, docs_a, counts_a,
+                       docs_b, counts_b, depth, k, scores_out, docs_out, counts_out);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

@@ -1,0 +1,209 @@
+"""Hybrid retrieval (cosine + BM25 + reciprocal-rank fusion) on one MI355X.
+
+The reference has no retrieval port, so `PostRetriever` is a NEW port,
+styled after the reference's existing ones (borrowed inputs, owned outputs, DomainError-style
+failures -- compare src/domain/ports/post_analyzer.rs:7-11).  `HybridIndex` is its
+libopenintel_hip.so implementation; `openintel_amd.sharded` scales it over RCCL.
+"""
+from __future__ import annotations
+
+import abc
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from .context import HipContext
+
+DEFAULT_DEPTH = 1000  # per-list depth k' fed to RRF
+DEFAULT_K = 100
+
+
+@dataclass
+class RankedLists:
+    """Per-query ranked lists of one shard: rows sorted by (score desc, doc id asc)."""
+    cos_scores: object
+    cos_docs: object
+    cos_counts: object
+    bm25_scores: object
+    bm25_docs: object
+    bm25_counts: object
+
+
+@dataclass
+class SearchResult:
+    scores: object   # [B, k] f32 RRF scores
+    docs: object     # [B, k] u32 global doc ids
+    counts: object   # [B] valid entries per row
+
+
+class PostRetriever(abc.ABC):
+    """New port: rank stored posts for a batch of (embedding, term-id) queries."""
+
+    @abc.abstractmethod
+    def search(self, query_vecs, query_terms, q_term_offsets, k: int = DEFAULT_K,
+               depth: int = DEFAULT_DEPTH) -> SearchResult:
+        ...
+
+
+def _is_dev(x) -> bool:
+    return hasattr(x, "data_ptr")
+
+
+def _np(x, dtype):
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+def pack_query_terms(term_lists: Sequence[Sequence[int]]) -> Tuple[np.ndarray, np.ndarray]:
+    offs = np.zeros(len(term_lists) + 1, dtype=np.uint32)
+    offs[1:] = np.cumsum([len(t) for t in term_lists])
+    flat = np.fromiter((t for ts in term_lists for t in ts), dtype=np.uint32, count=int(offs[-1]))
+    return flat, offs
+
+
+class HybridIndex(PostRetriever):
+    """One corpus shard resident in HBM: n_docs x dim f32 rows + a blocked BM25 inverted index."""
+
+    def __init__(self, ctx: HipContext, n_docs: int, dim: int, vocab: int, doc_id_base: int = 0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.n_docs, self.dim, self.vocab, self.doc_id_base = int(n_docs), int(dim), int(vocab), int(doc_id_base)
+        h = C.c_void_p()
+        _lib.check(self.lib.oi_index_create(ctx.handle, self.n_docs, self.dim, self.vocab, self.doc_id_base,
+                                            C.byref(h)))
+        self.handle = h
+        self._keep = []  # device tensors the library borrows
+
+    # ---------------------------------------------------------------- build
+    def set_embeddings(self, rows, normalize: bool = True) -> None:
+        """rows: [n_docs, dim] f32 numpy array (copied to HBM) or torch CUDA tensor (borrowed;
+        normalised in place when normalize=True)."""
+        if _is_dev(rows):
+            assert tuple(rows.shape) == (self.n_docs, self.dim) and rows.is_contiguous()
+            self._keep.append(rows)
+            loc = _lib.OI_DEVICE
+        else:
+            rows = _np(rows, np.float32)
+            assert rows.shape == (self.n_docs, self.dim)
+            loc = _lib.OI_HOST
+        _lib.check(self.lib.oi_index_set_embeddings(self.handle, _lib.ptr(rows), loc, 1 if normalize else 0))
+
+    def set_forward(self, term_ids, doc_offsets) -> None:
+        """Forward index: doc d owns term_ids[doc_offsets[d]:doc_offsets[d+1]] (u32 ids, u64 offsets)."""
+        if _is_dev(term_ids):
+            loc = _lib.OI_DEVICE
+        else:
+            term_ids, doc_offsets = _np(term_ids, np.uint32), _np(doc_offsets, np.uint64)
+            assert doc_offsets.size == self.n_docs + 1
+            loc = _lib.OI_HOST
+        _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
+
+    def local_stats(self) -> Tuple[int, np.ndarray]:
+        tot = C.c_uint64()
+        df = np.zeros(self.vocab, dtype=np.uint32)
+        _lib.check(self.lib.oi_index_local_stats(self.handle, C.byref(tot), _lib.ptr(df)))
+        return tot.value, df
+
+    def finalize(self, global_n_docs: Optional[int] = None, global_total_tokens: Optional[int] = None,
+                 global_df: Optional[np.ndarray] = None) -> None:
+        if global_n_docs is None:
+            tot, _ = self.local_stats()
+            global_n_docs, global_total_tokens, global_df = self.n_docs, tot, None
+        df = None if global_df is None else _np(global_df, np.uint32)
+        _lib.check(self.lib.oi_index_finalize(self.handle, int(global_n_docs), int(global_total_tokens),
+                                              _lib.ptr(df)))
+
+    # ---------------------------------------------------------------- query
+    def _alloc(self, like_device: bool, shape, dtype):
+        if like_device:
+            import torch
+            tdt = {np.float32: torch.float32, np.uint32: torch.int32}[dtype]
+            return torch.zeros(shape, dtype=tdt, device="cuda:%d" % self.ctx.device)
+        return np.zeros(shape, dtype=dtype)
+
+    def _queries(self, query_vecs, query_terms, q_term_offsets):
+        dev = _is_dev(query_vecs)
+        if not dev:
+            query_vecs = _np(query_vecs, np.float32)
+            query_terms = _np(query_terms, np.uint32)
+            q_term_offsets = _np(q_term_offsets, np.uint32)
+            if query_terms.size == 0:
+                query_terms = np.zeros(1, dtype=np.uint32)
+        B = int(query_vecs.shape[0])
+        assert int(query_vecs.shape[1]) == self.dim
+        return dev, B, query_vecs, query_terms, q_term_offsets
+
+    def search_lists(self, query_vecs, query_terms, q_term_offsets, depth: int = DEFAULT_DEPTH) -> RankedLists:
+        dev, B, qv, qt, qo = self._queries(query_vecs, query_terms, q_term_offsets)
+        out = RankedLists(*(self._alloc(dev, s, d) for s, d in (
+            ((B, depth), np.float32), ((B, depth), np.uint32), ((B,), np.uint32),
+            ((B, depth), np.float32), ((B, depth), np.uint32), ((B,), np.uint32))))
+        _lib.check(self.lib.oi_search_lists(
+            self.handle, _lib.ptr(qv), _lib.ptr(qt), _lib.ptr(qo), B, int(depth),
+            _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.cos_scores), _lib.ptr(out.cos_docs),
+            _lib.ptr(out.cos_counts), _lib.ptr(out.bm25_scores), _lib.ptr(out.bm25_docs),
+            _lib.ptr(out.bm25_counts)))
+        return out
+
+    def search(self, query_vecs, query_terms, q_term_offsets, k: int = DEFAULT_K,
+               depth: int = DEFAULT_DEPTH, out: Optional[SearchResult] = None) -> SearchResult:
+        dev, B, qv, qt, qo = self._queries(query_vecs, query_terms, q_term_offsets)
+        if out is None:
+            out = SearchResult(self._alloc(dev, (B, k), np.float32), self._alloc(dev, (B, k), np.uint32),
+                               self._alloc(dev, (B,), np.uint32))
+        _lib.check(self.lib.oi_search(self.handle, _lib.ptr(qv), _lib.ptr(qt), _lib.ptr(qo), B, int(depth), int(k),
+                                      _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.scores),
+                                      _lib.ptr(out.docs), _lib.ptr(out.counts)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.oi_index_destroy(self.handle)
+            self.handle = None
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------- list-level ops (any ctx)
+def rrf_fuse(ctx: HipContext, docs_a, counts_a, docs_b, counts_b, k: int) -> SearchResult:
+    dev = _is_dev(docs_a)
+    if not dev:
+        docs_a, docs_b = _np(docs_a, np.uint32), _np(docs_b, np.uint32)
+        counts_a, counts_b = _np(counts_a, np.uint32), _np(counts_b, np.uint32)
+    B, depth = int(docs_a.shape[0]), int(docs_a.shape[1])
+    if dev:
+        import torch
+        mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=docs_a.device)
+        out = SearchResult(mk((B, k), torch.float32), mk((B, k), torch.int32), mk((B,), torch.int32))
+    else:
+        out = SearchResult(np.zeros((B, k), np.float32), np.zeros((B, k), np.uint32), np.zeros(B, np.uint32))
+    _lib.check(ctx.lib.oi_rrf_fuse(ctx.handle, _lib.ptr(docs_a), _lib.ptr(counts_a), _lib.ptr(docs_b),
+                                   _lib.ptr(counts_b), B, depth, int(k),
+                                   _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.scores),
+                                   _lib.ptr(out.docs), _lib.ptr(out.counts)))
+    return out
+
+
+def merge_lists(ctx: HipContext, scores, docs, counts):
+    """[S, B, depth] per-shard lists (+ counts [S, B]) -> global top-depth per query."""
+    dev = _is_dev(scores)
+    if not dev:
+        scores, docs, counts = _np(scores, np.float32), _np(docs, np.uint32), _np(counts, np.uint32)
+    S, B, depth = (int(x) for x in scores.shape)
+    if dev:
+        import torch
+        mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=scores.device)
+        so, do, co = mk((B, depth), torch.float32), mk((B, depth), torch.int32), mk((B,), torch.int32)
+    else:
+        so, do, co = np.zeros((B, depth), np.float32), np.zeros((B, depth), np.uint32), np.zeros(B, np.uint32)
+    _lib.check(ctx.lib.oi_merge_lists(ctx.handle, _lib.ptr(scores), _lib.ptr(docs), _lib.ptr(counts), S, B, depth,
+                                      _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(so), _lib.ptr(do),
+                                      _lib.ptr(co)))
+    return so, do, co

@@ -1,0 +1,52 @@
+"""CPU-side checks of the boundary: the library builds for gfx950, loads, and exports every
+symbol include/openintel_hip.h declares.  No compute calls (no GPU here)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "openintel_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(oi_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from openintel_amd import build, _lib
+    build.build()
+    lib = _lib.load()
+    declared = _declared()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "missing export: " + name
+    assert sorted(_lib.SIGNATURES) == declared, "python binding table out of sync with the header"
+    assert lib.oi_abi_version() == 1
+
+
+def test_library_is_gfx950_only_and_has_no_cpu_fallback():
+    import ctypes as C
+    import subprocess
+    from openintel_amd import _lib
+    lib = _lib.load()
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          "--input=" + _lib.LIB_PATH], capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        targets = [t for t in out.stdout.split() if "amdgcn" in t]
+        assert targets and all("gfx950" in t for t in targets), targets
+    import torch
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        rc = lib.oi_create(0, C.byref(h))
+        assert rc != 0 and not h.value            # no device -> loud failure, never a CPU path
+        assert b"no HIP device" in lib.oi_last_error() or lib.oi_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "openintel_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oi_oracle" not in src and "liboi_oracle" not in src, f

@@ -1,0 +1,400 @@
+"""GPU parity tests: the HIP path (through the C ABI of libopenintel_hip.so) vs the CPU oracle on
+the same seeded inputs.  Run on a real MI355X:  python -m pytest tests -m gpu
+
+Bars (written where they are applied):
+  * lexicon path (reference-pinned): per-post polarity f64 BIT-EXACT, flags exact, integer
+    summary counters exact, polarity_sum within n * 2^-52 * max|partial sum| of the input-order sum;
+  * BM25 / RRF / merge: scores and doc-id order BIT-EXACT vs the (unpinned) oracle;
+  * cosine: scores within 1e-5 absolute (f32 MFMA/FMA order differs from the f64 oracle).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import openintel_amd as oi
+    c = oi.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import lib
+    return lib
+
+
+# ----------------------------------------------------------------------------- lexicon path
+def _analyze(ctx, texts):
+    import openintel_amd as oi
+    blob, offs = oi.pack_posts(texts)
+    return oi.HipLexiconAnalyzer(ctx).analyze_packed(blob, offs), (blob, offs)
+
+
+def _check_lexicon(ctx, O, texts):
+    (pol, spec), (blob, offs) = _analyze(ctx, texts)
+    rpol, rspec = O.lexicon_analyze(blob if blob.size else np.zeros(1, np.uint8), offs)
+    bad = np.nonzero((pol.view(np.uint64) != rpol.view(np.uint64)) | (spec != rspec))[0]
+    assert bad.size == 0, "first mismatch at post %d: %r gpu=(%r,%r) ref=(%r,%r)" % (
+        bad[0], texts[bad[0]][:120], pol[bad[0]], spec[bad[0]], rpol[bad[0]], rspec[bad[0]])
+    return pol, spec
+
+
+def test_lexicon_reference_fixture(ctx, O, golden):
+    texts = [p["text"] for p in golden["fixture_posts"]]
+    pol, spec = _check_lexicon(ctx, O, texts)
+    assert pol.tolist() == [s["polarity"] for s in golden["derived"]["signals"]]
+    assert spec.astype(bool).tolist() == [s["speculative"] for s in golden["derived"]["signals"]]
+    # lexicon.rs:106-120
+    pol, spec = _check_lexicon(ctx, O, [c["text"] for c in golden["lexicon_test"]])
+    assert [int(np.sign(p)) for p in pol] == [c["polarity_sign"] for c in golden["lexicon_test"]]
+
+
+def test_lexicon_port_object_and_engine_end_to_end(ctx, golden):
+    import openintel_amd as oi
+    posts = [oi.SocialPost(p["id"], oi.SourceKind.REDDIT if p["source"] == "reddit" else oi.SourceKind.BLUESKY,
+                           p["author"], oi.PostText.parse(p["text"]), None, p["engagement"])
+             for p in golden["fixture_posts"]]
+    analyzer: oi.PostAnalyzer = oi.HipLexiconAnalyzer(ctx)
+    signals = analyzer.analyze(posts)
+    assert len(signals) == len(posts)                                  # post_analyzer.rs:9
+    m = golden["mock_market"]
+    tk = oi.Ticker.parse("AAPL")
+    snap = oi.MarketSnapshot(tk, m["last_price"], m["previous_close"], m["volume"], m["avg_volume"],
+                             m["realized_vol"], m["put_call_ratio"], m["iv_rank"])
+    rep = oi.SpeculationEngine.aggregate(tk, posts, signals, snap, None, oi.EngineConfig())
+    d = golden["derived"]["summary"]
+    assert rep.social.total_mentions == 10 and rep.fusion.alignment.value == "confirming_bullish"  # analyze_flow.rs:128-129
+    assert rep.social.net_sentiment == d["net_sentiment"] and rep.social.speculation_index == d["speculation_index"]
+    assert (rep.social.bullish, rep.social.bearish, rep.social.neutral) == (7, 2, 1)
+    assert rep.social.bull_bear_ratio == d["bull_bear_ratio"] and rep.fusion.crowding == d["crowding"]
+    assert rep.market.pct_change == d["pct_change"] and rep.market.rvol == d["rvol"]
+    assert rep.social_confidence.value == "medium"
+    # same report from the GPU reduction
+    src = np.array([int(p.source) for p in posts], np.uint8)
+    pol = np.array([s.polarity for s in signals]); spec = np.array([s.speculative for s in signals], np.uint8)
+    cnt = oi.SpeculationEngine.social_counters(ctx, src, pol, spec, oi.EngineConfig())
+    rep2 = oi.SpeculationEngine.aggregate_counters(tk, cnt, snap, None, oi.EngineConfig())
+    assert rep2.social == rep.social and rep2.fusion.crowding == rep.fusion.crowding
+    assert rep2.fusion.alignment == rep.fusion.alignment
+    # speculation_engine.rs:335-355 length mismatch
+    with pytest.raises(oi.AnalyzerMismatch):
+        oi.SpeculationEngine.social_counters(ctx, src, pol[:5], spec[:5], oi.EngineConfig(), n_posts=10)
+    with pytest.raises(oi.AnalyzerMismatch):
+        oi.SpeculationEngine.aggregate(tk, posts, signals[:3], None, None, oi.EngineConfig())
+
+
+def test_lexicon_unicode_and_edge_cases(ctx, O):
+    from tests.test_oracle_golden import UNICODE_CASES
+    texts = list(UNICODE_CASES)
+    texts += ["", "a", "up", "", "", "iv", "x" * 15 + " moon", "x" * 16 + "moon", "moon" * 4, "y" * 4095 + " up",
+              "K" * 9, "pumK", "Kpump", "buK buy", "İv iv", "moonİ", "caKlls"]
+    # tokens that straddle 16-byte lanes and 4 KiB sub-tiles at every phase
+    for pad in range(0, 40):
+        texts.append("z" * pad + " squeeze " + "q" * (4096 - pad) + " bagholder rocket")
+    # a post far longer than one sub-tile, lexicon words everywhere
+    texts.append(" ".join(["moon", "dump", "filler", "0dte", "UP", "Down."] * 3000))
+    # posts that END exactly where a token would continue in the next post
+    texts += ["to the mo", "on calls", "pu", "ts", "b", "uy", "sell"]
+    _check_lexicon(ctx, O, texts)
+
+
+def test_lexicon_many_tiny_posts_and_random_corpus(ctx, O):
+    from openintel_amd import synth
+    rng = np.random.default_rng(5)
+    words = synth.LEXICON_WORDS + ["the", "a", "zz", "é", "K", "UP", "Moon", "\U0001F680"]
+    tiny = [str(rng.choice(words)) if rng.random() < 0.8 else "" for _ in range(5000)]
+    _check_lexicon(ctx, O, tiny)
+    texts = synth.posts_np(20000)
+    for i in range(0, len(texts), 7):  # sprinkle upper case / punctuation / non-ASCII
+        texts[i] = texts[i].upper().replace(" ", ", ", 3) + " — \U0001F680"
+    pol, spec = _check_lexicon(ctx, O, texts)
+    assert 0 < (pol != 0).mean() < 1 and 0 < spec.mean() < 1
+
+
+def test_lexicon_device_buffers_and_summary(ctx, O):
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    blob, offs = synth.posts_torch(300_000, dev)
+    n = offs.numel() - 1
+    pol = torch.zeros(n, dtype=torch.float64, device=dev)
+    spec = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    oi.HipLexiconAnalyzer(ctx).analyze_device(blob, offs, pol, spec)
+    ctx.synchronize()
+    rpol, rspec = O.lexicon_analyze(blob.cpu().numpy(), offs.cpu().numpy().astype(np.uint64))
+    assert np.array_equal(pol.cpu().numpy().view(np.uint64), rpol.view(np.uint64))
+    assert np.array_equal(spec.cpu().numpy(), rspec)
+    src = (torch.arange(n, device=dev) % 3 == 0).to(torch.uint8)
+    cfg = oi.EngineConfig()
+    cnt = oi.SpeculationEngine.social_counters(ctx, src, pol, spec, cfg)
+    ref = O.social_summary(src.cpu().numpy(), rpol, rspec)
+    assert (cnt.total, cnt.bullish, cnt.bearish, cnt.neutral, cnt.spec_count) == (
+        n, ref.bullish, ref.bearish, ref.neutral, ref.spec_count)                      # exact
+    assert list(cnt.by_source) == list(ref.mentions_by_source)                          # exact
+    bound = n * 2.0 ** -52 * max(1.0, float(np.abs(np.cumsum(rpol)).max()))
+    assert abs(cnt.polarity_sum - ref.polarity_sum) <= bound
+    # and a second run gives the identical bits (fixed-shape tree)
+    cnt2 = oi.SpeculationEngine.social_counters(ctx, src, pol, spec, cfg)
+    assert cnt2.polarity_sum == cnt.polarity_sum
+
+
+# ----------------------------------------------------------------------------- retrieval helpers
+def _check_cos_list(scores, docs, count, ref_dense, depth, doc_base=0):
+    n = ref_dense.size
+    assert count == min(depth, n)
+    s, d = scores[:count], docs[:count].astype(np.int64) - doc_base
+    assert np.all(d >= 0) and np.all(d < n) and np.unique(d).size == count
+    order_ok = (s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (d[:-1] < d[1:]))
+    assert order_ok.all(), "list not sorted by (score desc, doc asc)"
+    assert np.abs(s.astype(np.float64) - ref_dense[d].astype(np.float64)).max() <= COS_TOL   # the 1e-5 bar
+    kth = np.sort(ref_dense)[::-1][count - 1]
+    must = np.nonzero(ref_dense > kth + 2 * COS_TOL)[0]
+    assert np.isin(must, d).all(), "a clearly better doc is missing"
+    assert (ref_dense[d] >= kth - 2 * COS_TOL).all(), "a clearly worse doc is present"
+
+
+def _build(ctx, rows, terms, offs, vocab, normalize=False, doc_base=0):
+    import openintel_amd as oi
+    idx = oi.HybridIndex(ctx, rows.shape[0], rows.shape[1], vocab, doc_base)
+    idx.set_embeddings(rows, normalize=normalize)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    return idx
+
+
+def _small_forward(rng, n, vocab, max_len=12, zipf=True):
+    lens = rng.integers(1, max_len + 1, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    if zipf:
+        p = 1.0 / np.arange(1, vocab + 1) ** 1.07
+        terms = rng.choice(vocab, size=int(offs[-1]), p=p / p.sum()).astype(np.uint32)
+    else:
+        terms = rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32)
+    return terms, offs
+
+
+@pytest.mark.parametrize("B,dim,n", [(1, 768, 5000), (3, 384, 3000), (8, 128, 9000), (20, 128, 9000),
+                                     (64, 768, 4000), (70, 64, 6000), (1, 1024, 2000), (33, 100, 1000)])
+def test_cosine_lists_within_tolerance(ctx, O, B, dim, n):
+    from openintel_amd import synth
+    rows = synth.embeddings_np(n, dim, seed=1 + B)
+    q = synth.embeddings_np(B, dim, seed=99 + B)
+    rng = np.random.default_rng(B)
+    terms, offs = _small_forward(rng, n, 50)
+    idx = _build(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    for depth in (10, 1000):
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        for b in range(B):
+            _check_cos_list(L.cos_scores[b], L.cos_docs[b], int(L.cos_counts[b]), O.dot_scores(rows, q[b]), depth)
+    idx.close()
+
+
+def test_cosine_normalize_on_device_matches_oracle(ctx, O):
+    rng = np.random.default_rng(3)
+    raw = (rng.standard_normal((3000, 96)) * rng.uniform(0.1, 30, size=(3000, 1))).astype(np.float32)
+    raw[7] = 0.0  # zero row stays zero
+    terms, offs = _small_forward(rng, 3000, 20)
+    idx = _build(ctx, raw, terms, offs, 20, normalize=True)
+    ref_rows = O.l2_normalize_rows(raw)
+    q = O.l2_normalize_rows(rng.standard_normal((2, 96)).astype(np.float32))
+    L = idx.search_lists(q, np.zeros(2, np.uint32), np.arange(3, dtype=np.uint32), depth=50)
+    for b in range(2):
+        _check_cos_list(L.cos_scores[b], L.cos_docs[b], int(L.cos_counts[b]), O.dot_scores(ref_rows, q[b]), 50)
+    idx.close()
+
+
+def _exact_case(rng, n, dim, vocab, B, n_q_terms=4, max_len=12):
+    # small-integer embeddings: every dot product is an exact integer in f32 whatever the
+    # summation order, so even the cosine list (with its many ties) must match bit for bit
+    rows = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+    q = rng.integers(-3, 4, size=(B, dim)).astype(np.float32)
+    terms, offs = _small_forward(rng, n, vocab, max_len)
+    qt = rng.integers(0, min(vocab, 12), size=B * n_q_terms).astype(np.uint32)
+    qo = (np.arange(B + 1) * n_q_terms).astype(np.uint32)
+    return rows, q, terms, offs, qt, qo
+
+
+@pytest.mark.parametrize("n,dim,vocab,B,depth,k", [
+    (70_000, 32, 40, 4, 100, 100),      # 3 doc blocks, dense BM25 path (frequent terms), many ties
+    (70_000, 32, 5000, 9, 1000, 100),   # sparse BM25 path, MFMA cosine kernel
+    (40_000, 64, 300, 64, 10, 10),      # batch 64
+    (1_000, 384, 64, 1, 10, 10),        # BASELINE configs[0] shape
+    (33_000, 16, 8, 2, 1024, 1024),     # maximum depth / k
+])
+def test_hybrid_pipeline_bit_exact(ctx, O, n, dim, vocab, B, depth, k):
+    rng = np.random.default_rng(n + B)
+    rows, q, terms, offs, qt, qo = _exact_case(rng, n, dim, vocab, B)
+    idx = _build(ctx, rows, terms, offs, vocab, normalize=False, doc_base=1000)
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    R = idx.search(q, qt, qo, k=k, depth=depth)
+    for b in range(B):
+        cs, cd = O.topk(O.dot_scores(rows, q[b]), depth, False, 1000)
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, qt[qo[b]:qo[b + 1]]), depth, True, 1000)
+        fs, fd = O.rrf_fuse(cd, bd, k)
+        assert int(L.cos_counts[b]) == cd.size and int(L.bm25_counts[b]) == bd.size
+        assert np.array_equal(L.cos_docs[b][:cd.size], cd) and np.array_equal(L.cos_scores[b][:cd.size], cs)
+        assert np.array_equal(L.bm25_docs[b][:bd.size], bd), "BM25 doc order differs (query %d)" % b
+        assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), "BM25 score bits"
+        assert int(R.counts[b]) == fd.size
+        assert np.array_equal(R.docs[b][:fd.size], fd) and np.array_equal(
+            R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32))
+    idx.close()
+
+
+def test_bm25_edge_cases(ctx, O):
+    rng = np.random.default_rng(11)
+    n, vocab = 5000, 30
+    rows = rng.integers(-2, 3, size=(n, 8)).astype(np.float32)
+    terms, offs = _small_forward(rng, n, vocab - 2)   # terms 28, 29 never occur
+    idx = _build(ctx, rows, terms, offs, vocab)
+    queries = [[28], [29, 28], [], [3, 3, 3], [0], [5, 28, 7], [999999]]   # absent / empty / repeated / out-of-vocab
+    from openintel_amd import pack_query_terms
+    qt, qo = pack_query_terms(queries)
+    q = rng.integers(-2, 3, size=(len(queries), 8)).astype(np.float32)
+    L = idx.search_lists(q, qt, qo, depth=20)
+    for b, terms_b in enumerate(queries):
+        tb = [t for t in terms_b if t < vocab]
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, np.array(tb, np.uint32)), 20, True)
+        assert int(L.bm25_counts[b]) == bd.size
+        assert np.array_equal(L.bm25_docs[b][:bd.size], bd)
+        assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32))
+    idx.close()
+
+
+def test_merge_and_rrf_kernels_bit_exact(ctx, O):
+    from openintel_amd import merge_lists, rrf_fuse
+    rng = np.random.default_rng(2)
+    S, B, depth = 8, 5, 100
+    scores = np.zeros((S, B, depth), np.float32); docs = np.zeros((S, B, depth), np.uint32)
+    counts = rng.integers(0, depth + 1, size=(S, B)).astype(np.uint32)
+    counts[0, 0] = depth; counts[1, 1] = 0
+    for s in range(S):
+        for b in range(B):
+            c = counts[s, b]
+            sc = np.round(rng.standard_normal(c), 1).astype(np.float32)       # lots of ties
+            dd = rng.choice(100000, size=c, replace=False).astype(np.uint32) * S + s   # disjoint across shards
+            o = np.lexsort((dd, -sc.astype(np.float64)))
+            scores[s, b, :c], docs[s, b, :c] = sc[o], dd[o]
+    so, do, co = merge_lists(ctx, scores, docs, counts)
+    for b in range(B):
+        ms, md = O.merge_ranked([scores[s, b, :counts[s, b]] for s in range(S)],
+                                [docs[s, b, :counts[s, b]] for s in range(S)], depth)
+        assert co[b] == md.size and np.array_equal(do[b][:md.size], md) and np.array_equal(so[b][:md.size], ms)
+    for depth, k in ((100, 100), (1000, 100), (1024, 1024), (7, 3)):
+        da = np.stack([rng.choice(5000, size=depth, replace=False) for _ in range(B)]).astype(np.uint32)
+        db = np.stack([rng.choice(5000, size=depth, replace=False) for _ in range(B)]).astype(np.uint32)
+        ca = rng.integers(0, depth + 1, size=B).astype(np.uint32); cb = rng.integers(0, depth + 1, size=B).astype(np.uint32)
+        ca[0], cb[0] = depth, depth
+        if B > 1:
+            ca[1], cb[1] = 0, 0
+        R = rrf_fuse(ctx, da, ca, db, cb, k)
+        for b in range(B):
+            fs, fd = O.rrf_fuse(da[b][:ca[b]], db[b][:cb[b]], k)
+            assert R.counts[b] == fd.size and np.array_equal(R.docs[b][:fd.size], fd)
+            assert np.array_equal(R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32))
+
+
+def test_errors_are_loud(ctx):
+    import openintel_amd as oi
+    from openintel_amd._lib import OiError
+    with pytest.raises(OiError):
+        oi.HybridIndex(ctx, 10, 7, 10)            # dim not a multiple of 4
+    idx = oi.HybridIndex(ctx, 10, 8, 10)
+    idx.set_embeddings(np.zeros((10, 8), np.float32), normalize=False)
+    with pytest.raises(OiError):                   # BM25 index never built
+        idx.search_lists(np.zeros((1, 8), np.float32), np.zeros(1, np.uint32), np.array([0, 1], np.uint32), depth=5)
+    with pytest.raises(OiError):
+        idx.set_forward(np.array([11], np.uint32), np.array([0] + [1] * 10, np.uint64))   # term >= vocab
+    idx.close()
+
+
+# ----------------------------------------------------------------------------- full BASELINE sizes
+def _planted_check(ctx, n, dim, B, depth, k):
+    """Size-independent properties at full size: planted near-duplicates of the queries must come
+    back first with score ~1; lists are sorted; results are reproducible; sharding the same corpus
+    in two and merging gives the same answer as one shard."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    rows = synth.embeddings_torch(n, dim, dev)
+    qv, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=4096)
+    plant = torch.arange(B, device=dev) * (n // B) + 17
+    rows[plant] = qv
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    idx = oi.HybridIndex(ctx, n, dim, 4096)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    L = idx.search_lists(qv, qt, qo, depth=depth)
+    ctx.synchronize()
+    cs, cd, cc = L.cos_scores.cpu().numpy(), L.cos_docs.cpu().numpy(), L.cos_counts.cpu().numpy()
+    assert (cc == depth).all()
+    assert np.array_equal(cd[:, 0], plant.cpu().numpy()) and np.abs(cs[:, 0] - 1.0).max() < 1e-5
+    assert (np.diff(cs, axis=1) <= 0).all()
+    bs, bc = L.bm25_scores.cpu().numpy(), L.bm25_counts.cpu().numpy()
+    for b in range(B):
+        assert (np.diff(bs[b, :bc[b]]) <= 0).all() and (bs[b, :bc[b]] > 0).all()
+    R1 = idx.search(qv, qt, qo, k=k, depth=depth)
+    R2 = idx.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    assert torch.equal(R1.docs, R2.docs) and torch.equal(R1.scores, R2.scores)     # idempotent
+    # spot-check a few queries' cosine lists against exact torch scores of the candidates
+    for b in range(min(B, 3)):
+        full = (rows @ qv[b]).cpu().numpy()
+        _check_cos_list(cs[b], cd[b], int(cc[b]), full, depth)
+    idx.close()
+    return rows, terms, offs, qv, qt, qo, (cs, cd, cc, bs, L.bm25_docs.cpu().numpy(), bc)
+
+
+def test_full_size_config1_1M_768_batch1(ctx):
+    _planted_check(ctx, 1_000_000, 768, 1, 100, 100)     # BASELINE.json configs[1]
+
+
+def test_full_size_two_shards_equal_one(ctx, O):
+    import torch
+    import openintel_amd as oi
+    n, dim, B, depth, k = 400_000, 128, 16, 100, 100
+    rows, terms, offs, qv, qt, qo, one = _planted_check(ctx, n, dim, B, depth, k)
+    cs, cd, cc, bs, bd, bc = one
+    half = n // 2
+    lists = []
+    tot, dfs = 0, []
+    shards = []
+    for s, (lo, hi) in enumerate(((0, half), (half, n))):
+        t_lo, t_hi = int(offs[lo]), int(offs[hi])
+        ix = oi.HybridIndex(ctx, hi - lo, dim, 4096, doc_id_base=lo)
+        ix.set_embeddings(rows[lo:hi], normalize=False)
+        ix.set_forward(terms[t_lo:t_hi].contiguous(), (offs[lo:hi + 1] - offs[lo]).contiguous())
+        t, df = ix.local_stats()
+        tot += t; dfs.append(df); shards.append(ix)
+    gdf = (dfs[0].astype(np.uint64) + dfs[1]).astype(np.uint32)
+    for ix in shards:
+        ix.finalize(n, tot, gdf)          # global N / tokens / df: the all-reduce a multi-GPU caller does
+        lists.append(ix.search_lists(qv, qt, qo, depth=depth))
+    ctx.synchronize()
+    st = lambda f: torch.stack([getattr(l, f) for l in lists])
+    ms, md, mc = oi.merge_lists(ctx, st("cos_scores"), st("cos_docs"), st("cos_counts"))
+    bs2, bd2, bc2 = oi.merge_lists(ctx, st("bm25_scores"), st("bm25_docs"), st("bm25_counts"))
+    ctx.synchronize()
+    assert np.array_equal(md.cpu().numpy(), cd) and np.array_equal(ms.cpu().numpy(), cs)
+    assert np.array_equal(bc2.cpu().numpy(), bc)
+    for b in range(B):   # BM25 with global statistics is bit-identical to the unsharded index
+        assert np.array_equal(bd2.cpu().numpy()[b, :bc[b]], bd[b, :bc[b]])
+        assert np.array_equal(bs2.cpu().numpy()[b, :bc[b]], bs[b, :bc[b]])
+    for ix in shards:
+        ix.close()
+
+
+def test_full_size_config2_10M_768_batch64(ctx):
+    _planted_check(ctx, 10_000_000, 768, 64, 100, 100)   # BASELINE.json configs[2]
