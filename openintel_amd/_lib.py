@@ -84,6 +84,15 @@ def load() -> C.CDLL:
         raise RuntimeError(
             "libopenintel_hip.so is not built (%s). Run `python -m openintel_amd.build`. "
             "openintel_amd has no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime (same soname, libamdhip64.so.7).  Two HIP runtimes in one
+    # process cannot share a GPU, so when torch is present it must be loaded FIRST: the dynamic
+    # linker then resolves this library's libamdhip64.so.7 to the copy torch already mapped, and
+    # torch tensors / streams are valid arguments.  A host without torch (the Rust shim of
+    # INTEGRATION.md) simply gets the system ROCm runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
