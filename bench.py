@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- hybrid BM25 + cosine + RRF top-100 queries/sec on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2]): 10M posts x 768-d f32 synthetic corpus,
+batches of 64 queries (embedding + 4 BM25 terms), per-list depth k'=1000, RRF top-100.
+A step = one batch through the whole hot path with corpus, index and queries resident in HBM.
+With N > 1 the SAME 10M-row corpus is row-sharded over the N ranks (strong scaling) and the
+per-shard lists are exchanged with one RCCL all-gather per batch.
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def cpu_baseline(n_total, dim, vocab, depth, k, sample_docs, sample_queries):
+    """The CPU oracle (kind "port": the build's own scalar C restatement; the reference has no
+    retrieval code and its Rust cannot be built here) timed on a bounded slice of the same
+    workload.  Brute-force cost is linear in corpus size, so the full-corpus rate is the
+    sample rate scaled by sample_docs / n_total."""
+    import numpy as np
+    from openintel_amd import synth
+    from oracle import lib as O
+    rows = synth.embeddings_np(sample_docs, dim)
+    q = synth.embeddings_np(sample_queries, dim, seed=synth.SEED_QUERY)
+    terms, offs = synth.forward_index_np(sample_docs, vocab)
+    qt, qo = synth.query_terms_np(sample_queries, vocab)
+    df, tot = O.bm25_df(terms, offs, vocab)
+    t0 = time.perf_counter()
+    for b in range(sample_queries):
+        _, cd = O.topk(O.dot_scores(rows, q[b]), depth)
+        _, bd = O.topk(O.bm25_scores(terms, offs, vocab, qt[qo[b]:qo[b + 1]], df=df), depth, True)
+        O.rrf_fuse(cd, bd, k)
+    dt = time.perf_counter() - t0
+    qps_sample = sample_queries / dt
+    return {
+        "value": qps_sample * sample_docs / n_total, "unit": "queries/s", "cores": 1, "kind": "port",
+        "sample": "%d queries against a %d-doc slice (%.1f s of single-thread C oracle); rate scaled by %d/%d "
+                  "(brute-force cost is linear in corpus size)" % (sample_queries, sample_docs, dt, sample_docs, n_total),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--depth", type=int, default=1000)
+    ap.add_argument("--vocab", type=int, default=131072)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-docs", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=16)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import openintel_amd as oi
+    from openintel_amd import sharded, synth
+
+    ctx = oi.HipContext(local_rank)
+    ctx.use_torch_current_stream()
+
+    # ---------------------------------------------------------------- corpus shard in HBM
+    lo, hi = sharded.shard_bounds(args.docs, world, rank)
+    n_local = hi - lo
+    t_build = time.perf_counter()
+    rows = synth.embeddings_torch(n_local, args.dim, dev, seed=synth.SEED_EMB + rank)
+    terms, offs = synth.forward_index_torch(n_local, dev, vocab=args.vocab, seed=synth.SEED_TEXT + rank)
+    idx = oi.HybridIndex(ctx, n_local, args.dim, args.vocab, doc_id_base=lo)
+    idx.set_embeddings(rows, normalize=False)          # rows are generated unit-norm
+    idx.set_forward(terms, offs)
+    n_tokens_local = int(offs[-1].item())
+    del terms, offs
+    torch.cuda.empty_cache()
+    sr = sharded.make_hip_sharded(ctx, idx, dev)
+    sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
+    qv, qt, qo = synth.query_batch_torch(args.batch, args.dim, dev, vocab=args.vocab)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    out = oi.SearchResult(torch.zeros((args.batch, args.k), dtype=torch.float32, device=dev),
+                          torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
+                          torch.zeros((args.batch,), dtype=torch.int32, device=dev))
+
+    def step():
+        if world == 1:
+            idx.search(qv, qt, qo, k=args.k, depth=args.depth, out=out)   # one C-ABI call: the whole query
+            return out.docs
+        return sr.search(qv, qt, qo, args.k, args.depth)[1]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.synchronize()   # also surfaces a pool overflow as an error
+
+    # ---------------------------------------------------------------- timed region: exactly K steps
+    ctx.profile_reset(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    elapsed = float(tm.item())
+    cos_ms, cos_launches = ctx.profile_read("cosine")
+    other = {t: ctx.profile_read(t) for t in ("bm25", "select", "rrf")}
+    ctx.profile_reset(False)
+
+    # per-batch latency (p50/p95), measured separately with a host sync after every batch
+    lat = []
+    for _ in range(max(10, min(args.steps, 50))):
+        fence()
+        t1 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat.sort()
+
+    # a result sanity check outside the timed region: every row full, ids in range
+    docs = step().cpu().numpy()
+    assert docs.shape == (args.batch, args.k) and docs.min() >= 0 and docs.max() < args.docs
+
+    if rank == 0:
+        qps = args.batch * args.steps / elapsed
+        # dominant kernel: the cosine scorer.  Algorithmic work per step on this rank
+        # (SURVEY.md 8d): flops = 2 * n_local * d * B, bytes = n_local * d * 4 (corpus read once per batch)
+        flops_step = 2.0 * n_local * args.dim * args.batch
+        bytes_step = 4.0 * n_local * args.dim
+        cos_s = cos_ms / 1e3
+        if args.batch > 8:
+            roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": bytes_step * args.steps / cos_s / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                roof["traffic"] = json.load(open(pmc)).get("cosine_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        roof["kernel"] = "cosine scorer (all corpus-chunk launches of a batch)"
+        roof["launches_per_step"] = cos_launches / max(1, args.steps)
+        roof["avg_launch_ms"] = cos_ms / max(1, cos_launches)
+        roof["kernel_ms_per_step"] = cos_ms / max(1, args.steps)
+        roof["hbm_GBs_algorithmic"] = bytes_step * args.steps / cos_s / 1e9
+        line = {
+            "metric": "queries/sec + p50 latency, 10M-post/768-d hybrid BM25+cosine+RRF top-100",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d posts x %d-d f32, batch %d queries x 4 BM25 terms, "
+                                   "per-list depth %d, RRF top-%d; corpus row-sharded over %d GPU(s)" % (
+                                       args.docs, args.dim, args.batch, args.depth, args.k, world),
+                       "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
+                       "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
+                       "parallelism": "row-shard x%d + all-gather of per-shard lists" % world},
+            "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
+            "roofline": roof,
+            "other_kernels_ms_per_step": {t: v[0] / max(1, args.steps) for t, v in other.items()},
+            "build_s": t_build,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
+                                                args.cpu_sample_docs, args.cpu_sample_queries)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
