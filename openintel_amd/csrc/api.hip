@@ -314,22 +314,32 @@ struct Pools {
     PoolView cos, bm;
 };
 
-// One contiguous state block: [overflow flag(16 B)] [counts cos][tau cos][counts bm][tau bm]
-int prepare_pools(oi_ctx *ctx, uint32_t B, uint32_t cos_cap, uint32_t bm_cap, Pools *out) {
+// State of both pools in one block, zeroed with ONE memset per search:
+//   cosine: carry_cnt[B] tau[B] seg_cnt[B][CUs]      BM25: carry_cnt[B] seg_cnt[B][n_blocks]
+int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_cap, uint32_t bm_blocks,
+                  uint32_t depth, Pools *out) {
     DevBuf &flag = ctx->buf("state_flag");
     if (!flag.p) {
         OI_CHECK(flag.ensure(16));
         OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, ctx->stream));
     }
+    const uint32_t cos_segs = (uint32_t)ctx->num_cus;
+    const uint32_t bm_segs = bm_blocks ? bm_blocks : 1;
+    const size_t words = (size_t)B * (2 + cos_segs + 1 + bm_segs);
     DevBuf &st = ctx->buf("pool_state");
-    OI_CHECK(st.ensure(sizeof(uint32_t) * 4 * (size_t)B));
-    OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * 4 * (size_t)B, ctx->stream));
+    OI_CHECK(st.ensure(sizeof(uint32_t) * words));
+    OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * words, ctx->stream));
+    const uint64_t bm_stride = (uint64_t)carry_cap + (uint64_t)bm_segs * depth;
     DevBuf &pc = ctx->buf("pool_cos"), &pb = ctx->buf("pool_bm");
-    OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_cap));
-    OI_CHECK(pb.ensure(sizeof(uint64_t) * (size_t)B * bm_cap));
+    OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_stride));
+    OI_CHECK(pb.ensure(sizeof(uint64_t) * (size_t)B * bm_stride));
     uint32_t *s = st.as<uint32_t>();
-    out->cos = PoolView{pc.as<uint64_t>(), s, s + B, cos_cap, cos_cap, flag.as<uint32_t>()};
-    out->bm = PoolView{pb.as<uint64_t>(), s + 2 * (size_t)B, s + 3 * (size_t)B, bm_cap, bm_cap, flag.as<uint32_t>()};
+    uint32_t *cos_carry = s, *cos_tau = s + B, *cos_seg = s + 2 * (size_t)B;
+    uint32_t *bm_carry = cos_seg + (size_t)B * cos_segs, *bm_seg = bm_carry + B;
+    out->cos = PoolView{pc.as<uint64_t>(), cos_carry, cos_seg, cos_tau, cos_stride, carry_cap, 0, 0, cos_segs,
+                        flag.as<uint32_t>()};
+    out->bm = PoolView{pb.as<uint64_t>(), bm_carry, bm_seg, nullptr, bm_stride, carry_cap, depth, bm_segs, bm_segs,
+                       flag.as<uint32_t>()};
     return OI_OK;
 }
 
@@ -341,17 +351,18 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     hipStream_t st = ctx->stream;
     const uint64_t n = idx->n_docs;
     // ---- pool capacities
-    // cosine: the corpus is scored in chunks; a chunk can append at most its row count, so a
-    // chunk of (cap - depth) rows can never overflow a pool that starts with <= depth entries.
-    uint64_t cos_cap = 1ull << 20;
-    const uint64_t budget = (1ull << 30) / 8 / B; // <= 1 GiB of pools
-    if (cos_cap > budget) cos_cap = budget;
-    if (cos_cap < 4ull * depth + 4096) cos_cap = 4ull * depth + 4096;
-    if (cos_cap > n + depth) cos_cap = n + depth;
-    // BM25: every doc block contributes at most `depth` candidates per query
-    const uint64_t bm_cap = (uint64_t)(idx->n_blocks ? idx->n_blocks : 1) * depth;
+    // cosine: the corpus is scored in chunks; a chunk can append at most one entry per row and
+    // query, so a chunk sized from the pool's free room can never overflow it (no overflow path
+    // to handle, no data-dependent sizing).  BM25: every doc block contributes <= depth entries.
+    const uint32_t carry_cap = OI_MAX_DEPTH;
+    const uint64_t slack = 32ull * ((uint64_t)ctx->num_cus + 1);
+    uint64_t cos_stride = 1ull << 20;
+    const uint64_t budget = (1ull << 30) / 8 / B; // <= 1 GiB of cosine pools
+    if (cos_stride > budget) cos_stride = budget;
+    if (cos_stride < carry_cap + 4 * slack) cos_stride = carry_cap + 4 * slack;
+    if (cos_stride > carry_cap + n + slack) cos_stride = carry_cap + n + slack;
     Pools P;
-    OI_CHECK(prepare_pools(ctx, B, (uint32_t)cos_cap, (uint32_t)bm_cap, &P));
+    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, idx->n_blocks, depth, &P));
 
     // ---- cosine list
     if (cos_s) {
@@ -365,7 +376,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
             q = qp.as<float>();
         }
-        const uint64_t max_chunk = cos_cap - depth;
+        const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
+        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
         uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
         uint64_t r = 0;
         while (r < n) {
@@ -495,16 +507,18 @@ extern "C" int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const uint32_t cap = n_shards * depth;
+    const uint32_t carry_cap = OI_MAX_DEPTH;
+    const uint64_t mstride = (uint64_t)carry_cap + (uint64_t)n_shards * depth;
     DevBuf &flag = ctx->buf("state_flag");
     if (!flag.p) {
         OI_CHECK(flag.ensure(16));
         OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, st));
     }
     DevBuf &pk = ctx->buf("merge_pool"), &pc = ctx->buf("merge_counts");
-    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * cap));
-    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)B));
-    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), nullptr, cap, cap, flag.as<uint32_t>()};
+    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * mstride));
+    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)B * (1 + n_shards)));
+    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), pc.as<uint32_t>() + B, nullptr, mstride, carry_cap,
+                  depth, n_shards, n_shards, flag.as<uint32_t>()};
     const size_t Lin = (size_t)n_shards * B * depth, Cin = (size_t)n_shards * B, L = (size_t)B * depth;
     if (location == OI_DEVICE) {
         OI_CHECK(oi_launch_lists_to_pool(ctx, scores, docs, counts, n_shards, B, depth, pool));

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
     const Posting *__restrict__ postings, const uint32_t *__restrict__ cell_start,
     const float *__restrict__ idf, uint32_t vocab, uint32_t doc_id_base, const uint32_t *__restrict__ q_terms,
     const uint32_t *__restrict__ q_offsets, uint32_t n_queries, uint32_t depth, uint64_t *pools,
-    uint32_t *pool_counts, uint64_t pool_stride, uint32_t pool_cap, uint32_t *overflow) {
+    uint32_t *seg_cnt, uint32_t seg_cnt_stride, uint64_t pool_stride, uint32_t carry_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *acc = reinterpret_cast<float *>(smem);                       // BM_R
     uint32_t *hist = reinterpret_cast<uint32_t *>(acc + BM_R);          // 2048
@@ -352,16 +352,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
             }
             __syncthreads();
         }
-        // ---- flush this block's candidates to the query's pool (one reservation per block)
+        // ---- this block's candidates go to ITS segment of the query's pool (<= depth entries, no atomics)
         const uint32_t cnt = sh[1];
-        if (tid == 0) sh[2] = atomicAdd(&pool_counts[q], cnt);
-        __syncthreads();
-        const uint32_t base_out = sh[2];
-        uint64_t *pool = pools + (uint64_t)q * pool_stride;
-        for (uint32_t i = tid; i < cnt; i += BM_THREADS) {
-            if (base_out + i < pool_cap) pool[base_out + i] = list[i];
-            else *overflow = 1u;
-        }
+        uint64_t *seg = pools + (uint64_t)q * pool_stride + carry_cap + (uint64_t)blk * depth;
+        for (uint32_t i = tid; i < cnt; i += BM_THREADS) seg[i] = list[i];
+        if (tid == 0) seg_cnt[(uint64_t)q * seg_cnt_stride + blk] = cnt;
         __syncthreads();
     }
 }
@@ -373,6 +368,9 @@ int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q
     oi_ctx *ctx = idx->ctx;
     if (n_queries == 0 || idx->n_postings == 0 || idx->n_blocks == 0) return OI_OK;
     OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "bm25: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
+    OI_REQUIRE(pool.seg_cap == depth && pool.n_segs == idx->n_blocks && pool.n_segs <= pool.seg_cnt_stride &&
+                   pool.carry_cap + (uint64_t)pool.n_segs * depth <= pool.stride,
+               "bm25: pool geometry mismatch");
     static bool attr_set = false;
     if (!attr_set) {
         OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_block_kernel),
@@ -388,7 +386,7 @@ int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q
     hipLaunchKernelGGL(bm25_block_kernel, dim3(idx->n_blocks, ysplit), dim3(BM_THREADS), BM_SMEM, ctx->stream,
                        idx->postings.as<Posting>(), idx->cell_start.as<uint32_t>(), idx->idf.as<float>(),
                        idx->vocab, idx->doc_id_base, d_q_terms, d_q_offsets, n_queries, depth, pool.keys,
-                       pool.counts, pool.stride, pool.cap, pool.overflow);
+                       pool.seg_cnt, pool.seg_cnt_stride, pool.stride, pool.carry_cap);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

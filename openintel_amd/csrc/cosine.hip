@@ -9,6 +9,8 @@
 //   cosine_mfma_filter<NQT>  B  > 8 : exact-f32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled.
 //                            (v1 tile kernel; the K-split register-resident kernel is in
 //                            cosine_ksplit.hip)
+#include <cstdlib>
+
 #include "oi_device.h"
 #include "oi_internal.h"
 
@@ -20,9 +22,9 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
                                                            uint64_t row_end, uint32_t dim,
                                                            const float *__restrict__ queries,
                                                            uint32_t doc_id_base, uint64_t *pools,
-                                                           uint32_t *pool_counts, const uint32_t *tau_keys,
-                                                           uint64_t pool_stride, uint32_t pool_cap,
-                                                           uint32_t *overflow) {
+                                                           uint32_t *pool_counts, uint32_t cnt_stride,
+                                                           const uint32_t *tau_keys, uint64_t pool_stride,
+                                                           uint32_t pool_cap, uint32_t *overflow) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
             if ((int)lane == q) mine = a;
         }
         if (lane < NQ && mine == mine && oi_f32_key(mine) >= tau)
-            oi_pool_append(pools + (uint64_t)lane * pool_stride, pool_counts + lane, pool_cap, overflow,
-                           oi_rank_key(mine, doc_id_base + (uint32_t)r));
+            oi_pool_append(pools + (uint64_t)lane * pool_stride, pool_counts + (uint64_t)lane * cnt_stride, pool_cap,
+                           overflow, oi_rank_key(mine, doc_id_base + (uint32_t)r));
     }
 }
 
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(256) void cosine_mfma_filter(const float *__restric
                                                            const float *__restrict__ queries, // [32*NQT][dim], zero padded
                                                            uint32_t n_queries, uint32_t doc_id_base,
                                                            uint64_t *pools, uint32_t *pool_counts,
-                                                           const uint32_t *tau_keys, uint64_t pool_stride,
-                                                           uint32_t pool_cap, uint32_t *overflow) {
+                                                           uint32_t cnt_stride, const uint32_t *tau_keys,
+                                                           uint64_t pool_stride, uint32_t pool_cap,
+                                                           uint32_t *overflow) {
     __shared__ float sA[CM_ROWS * CM_LD];
     __shared__ float sQ[32 * NQT * CM_LD];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -150,11 +153,19 @@ __global__ __launch_bounds__(256) void cosine_mfma_filter(const float *__restric
                 const uint64_t row = r0 + 32u * w + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float s = acc[t][r];
                 if (row < row_end && s == s && oi_f32_key(s) >= tau[t])
-                    oi_pool_append(pools + (uint64_t)q * pool_stride, pool_counts + q, pool_cap, overflow,
-                                   oi_rank_key(s, doc_id_base + (uint32_t)row));
+                    oi_pool_append(pools + (uint64_t)q * pool_stride, pool_counts + (uint64_t)q * cnt_stride, pool_cap,
+                                   overflow, oi_rank_key(s, doc_id_base + (uint32_t)row));
             }
         }
     }
+}
+
+uint64_t oi_cosine_max_chunk_rows(const oi_ctx *ctx, uint32_t dim, uint32_t n_queries, uint64_t stride,
+                                  uint32_t carry_cap) {
+    // K-split: segments are rounded up to whole tiles per workgroup -> up to 32 * (CUs + 1) slack
+    const uint64_t slack = 32ull * ((uint64_t)ctx->num_cus + 1);
+    const uint64_t room = stride - carry_cap;
+    return room > slack ? room - slack : 0; // api.hip sizes the pool so that room >= min(n, 3*slack) + slack
 }
 
 uint32_t oi_cosine_query_padding(uint32_t n_queries) {
@@ -164,7 +175,16 @@ uint32_t oi_cosine_query_padding(uint32_t n_queries) {
 
 int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end,
                            uint32_t dim, const float *d_queries, uint32_t n_queries,
-                           uint32_t n_queries_padded, uint32_t doc_id_base, const PoolView &pool) {
+                           uint32_t n_queries_padded, uint32_t doc_id_base, PoolView &pool) {
+    static const bool force_v1 = getenv("OI_COSINE_V1") != nullptr; // A/B switch for benchmarking
+    const bool ksplit = n_queries > 8 && !force_v1 && oi_cosine_ksplit_supported(dim);
+    if (ksplit) oi_cosine_ksplit_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
+    else { // atomic-append kernels use one segment spanning the whole appended region
+        pool.n_segs = 1;
+        pool.seg_cap = (uint32_t)(pool.stride - pool.carry_cap);
+    }
+    OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
+               "cosine: chunk does not fit the candidate pool");
     if (row_end <= row_begin || n_queries == 0) return OI_OK;
     OI_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= OI_MAX_DIM, "cosine: dim=%u must be a multiple of 4 in [4,%u]",
                dim, OI_MAX_DIM);
@@ -178,8 +198,8 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         dim3 g((uint32_t)blocks), b(256);
 #define OI_GEMV(NQ)                                                                                     \
     hipLaunchKernelGGL(cosine_gemv_filter<NQ>, g, b, 0, ctx->stream, rows, row_begin, row_end, dim,     \
-                       d_queries, doc_id_base, pool.keys, pool.counts, pool.tau_keys, pool.stride,      \
-                       pool.cap, pool.overflow)
+                       d_queries, doc_id_base, pool.keys + pool.carry_cap, pool.seg_cnt,                 \
+                       pool.seg_cnt_stride, pool.tau_keys, pool.stride, pool.seg_cap, pool.overflow)
         // queries beyond n_queries are not readable: dispatch on the exact count
         switch (n_queries) {
             case 1: OI_GEMV(1); break;
@@ -205,17 +225,21 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         const uint32_t nq_here = (n_queries - q0) < 64 ? (n_queries - q0) : 64;
         PoolView p = pool;
         p.keys += (uint64_t)q0 * pool.stride;
-        p.counts += q0;
+        p.carry_cnt += q0;
+        p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
         p.tau_keys += q0;
         const float *qptr = d_queries + (uint64_t)q0 * dim;
-        if (left >= 64)
+        if (ksplit) {
+            OI_CHECK(oi_launch_cosine_ksplit(ctx, rows, row_begin, row_end, dim, qptr, nq_here, left >= 64,
+                                             doc_id_base, p));
+        } else if (left >= 64)
             hipLaunchKernelGGL(cosine_mfma_filter<2>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows,
-                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys, p.counts, p.tau_keys,
-                               p.stride, p.cap, p.overflow);
+                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys + p.carry_cap, p.seg_cnt,
+                               p.seg_cnt_stride, p.tau_keys, p.stride, p.seg_cap, p.overflow);
         else
             hipLaunchKernelGGL(cosine_mfma_filter<1>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows,
-                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys, p.counts, p.tau_keys,
-                               p.stride, p.cap, p.overflow);
+                               row_begin, row_end, dim, qptr, nq_here, doc_id_base, p.keys + p.carry_cap, p.seg_cnt,
+                               p.seg_cnt_stride, p.tau_keys, p.stride, p.seg_cap, p.overflow);
         OI_HIP_CHECK(hipGetLastError());
         if (q0 + 64 >= n_queries) break;
     }

@@ -1,0 +1,296 @@
+// cosine_ksplit.hip -- the batch (B > 8) cosine scorer for gfx950: exact-f32 MFMA with the
+// query block RESIDENT IN REGISTERS and the corpus streamed once through per-wave LDS rings.
+//
+// Why this shape.  At B = 64, d = 768 the scorer needs 2*64 = 128 flop per corpus byte... per
+// 4-byte element, i.e. 32 flop/B: the f32 MFMA peak (157 TF) and the HBM rate (~6.3 TB/s
+// achievable) bind at almost the same time (6.3 ms vs 4.9 ms for 10M rows), so the kernel must
+// keep the matrix pipes issuing back to back WHILE streaming ~5 TB/s.  A conventional LDS-tiled
+// GEMM re-stages the 196 KB query block (it does not fit in 160 KB of LDS) for every row tile.
+// Instead:
+//   * one persistent workgroup per CU, 4 waves, one per SIMD, each owning the full 512-register
+//     file: the K dimension is split over the 4 waves (wave w owns k in [w*D/4, (w+1)*D/4)), so a
+//     wave's slice of all 64 queries is 2 * D/8 = 192 VGPRs (d = 768) -- loaded once per launch;
+//   * each wave streams ITS K-slice of the rows into ITS OWN LDS ring (6 x 4 KiB) with
+//     global_load_lds_dwordx4 (full 128-B lines, swizzled through the per-lane source address so
+//     the ds_read_b128 fragment reads are conflict-free), 5 chunks ahead, ordered only by its own
+//     counted s_waitcnt vmcnt -- no barrier in the main loop, and the prefetch runs across tile
+//     boundaries, under the epilogue;
+//   * per 32-row tile each wave issues D/4/2*2 = 192 v_mfma_f32_32x32x2_f32 (12288 cycles), then
+//     the four partial 32x64 tiles are summed through LDS in a fixed order, compared with the
+//     per-query threshold, and the survivors stored straight into THIS workgroup's private segment
+//     of each query's candidate pool (fill counters in LDS): no global atomic, no returning
+//     memory operation, hence nothing that would make a wave drain its DMA ring.
+//
+// Operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] is accumulator register r.
+#include <type_traits>
+
+#include "oi_device.h"
+#include "oi_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define KS_TILE_ROWS 32
+#define KS_CHUNK_K 32                       // floats of K per ring slot row (128 B)
+#define KS_SLOT_BYTES (KS_TILE_ROWS * KS_CHUNK_K * 4) // 4 KiB
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// Four 1-KiB LDS-DMA pieces = one ring slot.  hipcc does not see these loads: they are ordered
+// by ks_wait<N>() below (cdna_hip_programming.md section 5.7).  M0 carries the LDS destination.
+__device__ __forceinline__ void ks_issue_slot(const float *p0, const float *p1, const float *p2,
+                                              const float *p3, uint32_t lds_dst) {
+    uint32_t keep;
+    const uint32_t d0 = __builtin_amdgcn_readfirstlane(lds_dst);
+    const uint32_t d1 = d0 + 1024, d2 = d0 + 2048, d3 = d0 + 3072;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, off\n\t"
+        "s_mov_b32 m0, %7\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_mov_b32 m0, %8\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
+        : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void ks_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ks_static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void ks_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ks_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int D, int NQT>
+__global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
+    const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const float *__restrict__ queries, // [32*NQT][D], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int KS = D / 4;            // K-slice of one wave
+    constexpr int NKC = KS / KS_CHUNK_K; // ring slots per tile and wave
+    constexpr int NBUF = NKC <= 6 ? NKC : NKC / 2;
+    constexpr int P = NBUF - 1;          // slots in flight ahead of the one being consumed
+    constexpr int QR = KS / 2;           // query registers per 32-query tile
+    static_assert(KS % KS_CHUNK_K == 0 && NKC % NBUF == 0 && P >= 1 && P < NKC, "unsupported D");
+    constexpr int RED_FLOATS = NQT * 16 * 64; // one wave's partial tile
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                 // [4][NBUF][4 KiB]
+    float *red = reinterpret_cast<float *>(smem + 4 * NBUF * KS_SLOT_BYTES);    // [4][RED_FLOATS]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 4 * RED_FLOATS);    // [32*NQT] entries written so far
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t li = lane & 31, lh = lane >> 5;
+
+    // ---- this wave's K-slice of every query, in registers for the whole launch
+    float qreg[NQT][QR];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int s = 0; s < KS / 8; ++s) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(queries + (uint64_t)(32 * t + li) * D + w * KS + 8 * s + 4 * lh);
+            qreg[t][4 * s + 0] = v[0]; qreg[t][4 * s + 1] = v[1]; qreg[t][4 * s + 2] = v[2]; qreg[t][4 * s + 3] = v[3];
+        }
+    // thresholds of the two queries this thread filters in the epilogue
+    uint32_t tau[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32u * t + li;
+        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+    }
+    if (tid < 64) seg_fill[tid] = 0;
+
+    // ---- tiles of this workgroup: blockIdx.x, + gridDim.x, ...
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + KS_TILE_ROWS - 1) / KS_TILE_ROWS;
+    const uint64_t my_nt = blockIdx.x < n_tiles ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_nt == 0) return;
+    // this workgroup's segment of query q: pools[q*stride + carry_cap + blockIdx.x*seg_cap ..)
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+
+    // per-lane source of the 4 DMA pieces of a slot: piece m covers tile rows 8m..8m+7;
+    // lane l -> row 8m + (l>>3), physical 16-B column l&7 holding LOGICAL column (l&7) ^ ((row>>1)&7)
+    uint32_t piece_row[4], piece_col[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        piece_row[m] = 8 * m + (lane >> 3);
+        piece_col[m] = ((lane & 7) ^ ((piece_row[m] >> 1) & 7)) * 4 + w * KS; // float offset in the row
+    }
+    const uint64_t last_row = row_end - 1;
+    auto tile_ptrs = [&](uint64_t ti, const float *(&p)[4]) {
+        const uint64_t r0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            uint64_t r = r0 + piece_row[m];
+            r = r < last_row ? r : last_row; // ragged last tile: re-read the last row, masked later
+            p[m] = rows + r * D + piece_col[m];
+        }
+    };
+    const uint32_t ring_w = lds_addr(ring) + w * (NBUF * KS_SLOT_BYTES);
+    const unsigned char *ring_rd = ring + w * (NBUF * KS_SLOT_BYTES);
+    // fragment read address inside a slot: row li, logical 16-B column (2g + lh)
+    uint32_t frag_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
+
+    const float *cur[4], *nxt[4];
+    tile_ptrs(0, cur);
+    tile_ptrs(my_nt > 1 ? 1 : 0, nxt);
+    // Every load hipcc knows about (queries, thresholds) is retired HERE, with a wait it models:
+    // otherwise it re-waits for them at the top of the tile loop (vmcnt(1)) and drains the DMA ring.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+    // prologue: slots 0..P-1 of the first tile
+#pragma unroll
+    for (int kc = 0; kc < P; ++kc)
+        ks_issue_slot(cur[0] + kc * KS_CHUNK_K, cur[1] + kc * KS_CHUNK_K, cur[2] + kc * KS_CHUNK_K,
+                      cur[3] + kc * KS_CHUNK_K, ring_w + (kc % NBUF) * KS_SLOT_BYTES);
+
+    for (uint64_t ti = 0; ti < my_nt; ++ti) {
+        const bool has_next_tile = ti + 1 < my_nt;
+        f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+        // Slot s of this tile lives in ring buffer s % NBUF.  Schedule per tile:
+        //   start      : issue slot P, wait -> slot 0 landed, read fragment (0,0)
+        //   group (kc,g): read the NEXT fragment first, then 4*NQT MFMAs on the current one;
+        //                at g == 3 the next fragment is (kc+1, 0): slot kc's four fragments are
+        //                all in registers by then, so its buffer is refilled (slot kc+1+P) and
+        //                the counted wait retires slot kc+1.
+        ks_issue_slot(cur[0] + P * KS_CHUNK_K, cur[1] + P * KS_CHUNK_K, cur[2] + P * KS_CHUNK_K,
+                      cur[3] + P * KS_CHUNK_K, ring_w + (P % NBUF) * KS_SLOT_BYTES);
+        ks_wait<4 * P>();
+        f32x4 a_cur = *reinterpret_cast<const f32x4 *>(ring_rd + frag_off[0]);
+        ks_static_for<0, NKC * 4>([&](auto gi_) {
+            constexpr int gi = decltype(gi_)::value;
+            constexpr int kc = gi / 4, g = gi % 4;
+            f32x4 a_nxt = a_cur;
+            if constexpr (g < 3) {
+                a_nxt = *reinterpret_cast<const f32x4 *>(ring_rd + (kc % NBUF) * KS_SLOT_BYTES + frag_off[g + 1]);
+            } else if constexpr (kc + 1 < NKC) {
+                constexpr int sn = kc + 1 + P; // refill this slot's buffer
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // fragment (kc,3) is in registers
+                if constexpr (sn < NKC) {
+                    ks_issue_slot(cur[0] + sn * KS_CHUNK_K, cur[1] + sn * KS_CHUNK_K, cur[2] + sn * KS_CHUNK_K,
+                                  cur[3] + sn * KS_CHUNK_K, ring_w + (sn % NBUF) * KS_SLOT_BYTES);
+                    ks_wait<4 * P>();
+                } else if (has_next_tile) {
+                    constexpr int kn = sn - NKC;
+                    ks_issue_slot(nxt[0] + kn * KS_CHUNK_K, nxt[1] + kn * KS_CHUNK_K, nxt[2] + kn * KS_CHUNK_K,
+                                  nxt[3] + kn * KS_CHUNK_K, ring_w + (sn % NBUF) * KS_SLOT_BYTES);
+                    ks_wait<4 * P>();
+                } else {
+                    ks_wait<4 * (NKC - 2 - kc)>();
+                }
+                a_nxt = *reinterpret_cast<const f32x4 *>(ring_rd + ((kc + 1) % NBUF) * KS_SLOT_BYTES + frag_off[0]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], qreg[t][(kc * 4 + g) * 4 + j], acc[t], 0, 0, 0);
+            a_cur = a_nxt;
+        });
+
+        // ---- epilogue: sum the four K-slices, filter, stage survivors
+        float *my_red = red + w * RED_FLOATS;
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) my_red[(t * 16 + r) * 64 + lane] = acc[t][r];
+        ks_barrier(); // (A) partials visible
+        const uint64_t tile_row0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
+#pragma unroll
+        for (int i = 0; i < NQT * 4; ++i) {
+            const uint32_t e = tid + 256u * i; // (t = i>>2, r = (e>>6)&15, lane)
+            const float s = (red[e] + red[RED_FLOATS + e]) + (red[2 * RED_FLOATS + e] + red[3 * RED_FLOATS + e]);
+            const uint32_t t = i >> 2, r = (e >> 6) & 15u;
+            const uint32_t q = 32u * t + li;
+            const uint64_t row = tile_row0 + (r & 3u) + 8u * (r >> 2) + 4u * lh;
+            if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+                const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+                if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+                else *overflow = 1u;
+            }
+        }
+        ks_barrier(); // (B) `red` may be rewritten by the next tile
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cur[m] = nxt[m];
+        if (ti + 2 < my_nt) tile_ptrs(ti + 2, nxt);
+    }
+    // publish this segment's fill counts (LDS atomics of every wave are complete after barrier B)
+    if (tid < 32 * NQT && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
+template <int D, int NQT>
+static int launch_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const float *q,
+                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    constexpr int KS = D / 4, NKC = KS / KS_CHUNK_K, NBUF = NKC <= 6 ? NKC : NKC / 2;
+    constexpr size_t smem = 4 * NBUF * KS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_ksplit_filter<D, NQT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((cosine_ksplit_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
+                       row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
+                       p.carry_cap, p.seg_cap, p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+bool oi_cosine_ksplit_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
+
+// Pool geometry for one chunk: one segment per workgroup, sized for the worst case (every score of
+// every tile that workgroup owns passes the filter).
+void oi_cosine_ksplit_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
+    const uint64_t n_tiles = (n_rows + KS_TILE_ROWS - 1) / KS_TILE_ROWS;
+    const uint64_t grid = n_tiles < (uint64_t)ctx->num_cus ? n_tiles : (uint64_t)ctx->num_cus;
+    *n_segs = (uint32_t)grid;
+    *seg_cap = (uint32_t)((n_tiles + grid - 1) / grid) * KS_TILE_ROWS;
+}
+
+// One group of <= 64 queries (zero padded to 32 or 64 rows at `q`).
+int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                            const float *q, uint32_t nq, bool two_tiles, uint32_t doc_id_base, const PoolView &p) {
+#define OI_KS(DD)                                                                                       \
+    case DD:                                                                                            \
+        return two_tiles ? launch_ksplit<DD, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)   \
+                         : launch_ksplit<DD, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+    switch (dim) {
+        OI_KS(384)
+        OI_KS(768)
+        OI_KS(1024)
+        default:
+            oi_set_error("cosine_ksplit: dim %u not instantiated", dim);
+            return OI_ERR_UNSUPPORTED;
+    }
+#undef OI_KS
+}

@@ -120,13 +120,22 @@ int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double
                              const uint8_t *d_spec, uint64_t n, double tau,
                              oi_social_counters *out_host);
 // select.hip
+// Candidate pools, one per query, never touched by a global atomic in the batch kernels:
+//   keys[q*stride + 0 .. carry_cap)                    the top-k carried over from earlier corpus chunks
+//   keys[q*stride + carry_cap + s*seg_cap ..)          segment s: written by exactly one producer
+//                                                      (cosine: workgroup s; BM25: doc block s)
+//   carry_cnt[q], seg_cnt[q*seg_cnt_stride + s]        fill counts
 struct PoolView {
-    uint64_t *keys;      // [n_queries][stride]
-    uint32_t *counts;    // [n_queries]
-    uint32_t *tau_keys;  // [n_queries] orderable-u32 threshold (0 = accept all)
-    uint64_t stride;     // entries between consecutive queries' pools
-    uint32_t cap;        // usable entries per pool
-    uint32_t *overflow;  // single device word, set nonzero on overflow
+    uint64_t *keys;
+    uint32_t *carry_cnt;      // [n_queries]
+    uint32_t *seg_cnt;        // [n_queries][seg_cnt_stride]
+    uint32_t *tau_keys;       // [n_queries] orderable-u32 threshold (0 = accept all); may be null
+    uint64_t stride;          // u64 entries between consecutive queries' pools
+    uint32_t carry_cap;       // entries reserved for the carried top-k (>= k)
+    uint32_t seg_cap;         // entries per segment
+    uint32_t n_segs;          // segments in use
+    uint32_t seg_cnt_stride;  // allocated segments per query
+    uint32_t *overflow;       // single device word, set nonzero if a segment overflowed (bug guard)
 };
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
                      float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride);
@@ -137,11 +146,20 @@ int oi_launch_rrf(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a,
                   const uint32_t *counts_b, uint32_t n_queries, uint32_t depth, uint32_t k,
                   float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 // cosine.hip
+// Sets pool.n_segs / pool.seg_cap for this chunk (the following select must use the same view).
 int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end,
                            uint32_t dim, const float *d_queries_padded, uint32_t n_queries,
-                           uint32_t n_queries_padded, uint32_t doc_id_base, const PoolView &pool);
+                           uint32_t n_queries_padded, uint32_t doc_id_base, PoolView &pool);
+// Largest chunk (rows) that can never overflow a pool of `stride` entries per query.
+uint64_t oi_cosine_max_chunk_rows(const oi_ctx *ctx, uint32_t dim, uint32_t n_queries, uint64_t stride,
+                                  uint32_t carry_cap);
 int oi_launch_l2_normalize(oi_ctx *ctx, float *rows, uint64_t n, uint32_t dim);
 uint32_t oi_cosine_query_padding(uint32_t n_queries);
+// cosine_ksplit.hip
+bool oi_cosine_ksplit_supported(uint32_t dim);
+void oi_cosine_ksplit_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap);
+int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                            const float *q, uint32_t nq, bool two_tiles, uint32_t doc_id_base, const PoolView &p);
 // bm25.hip
 int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets);
 int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, const uint32_t *global_df_host);

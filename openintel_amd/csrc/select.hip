@@ -27,32 +27,82 @@ __device__ void bitonic_sort_desc(uint64_t *a, uint32_t P) {
     }
 }
 
-// Top-k of pool q.  Radix select (8 passes of 8 bits, early exit once the k-th key is
-// alone in its bin) + gather + bitonic sort.  compact: the pool is rewritten to hold
-// exactly the selected keys, so the next corpus chunk appends after them.
+// Top-k of pool q (carry region + segments, see PoolView).  Small pools are gathered into LDS
+// once; the radix select (8 passes of 8 bits from the top, stopping as soon as the k-th key is
+// alone in its bin) then runs out of LDS.  Large pools are scanned in place, one wave per segment.
+// compact: the pool is rewritten as carry = the selected keys, all segments empty, and the
+// threshold raised to the k-th score, so the next corpus chunk appends after them.
+#define SEL_LDS_KEYS 4096
+
+struct SelSource {
+    const uint64_t *pool;      // this query's pool
+    const uint32_t *segc;      // this query's segment counts
+    const uint64_t *lds_keys;  // non-null: everything already gathered here
+    uint32_t n, c0, carry_cap, seg_cap, n_segs;
+};
+
+template <class F>
+__device__ __forceinline__ void sel_for_each(const SelSource &S, F &&f) {
+    const uint32_t tid = threadIdx.x;
+    if (S.lds_keys) {
+        for (uint32_t i = tid; i < S.n; i += SEL_THREADS) f(S.lds_keys[i]);
+        return;
+    }
+    for (uint32_t i = tid; i < S.c0; i += SEL_THREADS) f(S.pool[i]);
+    const uint32_t lane = tid & 63, wv = tid >> 6;
+    for (uint32_t sg = wv; sg < S.n_segs; sg += SEL_THREADS / 64) {
+        uint32_t c = S.segc[sg];
+        if (c > S.seg_cap) c = S.seg_cap;
+        const uint64_t *base = S.pool + S.carry_cap + (uint64_t)sg * S.seg_cap;
+        for (uint32_t i = lane; i < c; i += 64) f(base[i]);
+    }
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
-    uint64_t *pools, uint32_t *pool_counts, uint32_t *tau_keys, uint64_t pool_stride,
-    uint32_t pool_cap, uint32_t *overflow, uint32_t k, int compact, float *out_scores,
-    uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+    uint64_t *pools, uint32_t *carry_cnt, uint32_t *seg_cnt, uint32_t *tau_keys, uint64_t pool_stride,
+    uint32_t carry_cap, uint32_t seg_cap, uint32_t n_segs, uint32_t seg_cnt_stride, uint32_t *overflow,
+    uint32_t k, int compact, float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
     __shared__ uint32_t hist[256];
     __shared__ uint64_t sel[2 * SEL_MAX];
-    __shared__ uint32_t s_cnt, s_kk, s_bin_cnt;
+    __shared__ uint64_t lds_keys[SEL_LDS_KEYS];
+    __shared__ uint32_t s_cnt, s_kk, s_bin_cnt, s_total;
     __shared__ uint64_t s_prefix;
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     uint64_t *pool = pools + (uint64_t)q * pool_stride;
-    uint32_t n = pool_counts[q];
-    if (n > pool_cap) {
-        if (tid == 0) *overflow = 1u;
-        n = pool_cap;
-    }
-    uint32_t m; // number selected
-    if (tid == 0) s_cnt = 0;
+    uint32_t *segc = seg_cnt + (uint64_t)q * seg_cnt_stride;
+    SelSource S;
+    S.pool = pool; S.segc = segc; S.lds_keys = nullptr;
+    S.carry_cap = carry_cap; S.seg_cap = seg_cap; S.n_segs = n_segs;
+    S.c0 = carry_cnt[q] < carry_cap ? carry_cnt[q] : carry_cap;
+    if (tid == 0) { s_cnt = 0; s_total = 0; }
     __syncthreads();
+    {
+        uint32_t local = 0;
+        for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) {
+            uint32_t c = segc[sg];
+            if (c > seg_cap) { *overflow = 1u; c = seg_cap; }
+            local += c;
+        }
+        local = oi_wave_sum(local);
+        if ((tid & 63) == 0 && local) atomicAdd(&s_total, local);
+    }
+    __syncthreads();
+    const uint32_t n = S.c0 + s_total;
+    S.n = n;
+    if (n <= SEL_LDS_KEYS) {
+        sel_for_each(S, [&](uint64_t key) { lds_keys[atomicAdd(&s_cnt, 1u)] = key; });
+        __syncthreads();
+        S.lds_keys = lds_keys;
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+    }
 
+    uint32_t m; // number selected
     if (n <= k) {
-        for (uint32_t i = tid; i < n; i += SEL_THREADS) sel[i] = pool[i];
+        sel_for_each(S, [&](uint64_t key) { sel[atomicAdd(&s_cnt, 1u)] = key; });
         m = n;
+        __syncthreads();
     } else {
         if (tid == 0) { s_prefix = 0; s_kk = k; }
         int shift = 56;
@@ -60,36 +110,49 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
             if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const uint64_t prefix = s_prefix;
-            for (uint32_t i = tid; i < n; i += SEL_THREADS) {
-                uint64_t key = pool[i];
-                if (shift == 56 || (key >> (shift + 8)) == prefix)
-                    atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
-            }
+            if (shift == 56)
+                sel_for_each(S, [&](uint64_t key) { atomicAdd(&hist[(uint32_t)(key >> 56)], 1u); });
+            else
+                sel_for_each(S, [&](uint64_t key) {
+                    if ((key >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & 255u], 1u);
+                });
             __syncthreads();
-            if (tid == 0) {
-                uint32_t kk = s_kk, cum = 0;
-                int d = 255;
-                for (; d > 0; --d) {
-                    uint32_t c = hist[d];
-                    if (cum + c >= kk) break;
-                    cum += c;
+            if (tid < 64) { // wave 0: find the digit holding the kk-th key counted from the top
+                const uint32_t kk = s_kk;
+                uint32_t mine = 0;
+                for (int i = 0; i < 4; ++i) mine += hist[255 - (tid * 4 + i)];
+                uint32_t incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    uint32_t v = __shfl_up(incl, o, OI_WAVE);
+                    if ((int)tid >= o) incl += v;
                 }
-                s_prefix = (prefix << 8) | (uint64_t)d;
-                s_kk = kk - cum;
-                s_bin_cnt = hist[d];
+                const unsigned long long ball = __ballot(incl >= kk);
+                const uint32_t owner = ball ? (uint32_t)__builtin_ctzll(ball) : 63u;
+                if (tid == owner) {
+                    uint32_t cum = incl - mine;
+                    int d = 255 - (int)(tid * 4);
+                    for (int i = 0; i < 3; ++i, --d) {
+                        const uint32_t c = hist[d];
+                        if (cum + c >= kk) break;
+                        cum += c;
+                    }
+                    s_prefix = (prefix << 8) | (uint64_t)d;
+                    s_kk = kk - cum;
+                    s_bin_cnt = hist[d];
+                }
             }
             __syncthreads();
             if (s_bin_cnt == 1 || shift == 0) break;
         }
-        // every key whose top bits are >= prefix is selected: exactly k of them
+        // every key whose top bits are >= prefix is selected: exactly k of them (keys are distinct)
         const uint64_t prefix = s_prefix;
-        for (uint32_t i = tid; i < n; i += SEL_THREADS) {
-            uint64_t key = pool[i];
+        sel_for_each(S, [&](uint64_t key) {
             if ((key >> shift) >= prefix) {
-                uint32_t pos = atomicAdd(&s_cnt, 1u);
+                const uint32_t pos = atomicAdd(&s_cnt, 1u);
                 if (pos < SEL_MAX) sel[pos] = key;
             }
-        }
+        });
         __syncthreads();
         m = s_cnt < k ? s_cnt : k;
     }
@@ -101,7 +164,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
 
     if (out_scores) {
         for (uint32_t i = tid; i < m; i += SEL_THREADS) {
-            uint64_t key = sel[i];
+            const uint64_t key = sel[i];
             out_scores[(uint64_t)q * out_stride + i] = oi_rank_key_score(key);
             out_docs[(uint64_t)q * out_stride + i] = oi_rank_key_doc(key);
         }
@@ -109,12 +172,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
     }
     if (compact) {
         for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = sel[i];
+        for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) segc[sg] = 0;
         if (tid == 0) {
-            pool_counts[q] = m;
+            carry_cnt[q] = m;
             if (m == k && tau_keys) {
                 // k docs at or above this score exist: a valid lower bound for the final
                 // k-th score, so later chunks may drop anything strictly below it.
-                uint32_t t = (uint32_t)(sel[k - 1] >> 32);
+                const uint32_t t = (uint32_t)(sel[k - 1] >> 32);
                 if (t > tau_keys[q]) tau_keys[q] = t;
             }
         }
@@ -124,40 +188,41 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
                      float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
     if (n_queries == 0) return OI_OK;
-    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
+    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH && k <= pool.carry_cap, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
     ProfScope ps(ctx, "select");
     hipLaunchKernelGGL(select_topk_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, pool.keys,
-                       pool.counts, pool.tau_keys, pool.stride, pool.cap, pool.overflow, k, compact ? 1 : 0,
-                       out_scores, out_docs, out_counts, out_stride);
+                       pool.carry_cnt, pool.seg_cnt, pool.tau_keys, pool.stride, pool.carry_cap, pool.seg_cap,
+                       pool.n_segs, pool.seg_cnt_stride, pool.overflow, k, compact ? 1 : 0, out_scores, out_docs,
+                       out_counts, out_stride);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
 
-// [n_shards][n_queries][depth] lists -> one pool per query (keys rebuilt from score/doc).
+// [n_shards][n_queries][depth] lists -> pool segment s of query q = shard s's list (keys rebuilt).
 __global__ void lists_to_pool_kernel(const float *scores, const uint32_t *docs, const uint32_t *counts,
-                                     uint32_t n_shards, uint32_t n_queries, uint32_t depth,
-                                     uint64_t *pools, uint32_t *pool_counts, uint64_t pool_stride) {
-    const uint32_t q = blockIdx.x;
-    uint64_t *pool = pools + (uint64_t)q * pool_stride;
-    uint32_t base = 0;
-    for (uint32_t s = 0; s < n_shards; ++s) {
-        uint32_t c = counts[(uint64_t)s * n_queries + q];
-        if (c > depth) c = depth;
-        const uint64_t src = ((uint64_t)s * n_queries + q) * depth;
-        for (uint32_t i = threadIdx.x; i < c; i += blockDim.x)
-            pool[base + i] = oi_rank_key(scores[src + i], docs[src + i]);
-        base += c;
+                                     uint32_t n_queries, uint32_t depth, uint64_t *pools, uint32_t *carry_cnt,
+                                     uint32_t *seg_cnt, uint64_t pool_stride, uint32_t carry_cap,
+                                     uint32_t seg_cnt_stride) {
+    const uint32_t q = blockIdx.x, sh = blockIdx.y;
+    uint32_t c = counts[(uint64_t)sh * n_queries + q];
+    if (c > depth) c = depth;
+    const uint64_t src = ((uint64_t)sh * n_queries + q) * depth;
+    uint64_t *seg = pools + (uint64_t)q * pool_stride + carry_cap + (uint64_t)sh * depth;
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) seg[i] = oi_rank_key(scores[src + i], docs[src + i]);
+    if (threadIdx.x == 0) {
+        seg_cnt[(uint64_t)q * seg_cnt_stride + sh] = c;
+        if (sh == 0) carry_cnt[q] = 0;
     }
-    if (threadIdx.x == 0) pool_counts[q] = base;
 }
 
 int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
                             const uint32_t *counts, uint32_t n_shards, uint32_t n_queries,
                             uint32_t depth, const PoolView &pool) {
     if (n_queries == 0) return OI_OK;
-    OI_REQUIRE((uint64_t)n_shards * depth <= pool.cap, "merge: pool too small");
-    hipLaunchKernelGGL(lists_to_pool_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, scores, docs,
-                       counts, n_shards, n_queries, depth, pool.keys, pool.counts, pool.stride);
+    OI_REQUIRE(pool.seg_cap == depth && pool.n_segs == n_shards, "merge: pool geometry mismatch");
+    hipLaunchKernelGGL(lists_to_pool_kernel, dim3(n_queries, n_shards), dim3(256), 0, ctx->stream, scores, docs,
+                       counts, n_queries, depth, pool.keys, pool.carry_cnt, pool.seg_cnt, pool.stride,
+                       pool.carry_cap, pool.seg_cnt_stride);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
