@@ -23,6 +23,7 @@
 //
 // Operand maps (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5] and
 // B[k = l>>5][j = l&31]; D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31] is accumulator register r.
+#include <cstdlib>
 #include <type_traits>
 
 #include "oi_device.h"
@@ -42,7 +43,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) {
 // Four 1-KiB LDS-DMA pieces = one ring slot.  hipcc does not see these loads: they are ordered
 // by ks_wait<N>() below (cdna_hip_programming.md section 5.7).  M0 carries the LDS destination.
 __device__ __forceinline__ void ks_issue_slot(const float *p0, const float *p1, const float *p2,
-                                              const float *p3, uint32_t lds_dst) {
+                                              const float *p3, uint32_t lds_dst, bool skip = false) {
+    if (skip) return;
     uint32_t keep;
     const uint32_t d0 = __builtin_amdgcn_readfirstlane(lds_dst);
     const uint32_t d1 = d0 + 1024, d2 = d0 + 2048, d3 = d0 + 3072;
@@ -65,6 +67,37 @@ __device__ __forceinline__ void ks_issue_slot(const float *p0, const float *p1, 
         : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(d0), "s"(d1), "s"(d2), "s"(d3)
         : "memory");
 }
+// One 1-KiB LDS-DMA piece (8 rows x 128 B), issued one per MFMA group.  buffer_load ... lds with a
+// wave-uniform descriptor and a 32-bit per-lane offset: its issue is short enough to hide under a
+// 64-cycle matrix instruction (a global_load_lds with 64-bit per-lane addresses is not -- it cost
+// ~80 exposed cycles per piece here).  Lanes past the descriptor's end read as zero: the ragged
+// last tile needs no clamping.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ks_make_srd(const float *base, uint64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu); // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void ks_issue_piece(const u32x4 &srd, uint32_t voff, uint32_t soff, uint32_t lds_dst,
+                                               bool skip) {
+    if (skip) return;
+    uint32_t keep;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(so), "s"(d)
+        : "memory");
+}
 template <int I, int N, class F>
 __device__ __forceinline__ void ks_static_for(F &&f) {
     if constexpr (I < N) {
@@ -76,16 +109,23 @@ template <int N>
 __device__ __forceinline__ void ks_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// keep a value alive without cost (diagnostic builds).  Inline asm with AMDGPU constraints must
+// live in __device__ functions: directly inside a __global__ body it silently drops the host stub.
+__device__ __forceinline__ void ks_keep(const f32x4 &v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void ks_keep(const f32x16 &v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ void ks_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void ks_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int D, int NQT>
+template <int D, int NQT, int DBG>
 __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
     const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
     const float *__restrict__ queries, // [32*NQT][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
     const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    // DBG (diagnostic instantiations only, results are then wrong): 1 = no DMA, 2 = no MFMA, 4 = no epilogue,
+    // 8 = every workgroup re-reads the same 64 tiles (DMA served from L2/MALL instead of HBM)
     constexpr int KS = D / 4;            // K-slice of one wave
     constexpr int NKC = KS / KS_CHUNK_K; // ring slots per tile and wave
     constexpr int NBUF = NKC <= 6 ? NKC : NKC / 2;
@@ -137,16 +177,6 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
         piece_row[m] = 8 * m + (lane >> 3);
         piece_col[m] = ((lane & 7) ^ ((piece_row[m] >> 1) & 7)) * 4 + w * KS; // float offset in the row
     }
-    const uint64_t last_row = row_end - 1;
-    auto tile_ptrs = [&](uint64_t ti, const float *(&p)[4]) {
-        const uint64_t r0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            uint64_t r = r0 + piece_row[m];
-            r = r < last_row ? r : last_row; // ragged last tile: re-read the last row, masked later
-            p[m] = rows + r * D + piece_col[m];
-        }
-    };
     const uint32_t ring_w = lds_addr(ring) + w * (NBUF * KS_SLOT_BYTES);
     const unsigned char *ring_rd = ring + w * (NBUF * KS_SLOT_BYTES);
     // fragment read address inside a slot: row li, logical 16-B column (2g + lh)
@@ -154,17 +184,28 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
 #pragma unroll
     for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
 
-    const float *cur[4], *nxt[4];
-    tile_ptrs(0, cur);
-    tile_ptrs(my_nt > 1 ? 1 : 0, nxt);
+    constexpr bool no_dma = DBG & 1, no_mfma = DBG & 2, no_epi = DBG & 4;
+    // DMA addressing: a descriptor per tile (wave-uniform base = the tile's first row), one 32-bit
+    // per-lane offset per piece (row * row bytes + swizzled column), the slot's K offset in soffset
+    uint32_t voff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) voff[m] = piece_row[m] * (uint32_t)(D * 4) + piece_col[m] * 4u;
+    auto tile_srd = [&](uint64_t ti) {
+        uint64_t tile_id = blockIdx.x + ti * gridDim.x;
+        if constexpr ((DBG & 8) != 0) tile_id &= 63;
+        const uint64_t r0 = row_begin + tile_id * (uint64_t)KS_TILE_ROWS;
+        return ks_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 4));
+    };
+    u32x4 cur = tile_srd(0), nxt = tile_srd(my_nt > 1 ? 1 : 0);
     // Every load hipcc knows about (queries, thresholds) is retired HERE, with a wait it models:
     // otherwise it re-waits for them at the top of the tile loop (vmcnt(1)) and drains the DMA ring.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
     // prologue: slots 0..P-1 of the first tile
 #pragma unroll
     for (int kc = 0; kc < P; ++kc)
-        ks_issue_slot(cur[0] + kc * KS_CHUNK_K, cur[1] + kc * KS_CHUNK_K, cur[2] + kc * KS_CHUNK_K,
-                      cur[3] + kc * KS_CHUNK_K, ring_w + (kc % NBUF) * KS_SLOT_BYTES);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            ks_issue_piece(cur, voff[m], kc * KS_CHUNK_K * 4, ring_w + (kc % NBUF) * KS_SLOT_BYTES + m * 1024, no_dma);
 
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
         const bool has_next_tile = ti + 1 < my_nt;
@@ -175,47 +216,55 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
         // Slot s of this tile lives in ring buffer s % NBUF.  Schedule per tile:
-        //   start      : issue slot P, wait -> slot 0 landed, read fragment (0,0)
-        //   group (kc,g): read the NEXT fragment first, then 4*NQT MFMAs on the current one;
-        //                at g == 3 the next fragment is (kc+1, 0): slot kc's four fragments are
-        //                all in registers by then, so its buffer is refilled (slot kc+1+P) and
-        //                the counted wait retires slot kc+1.
-        ks_issue_slot(cur[0] + P * KS_CHUNK_K, cur[1] + P * KS_CHUNK_K, cur[2] + P * KS_CHUNK_K,
-                      cur[3] + P * KS_CHUNK_K, ring_w + (P % NBUF) * KS_SLOT_BYTES);
-        ks_wait<4 * P>();
+        //   start       : wait -> slot 0 landed (slots 0..P-1 were issued during the previous tile),
+        //                 read fragment (0,0)
+        //   group (kc,g): read the NEXT fragment, 4*NQT MFMAs on the current one, and -- between
+        //                 them -- DMA piece g of slot kc+P into the buffer slot kc-1 has vacated;
+        //                 at g == 3 the next fragment is (kc+1,0), behind the counted wait that
+        //                 retires slot kc+1 (P-1 younger slots stay in flight).
+        ks_wait<4 * (P - 1)>();
         f32x4 a_cur = *reinterpret_cast<const f32x4 *>(ring_rd + frag_off[0]);
         ks_static_for<0, NKC * 4>([&](auto gi_) {
             constexpr int gi = decltype(gi_)::value;
             constexpr int kc = gi / 4, g = gi % 4;
+            constexpr int sn = kc + P; // slot refilled during this slot's groups
             f32x4 a_nxt = a_cur;
-            if constexpr (g < 3) {
+            if constexpr (g < 3)
                 a_nxt = *reinterpret_cast<const f32x4 *>(ring_rd + (kc % NBUF) * KS_SLOT_BYTES + frag_off[g + 1]);
-            } else if constexpr (kc + 1 < NKC) {
-                constexpr int sn = kc + 1 + P; // refill this slot's buffer
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // fragment (kc,3) is in registers
-                if constexpr (sn < NKC) {
-                    ks_issue_slot(cur[0] + sn * KS_CHUNK_K, cur[1] + sn * KS_CHUNK_K, cur[2] + sn * KS_CHUNK_K,
-                                  cur[3] + sn * KS_CHUNK_K, ring_w + (sn % NBUF) * KS_SLOT_BYTES);
-                    ks_wait<4 * P>();
-                } else if (has_next_tile) {
-                    constexpr int kn = sn - NKC;
-                    ks_issue_slot(nxt[0] + kn * KS_CHUNK_K, nxt[1] + kn * KS_CHUNK_K, nxt[2] + kn * KS_CHUNK_K,
-                                  nxt[3] + kn * KS_CHUNK_K, ring_w + (sn % NBUF) * KS_SLOT_BYTES);
-                    ks_wait<4 * P>();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (!no_mfma) {
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], qreg[t][(kc * 4 + g) * 4 + j], acc[t], 0, 0, 0);
                 } else {
-                    ks_wait<4 * (NKC - 2 - kc)>();
+                    ks_keep(a_cur);
                 }
+                if (j == 0) { // one DMA piece per group, right behind the group's first MFMAs
+                    if constexpr (sn < NKC)
+                        ks_issue_piece(cur, voff[g], sn * KS_CHUNK_K * 4, ring_w + (sn % NBUF) * KS_SLOT_BYTES + g * 1024,
+                                       no_dma);
+                    else
+                        ks_issue_piece(nxt, voff[g], (sn - NKC) * KS_CHUNK_K * 4,
+                                       ring_w + (sn % NBUF) * KS_SLOT_BYTES + g * 1024, no_dma || !has_next_tile);
+                }
+            }
+            if constexpr (g == 3 && kc + 1 < NKC) {
+                if (kc + P < NKC || has_next_tile) ks_wait<4 * (P - 1)>();
+                else ks_wait<4 * (NKC - 2 - kc)>();
                 a_nxt = *reinterpret_cast<const f32x4 *>(ring_rd + ((kc + 1) % NBUF) * KS_SLOT_BYTES + frag_off[0]);
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < NQT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[j], qreg[t][(kc * 4 + g) * 4 + j], acc[t], 0, 0, 0);
             a_cur = a_nxt;
         });
 
-        // ---- epilogue: sum the four K-slices, filter, stage survivors
+        if constexpr (no_epi) {
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) ks_keep(acc[t]);
+            cur = nxt;
+            if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
+            continue;
+        }
+        // ---- epilogue: sum the four K-slices, filter, store survivors
         float *my_red = red + w * RED_FLOATS;
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
@@ -237,9 +286,8 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
             }
         }
         ks_barrier(); // (B) `red` may be rewritten by the next tile
-#pragma unroll
-        for (int m = 0; m < 4; ++m) cur[m] = nxt[m];
-        if (ti + 2 < my_nt) tile_ptrs(ti + 2, nxt);
+        cur = nxt;
+        if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
     }
     // publish this segment's fill counts (LDS atomics of every wave are complete after barrier B)
     if (tid < 32 * NQT && tid < n_queries) {
@@ -248,22 +296,43 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
     }
 }
 
-template <int D, int NQT>
-static int launch_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const float *q,
-                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+template <int D, int NQT, int DBG>
+static int launch_ksplit_dbg(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const float *q,
+                             uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int KS = D / 4, NKC = KS / KS_CHUNK_K, NBUF = NKC <= 6 ? NKC : NKC / 2;
     constexpr size_t smem = 4 * NBUF * KS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
     static bool attr = false;
     if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_ksplit_filter<D, NQT>),
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_ksplit_filter<D, NQT, DBG>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
-    hipLaunchKernelGGL((cosine_ksplit_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
-                       row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
-                       p.carry_cap, p.seg_cap, p.overflow);
+    hipLaunchKernelGGL((cosine_ksplit_filter<D, NQT, DBG>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows,
+                       row_begin, row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys,
+                       p.stride, p.carry_cap, p.seg_cap, p.overflow);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
+}
+
+template <int D, int NQT>
+static int launch_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const float *q,
+                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    if constexpr (D == 768 && NQT == 2) {
+        // ablation builds for tools/ks_ablate.py (timings only; results are wrong by construction)
+        static const int dbg = getenv("OI_KS_DEBUG") ? atoi(getenv("OI_KS_DEBUG")) : 0;
+        switch (dbg) {
+            case 1: return launch_ksplit_dbg<D, NQT, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 2: return launch_ksplit_dbg<D, NQT, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 4: return launch_ksplit_dbg<D, NQT, 4>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 5: return launch_ksplit_dbg<D, NQT, 5>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 6: return launch_ksplit_dbg<D, NQT, 6>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 8: return launch_ksplit_dbg<D, NQT, 8>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 12: return launch_ksplit_dbg<D, NQT, 12>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 14: return launch_ksplit_dbg<D, NQT, 14>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            default: break;
+        }
+    }
+    return launch_ksplit_dbg<D, NQT, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 }
 
 bool oi_cosine_ksplit_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
