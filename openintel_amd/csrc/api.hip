@@ -325,7 +325,7 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
     }
     const uint32_t cos_segs = (uint32_t)ctx->num_cus;
     const uint32_t bm_segs = bm_blocks ? bm_blocks : 1;
-    const size_t words = (size_t)B * (2 + cos_segs + 1 + bm_segs);
+    const size_t words = (size_t)B * (2 + cos_segs + 2 + bm_segs);
     DevBuf &st = ctx->buf("pool_state");
     OI_CHECK(st.ensure(sizeof(uint32_t) * words));
     OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * words, ctx->stream));
@@ -335,10 +335,10 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
     OI_CHECK(pb.ensure(sizeof(uint64_t) * (size_t)B * bm_stride));
     uint32_t *s = st.as<uint32_t>();
     uint32_t *cos_carry = s, *cos_tau = s + B, *cos_seg = s + 2 * (size_t)B;
-    uint32_t *bm_carry = cos_seg + (size_t)B * cos_segs, *bm_seg = bm_carry + B;
+    uint32_t *bm_carry = cos_seg + (size_t)B * cos_segs, *bm_tau = bm_carry + B, *bm_seg = bm_tau + B;
     out->cos = PoolView{pc.as<uint64_t>(), cos_carry, cos_seg, cos_tau, cos_stride, carry_cap, 0, 0, cos_segs,
                         flag.as<uint32_t>()};
-    out->bm = PoolView{pb.as<uint64_t>(), bm_carry, bm_seg, nullptr, bm_stride, carry_cap, depth, bm_segs, bm_segs,
+    out->bm = PoolView{pb.as<uint64_t>(), bm_carry, bm_seg, bm_tau, bm_stride, carry_cap, depth, bm_segs, bm_segs,
                        flag.as<uint32_t>()};
     return OI_OK;
 }
@@ -356,8 +356,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // to handle, no data-dependent sizing).  BM25: every doc block contributes <= depth entries.
     const uint32_t carry_cap = OI_MAX_DEPTH;
     const uint64_t slack = 32ull * ((uint64_t)ctx->num_cus + 1);
-    uint64_t cos_stride = 1ull << 20;
-    const uint64_t budget = (1ull << 30) / 8 / B; // <= 1 GiB of cosine pools
+    // Large pools = few launches: at 10M rows the schedule is 32K, 256K, 2M, rest (4 launches).
+    // The room is address space, not traffic: only entries that pass the threshold are written.
+    uint64_t cos_stride = 1ull << 24;
+    const uint64_t budget = (8ull << 30) / 8 / B; // <= 8 GiB of cosine pools (288 GB HBM)
     if (cos_stride > budget) cos_stride = budget;
     if (cos_stride < carry_cap + 4 * slack) cos_stride = carry_cap + 4 * slack;
     if (cos_stride > carry_cap + n + slack) cos_stride = carry_cap + n + slack;
@@ -394,7 +396,16 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // ---- BM25 list
     if (bm_s) {
         OI_REQUIRE(idx->finalized, "search: index not finalized");
-        OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm));
+        // Two phases, like the cosine chunks: the first eighth of the doc blocks fixes a per-query
+        // threshold (the depth-th score seen so far is a lower bound of the final one); the remaining
+        // blocks then emit only candidates at or above it, so the final selection scans little.
+        const uint32_t nb = idx->n_blocks;
+        const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / 8) : nb;
+        OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, 0, first));
+        if (first < nb) {
+            OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth));
+            OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, first, nb));
+        }
         OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, false, bm_s, bm_d, bm_c, depth));
     }
     return OI_OK;

@@ -240,66 +240,135 @@ __device__ void bm_find_kth_from_top(const uint32_t *hist, uint32_t nbins, uint3
     }
 }
 
+#define BM_TB 4 // query terms handled per batch (their cell bounds and postings are fetched together)
+
 __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
     const Posting *__restrict__ postings, const uint32_t *__restrict__ cell_start,
-    const float *__restrict__ idf, uint32_t vocab, uint32_t doc_id_base, const uint32_t *__restrict__ q_terms,
-    const uint32_t *__restrict__ q_offsets, uint32_t n_queries, uint32_t depth, uint64_t *pools,
-    uint32_t *seg_cnt, uint32_t seg_cnt_stride, uint64_t pool_stride, uint32_t carry_cap) {
+    const float *__restrict__ idf, uint32_t vocab, uint32_t doc_id_base, uint32_t block0,
+    const uint32_t *__restrict__ q_terms, const uint32_t *__restrict__ q_offsets, uint32_t n_queries,
+    uint32_t depth, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride, const uint32_t *tau_keys,
+    uint64_t pool_stride, uint32_t carry_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *acc = reinterpret_cast<float *>(smem);                       // BM_R
     uint32_t *hist = reinterpret_cast<uint32_t *>(acc + BM_R);          // 2048
     uint64_t *list = reinterpret_cast<uint64_t *>(hist + 2048);         // OI_MAX_DEPTH
     uint32_t *scan = reinterpret_cast<uint32_t *>(list + OI_MAX_DEPTH); // 16 wave totals + scratch
-    uint32_t *sh = scan + 32;                                           // [0] touched [1] list_cnt [2] base [3] bin [4] above
+    uint32_t *sh = scan + 32;  // [0] touched [1] list_cnt [3] bin [4] above; [8..8+3*BM_TB) term info
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t blk = blockIdx.x;
+    const uint32_t blk = block0 + blockIdx.x;
     const uint64_t cell0 = (uint64_t)blk * vocab;
     const uint32_t doc0 = doc_id_base + blk * BM_R;
+    uint32_t *t_s = sh + 8, *t_e = sh + 8 + BM_TB;
+    float *t_w = reinterpret_cast<float *>(sh + 8 + 2 * BM_TB);
 
     for (uint32_t i = tid; i < BM_R / 4; i += BM_THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (uint32_t q = blockIdx.y; q < n_queries; q += gridDim.y) {
         if (tid < 8) sh[tid] = 0;
-        __syncthreads();
         const uint32_t t_begin = q_offsets[q], t_end = q_offsets[q + 1];
-        // ---- accumulate, one term at a time (fixed order; a doc occurs once per run)
-        for (uint32_t ti = t_begin; ti < t_end; ++ti) {
-            const uint32_t t = q_terms[ti];
-            if (t >= vocab) continue;
-            const uint32_t s = cell_start[cell0 + t], e = cell_start[cell0 + t + 1];
-            if (s == e) continue;
-            const float w = idf[t];
-            uint32_t fresh = 0;
-            for (uint32_t i = s + tid; i < e; i += BM_THREADS) {
-                const Posting p = postings[i];
-                const float old = acc[p.dib];
-                acc[p.dib] = __fadd_rn(old, __fmul_rn(w, p.impact));
-                fresh += old == 0.0f;
+        const uint32_t tau = tau_keys ? tau_keys[q] : 0u;
+        Posting pr[BM_TB]; // the first 1024 postings of each run of the LAST batch stay in registers
+        // ---- accumulate: term batches; within a batch all bounds, then all postings, are in flight
+        // together (one memory latency each), accumulation itself is term by term (fixed order; a
+        // doc occurs at most once per run, so no two lanes touch the same accumulator)
+        for (uint32_t tb = t_begin; tb < t_end; tb += BM_TB) {
+            __syncthreads(); // previous batch done with the term info; sh reset visible
+            if (tid < BM_TB) {
+                uint32_t s0 = 0, e0 = 0;
+                float w0 = 0.f;
+                if (tb + tid < t_end) {
+                    const uint32_t t = q_terms[tb + tid];
+                    if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; w0 = idf[t]; }
+                }
+                t_s[tid] = s0; t_e[tid] = e0; t_w[tid] = w0;
             }
-            if (fresh) atomicAdd(&sh[0], fresh);
             __syncthreads();
+#pragma unroll
+            for (int j = 0; j < BM_TB; ++j) {
+                pr[j].dib = 0xFFFFFFFFu;
+                if (t_s[j] + tid < t_e[j]) pr[j] = postings[t_s[j] + tid];
+            }
+#pragma unroll
+            for (int j = 0; j < BM_TB; ++j) {
+                const uint32_t s = t_s[j], e = t_e[j];
+                if (s == e) continue; // uniform
+                const float w = t_w[j];
+                uint32_t fresh = 0;
+                if (pr[j].dib != 0xFFFFFFFFu) {
+                    const float old = acc[pr[j].dib];
+                    acc[pr[j].dib] = __fadd_rn(old, __fmul_rn(w, pr[j].impact));
+                    fresh += old == 0.0f;
+                }
+                for (uint32_t i = s + BM_THREADS + tid; i < e; i += BM_THREADS) {
+                    const Posting p = postings[i];
+                    const float old = acc[p.dib];
+                    acc[p.dib] = __fadd_rn(old, __fmul_rn(w, p.impact));
+                    fresh += old == 0.0f;
+                }
+                if (fresh) atomicAdd(&sh[0], fresh);
+                __syncthreads();
+            }
         }
+        __syncthreads();
         const uint32_t touched = sh[0];
         if (touched == 0) { __syncthreads(); continue; }
 
-        if (touched <= depth) {
-            // ---- sparse emit: walk the same runs again; the first run to reach a doc takes it
-            for (uint32_t ti = t_begin; ti < t_end; ++ti) {
-                const uint32_t t = q_terms[ti];
-                if (t >= vocab) continue;
-                const uint32_t s = cell_start[cell0 + t], e = cell_start[cell0 + t + 1];
-                if (s == e) continue;
-                for (uint32_t i = s + tid; i < e; i += BM_THREADS) {
-                    const uint32_t dib = postings[i].dib;
-                    const float v = acc[dib];
-                    if (v != 0.0f) {
-                        acc[dib] = 0.0f;
-                        list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + dib);
+        // Walk every run of the query again, run by run (a doc occurs once per run, so within a run
+        // no two lanes touch the same accumulator; the barrier orders the runs).
+        const bool single_batch = t_end - t_begin <= BM_TB; // then `pr` still holds every run's head
+        auto walk = [&](auto &&visit) {
+            for (uint32_t tb = t_begin; tb < t_end; tb += BM_TB) {
+                if (!single_batch) {
+                    __syncthreads();
+                    if (tid < BM_TB) {
+                        uint32_t s0 = 0, e0 = 0;
+                        if (tb + tid < t_end) {
+                            const uint32_t t = q_terms[tb + tid];
+                            if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; }
+                        }
+                        t_s[tid] = s0; t_e[tid] = e0;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < BM_TB; ++j) {
+                        pr[j].dib = 0xFFFFFFFFu;
+                        if (t_s[j] + tid < t_e[j]) pr[j] = postings[t_s[j] + tid];
                     }
                 }
-                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < BM_TB; ++j) {
+                    const uint32_t s = t_s[j], e = t_e[j];
+                    if (s == e) continue;
+                    if (pr[j].dib != 0xFFFFFFFFu) visit(pr[j].dib);
+                    for (uint32_t i = s + BM_THREADS + tid; i < e; i += BM_THREADS) visit(postings[i].dib);
+                    __syncthreads();
+                }
             }
+        };
+        // emit + clear: the first run to reach a doc takes it (|acc|: a marking walk may have negated it)
+        auto emit_visit = [&](uint32_t dib) {
+            const float v = fabsf(acc[dib]);
+            if (v != 0.0f) {
+                acc[dib] = 0.0f;
+                if (oi_f32_key(v) >= tau) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + dib);
+            }
+        };
+        bool dense = touched > depth;
+        if (dense && tau != 0u) {
+            // Many docs touched, but a threshold is known: count the docs at or above it (marking each
+            // visited accumulator by its sign so that a doc is counted once); they almost always fit.
+            walk([&](uint32_t dib) {
+                const float v = acc[dib];
+                if (v > 0.0f) {
+                    acc[dib] = -v;
+                    if (oi_f32_key(v) >= tau) atomicAdd(&sh[5], 1u);
+                }
+            });
+            dense = sh[5] > depth;
+        }
+        if (!dense) {
+            walk(emit_visit);
         } else {
             // ---- dense: exact local top-`depth` by radix select over the LDS accumulators.
             // Scores are > 0, so their bit patterns order like the floats.
@@ -311,7 +380,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                 __syncthreads();
 #pragma unroll 4
                 for (uint32_t i = tid; i < BM_R; i += BM_THREADS) {
-                    const uint32_t bits = __float_as_uint(acc[i]);
+                    const uint32_t bits = __float_as_uint(acc[i]) & 0x7FFFFFFFu;
                     if (bits == 0) continue;
                     if (pass == 0) atomicAdd(&hist[bits >> 21], 1u);
                     else if (pass == 1) { if ((bits >> 21) == prefix) atomicAdd(&hist[(bits >> 10) & 2047u], 1u); }
@@ -330,7 +399,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
             const uint32_t base = tid * (BM_R / BM_THREADS);
             uint32_t eq = 0;
 #pragma unroll 4
-            for (uint32_t i = 0; i < BM_R / BM_THREADS; ++i) eq += __float_as_uint(acc[base + i]) == T;
+            for (uint32_t i = 0; i < BM_R / BM_THREADS; ++i) eq += (__float_as_uint(acc[base + i]) & 0x7FFFFFFFu) == T;
             uint32_t incl = eq;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -343,11 +412,11 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
             for (uint32_t w2 = 0; w2 < wv; ++w2) before += scan[w2];
 #pragma unroll 2
             for (uint32_t i = 0; i < BM_R / BM_THREADS; ++i) {
-                const float v = acc[base + i];
+                const float v = fabsf(acc[base + i]);
                 const uint32_t bits = __float_as_uint(v);
                 bool take = bits > T;
                 if (bits == T) { take = before < n_ties; ++before; }
-                if (take) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + base + i);
+                if (take && oi_f32_key(v) >= tau) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + base + i);
                 acc[base + i] = 0.0f;
             }
             __syncthreads();
@@ -361,12 +430,14 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
     }
 }
 
-#define BM_SMEM (BM_R * 4 + 2048 * 4 + OI_MAX_DEPTH * 8 + 32 * 4 + 8 * 4)
+#define BM_SMEM (BM_R * 4 + 2048 * 4 + OI_MAX_DEPTH * 8 + 32 * 4 + (8 + 3 * BM_TB) * 4)
 
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
-                   uint32_t n_queries, uint32_t depth, const PoolView &pool) {
+                   uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,
+                   uint32_t block_end) {
     oi_ctx *ctx = idx->ctx;
-    if (n_queries == 0 || idx->n_postings == 0 || idx->n_blocks == 0) return OI_OK;
+    if (n_queries == 0 || idx->n_postings == 0 || idx->n_blocks == 0 || block_end <= block_begin) return OI_OK;
+    const uint32_t nb = block_end - block_begin;
     OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH, "bm25: depth=%u outside [1,%u]", depth, OI_MAX_DEPTH);
     OI_REQUIRE(pool.seg_cap == depth && pool.n_segs == idx->n_blocks && pool.n_segs <= pool.seg_cnt_stride &&
                    pool.carry_cap + (uint64_t)pool.n_segs * depth <= pool.stride,
@@ -379,14 +450,14 @@ int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q
     }
     // one workgroup per CU is resident (128 KiB of LDS); split the batch so the grid has
     // about 4 workgroups per CU when the corpus has few blocks
-    uint32_t ysplit = (uint32_t)((4ull * ctx->num_cus + idx->n_blocks - 1) / idx->n_blocks);
+    uint32_t ysplit = (uint32_t)((4ull * ctx->num_cus + nb - 1) / nb);
     if (ysplit < 1) ysplit = 1;
     if (ysplit > n_queries) ysplit = n_queries;
     ProfScope ps(ctx, "bm25");
-    hipLaunchKernelGGL(bm25_block_kernel, dim3(idx->n_blocks, ysplit), dim3(BM_THREADS), BM_SMEM, ctx->stream,
+    hipLaunchKernelGGL(bm25_block_kernel, dim3(nb, ysplit), dim3(BM_THREADS), BM_SMEM, ctx->stream,
                        idx->postings.as<Posting>(), idx->cell_start.as<uint32_t>(), idx->idf.as<float>(),
-                       idx->vocab, idx->doc_id_base, d_q_terms, d_q_offsets, n_queries, depth, pool.keys,
-                       pool.seg_cnt, pool.seg_cnt_stride, pool.stride, pool.carry_cap);
+                       idx->vocab, idx->doc_id_base, block_begin, d_q_terms, d_q_offsets, n_queries, depth,
+                       pool.keys, pool.seg_cnt, pool.seg_cnt_stride, pool.tau_keys, pool.stride, pool.carry_cap);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

@@ -207,8 +207,30 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
         for (int m = 0; m < 4; ++m)
             ks_issue_piece(cur, voff[m], kc * KS_CHUNK_K * 4, ring_w + (kc % NBUF) * KS_SLOT_BYTES + m * 1024, no_dma);
 
+    // ---- deferred epilogue.  A tile's partial sums are written to LDS right after its last MFMA;
+    // the cross-wave sum + filter of tile t then rides INSIDE tile t+1's MFMA stream (barrier A at
+    // group 2, one output per group after it, barrier B behind the last one), so its LDS round
+    // trips and VALU work issue in the shadow of the 64-cycle matrix instructions.
+    float *my_red = red + w * RED_FLOATS;
+    uint64_t prev_row0 = 0; // first corpus row of the tile whose partials sit in `red`
+    auto epi_out = [&](int i) {
+        const uint32_t e = tid + 256u * i; // (t = i>>2, r = (e>>6)&15, lane)
+        const float s = (red[e] + red[RED_FLOATS + e]) + (red[2 * RED_FLOATS + e] + red[3 * RED_FLOATS + e]);
+        const uint32_t t = i >> 2, r = (e >> 6) & 15u;
+        const uint32_t q = 32u * t + li;
+        const uint64_t row = prev_row0 + (r & 3u) + 8u * (r >> 2) + 4u * lh;
+        if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+            const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+            if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+            else *overflow = 1u;
+        }
+    };
+    constexpr int EPI_G0 = 3, EPI_GB = EPI_G0 + NQT * 4; // groups of the outputs / of barrier B
+    static_assert(EPI_GB <= NKC * 4 - 1, "tile too short to host the deferred epilogue");
+
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
         const bool has_next_tile = ti + 1 < my_nt;
+        const bool have_prev = ti > 0;
         f32x16 acc[NQT];
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
@@ -249,6 +271,11 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
                                        ring_w + (sn % NBUF) * KS_SLOT_BYTES + g * 1024, no_dma || !has_next_tile);
                 }
             }
+            if constexpr (!no_epi) {
+                if constexpr (gi == EPI_G0 - 1) { if (have_prev) ks_barrier(); }                 // (A) partials visible
+                if constexpr (gi >= EPI_G0 && gi < EPI_GB) { if (have_prev) epi_out(gi - EPI_G0); }
+                if constexpr (gi == EPI_GB) { if (have_prev) ks_barrier(); }                     // (B) `red` is free again
+            }
             if constexpr (g == 3 && kc + 1 < NKC) {
                 if (kc + P < NKC || has_next_tile) ks_wait<4 * (P - 1)>();
                 else ks_wait<4 * (NKC - 2 - kc)>();
@@ -260,34 +287,22 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
         if constexpr (no_epi) {
 #pragma unroll
             for (int t = 0; t < NQT; ++t) ks_keep(acc[t]);
-            cur = nxt;
-            if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
-            continue;
+        } else {
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my_red[(t * 16 + r) * 64 + lane] = acc[t][r];
+            uint64_t tile_id = blockIdx.x + ti * gridDim.x;
+            prev_row0 = row_begin + tile_id * (uint64_t)KS_TILE_ROWS;
         }
-        // ---- epilogue: sum the four K-slices, filter, store survivors
-        float *my_red = red + w * RED_FLOATS;
-#pragma unroll
-        for (int t = 0; t < NQT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) my_red[(t * 16 + r) * 64 + lane] = acc[t][r];
-        ks_barrier(); // (A) partials visible
-        const uint64_t tile_row0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
-#pragma unroll
-        for (int i = 0; i < NQT * 4; ++i) {
-            const uint32_t e = tid + 256u * i; // (t = i>>2, r = (e>>6)&15, lane)
-            const float s = (red[e] + red[RED_FLOATS + e]) + (red[2 * RED_FLOATS + e] + red[3 * RED_FLOATS + e]);
-            const uint32_t t = i >> 2, r = (e >> 6) & 15u;
-            const uint32_t q = 32u * t + li;
-            const uint64_t row = tile_row0 + (r & 3u) + 8u * (r >> 2) + 4u * lh;
-            if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
-                const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
-                if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
-                else *overflow = 1u;
-            }
-        }
-        ks_barrier(); // (B) `red` may be rewritten by the next tile
         cur = nxt;
         if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
+    }
+    if constexpr (!no_epi) { // the last tile's epilogue has no MFMA stream to hide in
+        ks_barrier();
+#pragma unroll
+        for (int i = 0; i < NQT * 4; ++i) epi_out(i);
+        ks_barrier();
     }
     // publish this segment's fill counts (LDS atomics of every wave are complete after barrier B)
     if (tid < 32 * NQT && tid < n_queries) {

@@ -163,5 +163,7 @@ int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, 
 // bm25.hip
 int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets);
 int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, const uint32_t *global_df_host);
+// Doc blocks [block_begin, block_end); candidates below pool.tau_keys (if set) are dropped.
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
-                   uint32_t n_queries, uint32_t depth, const PoolView &pool);
+                   uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,
+                   uint32_t block_end);

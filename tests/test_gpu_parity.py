@@ -230,6 +230,8 @@ def _exact_case(rng, n, dim, vocab, B, n_q_terms=4, max_len=12):
     (40_000, 64, 300, 64, 10, 10),      # batch 64
     (1_000, 384, 64, 1, 10, 10),        # BASELINE configs[0] shape
     (33_000, 16, 8, 2, 1024, 1024),     # maximum depth / k
+    (600_000, 8, 30, 3, 100, 50),       # 19 doc blocks: two-phase BM25 with a threshold, heavy terms
+    (600_000, 8, 3000, 3, 1000, 100),   # same, sparse terms; several cosine chunks
 ])
 def test_hybrid_pipeline_bit_exact(ctx, O, n, dim, vocab, B, depth, k):
     rng = np.random.default_rng(n + B)
