@@ -64,8 +64,8 @@ def main():
     ap.add_argument("--depth", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=131072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-docs", type=int, default=200_000)
-    ap.add_argument("--cpu-sample-queries", type=int, default=16)
+    ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=64)
     args = ap.parse_args()
 
     import numpy as np
@@ -79,11 +79,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    # Rehearsal switches for a 1-GPU box (not for reported numbers): OI_BENCH_BACKEND=gloo lets two
+    # ranks share cuda:0 (RCCL refuses duplicate devices) so the sharded path runs end to end.
+    backend = os.environ.get("OI_BENCH_BACKEND", "nccl")
+    if os.environ.get("OI_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import openintel_amd as oi
     from openintel_amd import sharded, synth

@@ -67,8 +67,9 @@ class ShardedRetriever:
             dc = torch.stack([L.cos_docs, L.bm25_docs]).contiguous()
             cn = torch.stack([L.cos_counts, L.bm25_counts]).contiguous()
             packed = torch.cat([sc.view(torch.int32).reshape(-1), dc.reshape(-1), cn.reshape(-1)])
-            gathered = torch.empty((self.world, packed.numel()), dtype=packed.dtype, device=packed.device)
-            self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+            flat = torch.empty(self.world * packed.numel(), dtype=packed.dtype, device=packed.device)
+            self.dist.all_gather_into_tensor(flat, packed, group=self.group)
+            gathered = flat.view(self.world, packed.numel())
             n_list = 2 * B * depth
             g_sc = gathered[:, :n_list].contiguous().view(torch.float32).reshape(self.world, 2, B, depth)
             g_dc = gathered[:, n_list:2 * n_list].reshape(self.world, 2, B, depth)

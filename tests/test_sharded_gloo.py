@@ -1,0 +1,132 @@
+"""Multi-rank path on CPU: world_size 2 over gloo.  The collective choreography of
+openintel_amd.sharded.ShardedRetriever (global df/N/token all-reduce at build, ONE packed all-gather
+of the per-shard lists per batch, merge to global ranks, THEN fuse) is exercised with the CPU oracle
+standing in for the per-GPU engine and for the merge / RRF kernels; the result of every rank must be
+bit-identical to the unsharded oracle answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import lib as O
+from openintel_amd.sharded import ShardedRetriever, shard_bounds
+from openintel_amd.retriever import RankedLists
+
+N, DIM, VOCAB, B, DEPTH, K = 3000, 16, 50, 5, 40, 10
+
+
+def _corpus():
+    rng = np.random.default_rng(123)
+    rows = rng.integers(-3, 4, size=(N, DIM)).astype(np.float32)   # exact dot products
+    lens = rng.integers(1, 10, size=N)
+    offs = np.zeros(N + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(0, VOCAB, size=int(offs[-1])).astype(np.uint32)
+    q = rng.integers(-3, 4, size=(B, DIM)).astype(np.float32)
+    qt = rng.integers(0, 12, size=B * 3).astype(np.uint32)
+    qo = (np.arange(B + 1) * 3).astype(np.uint32)
+    return rows, terms, offs, q, qt, qo
+
+
+class OracleShard:
+    """Stands in for HybridIndex on one rank: same interface, CPU oracle inside."""
+
+    def __init__(self, rows, terms, offs, base):
+        self.rows, self.terms, self.offs, self.base = rows, terms, offs, base
+        self.n_docs, self.vocab = rows.shape[0], VOCAB
+
+    def local_stats(self):
+        df, tot = O.bm25_df(self.terms, self.offs, VOCAB)
+        return tot, df
+
+    def finalize(self, n_global, tok_global, df_global):
+        self.n_global, self.tok_global, self.df_global = n_global, tok_global, df_global
+
+    def search_lists(self, qv, qt, qo, depth):
+        qv, qt, qo = qv.numpy(), qt.numpy().astype(np.uint32), qo.numpy().astype(np.uint32)
+        nb = qv.shape[0]
+        out = [np.zeros((nb, depth), np.float32), np.zeros((nb, depth), np.int32), np.zeros(nb, np.int32),
+               np.zeros((nb, depth), np.float32), np.zeros((nb, depth), np.int32), np.zeros(nb, np.int32)]
+        for b in range(nb):
+            cs, cd = O.topk(O.dot_scores(self.rows, qv[b]), depth, False, self.base)
+            bs, bd = O.topk(O.bm25_scores(self.terms, self.offs, VOCAB, qt[qo[b]:qo[b + 1]], df=self.df_global,
+                                          n_docs_global=self.n_global, total_tokens_global=self.tok_global),
+                            depth, True, self.base)
+            out[0][b, :cs.size], out[1][b, :cd.size], out[2][b] = cs, cd, cs.size
+            out[3][b, :bs.size], out[4][b, :bd.size], out[5][b] = bs, bd, bs.size
+        return RankedLists(*[torch.from_numpy(x) for x in out])
+
+
+def _merge(scores, docs, counts):
+    S, nb, depth = scores.shape
+    so, do, co = np.zeros((nb, depth), np.float32), np.zeros((nb, depth), np.int32), np.zeros(nb, np.int32)
+    for b in range(nb):
+        ms, md = O.merge_ranked([scores[s, b, :counts[s, b]].numpy() for s in range(S)],
+                                [docs[s, b, :counts[s, b]].numpy().astype(np.uint32) for s in range(S)], depth)
+        so[b, :ms.size], do[b, :md.size], co[b] = ms, md, md.size
+    return torch.from_numpy(so), torch.from_numpy(do), torch.from_numpy(co)
+
+
+def _fuse(cd, cc, bd, bc, k):
+    nb = cd.shape[0]
+    fs, fd, fc = np.zeros((nb, k), np.float32), np.zeros((nb, k), np.int32), np.zeros(nb, np.int32)
+    for b in range(nb):
+        s, d = O.rrf_fuse(cd[b, :cc[b]].numpy().astype(np.uint32), bd[b, :bc[b]].numpy().astype(np.uint32), k)
+        fs[b, :s.size], fd[b, :d.size], fc[b] = s, d, d.size
+    return torch.from_numpy(fs), torch.from_numpy(fd), torch.from_numpy(fc)
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows, terms, offs, q, qt, qo = _corpus()
+        lo, hi = shard_bounds(N, world, rank)
+        t_lo, t_hi = int(offs[lo]), int(offs[hi])
+        shard = OracleShard(rows[lo:hi], terms[t_lo:t_hi], (offs[lo:hi + 1] - offs[lo]).astype(np.uint64), lo)
+        sr = ShardedRetriever(shard, torch.device("cpu"), _merge, _fuse)
+        sr.finalize()
+        assert shard.n_global == N and shard.tok_global == int(offs[-1])
+        s, d, c = sr.search(torch.from_numpy(q), torch.from_numpy(qt.astype(np.int32)),
+                            torch.from_numpy(qo.astype(np.int32)), K, DEPTH)
+        ret[rank] = (s.numpy().copy(), d.numpy().copy(), c.numpy().copy(), shard.df_global.copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_bounds_cover_and_align():
+    for n, w in ((10_000_000, 8), (1001, 3), (7, 8), (12_500_000, 8)):
+        edges = [shard_bounds(n, w, r) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+        assert all(lo % 4 == 0 for lo, hi in edges if hi > lo)
+
+
+@pytest.mark.timeout(180)
+def test_two_ranks_match_unsharded_oracle():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    rows, terms, offs, q, qt, qo = _corpus()
+    df, _ = O.bm25_df(terms, offs, VOCAB)
+    for rank in range(world):
+        s, d, c, gdf = ret[rank]
+        assert np.array_equal(gdf, df)                       # the df all-reduce
+        for b in range(B):
+            ref = O.hybrid_search(rows, terms, offs, VOCAB, q[b], qt[qo[b]:qo[b + 1]], K, DEPTH)
+            fs, fd = ref["fused"]
+            assert c[b] == fd.size
+            assert np.array_equal(d[b, :fd.size].astype(np.uint32), fd)
+            assert np.array_equal(s[b, :fs.size].view(np.uint32), fs.view(np.uint32))
+    assert np.array_equal(ret[0][1], ret[1][1])              # every rank holds the same answer
