@@ -156,6 +156,24 @@ int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *docs, const
                    uint32_t n_shards, uint32_t n_queries, uint32_t depth, int location,
                    float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 
+/*
+ * The multi-GPU exchange format.  A shard's two lists for a batch, packed in ONE buffer of
+ * OI_PACKED_WORDS(n_queries, depth) 32-bit words:
+ *     float    scores[2][n_queries][depth]     list 0 = cosine, list 1 = BM25
+ *     uint32_t docs  [2][n_queries][depth]
+ *     uint32_t counts[2][n_queries]
+ * oi_search_lists_packed fills it (same contents as oi_search_lists); every rank all-gathers the
+ * buffers (RCCL) into [n_shards][OI_PACKED_WORDS] and calls oi_fuse_packed, which merges each list to
+ * its global top-`depth` and THEN fuses (global ranks are needed: fusing per shard is not equivalent).
+ */
+#define OI_PACKED_WORDS(n_queries, depth) (4ull * (n_queries) * (depth) + 2ull * (n_queries))
+int oi_search_lists_packed(oi_index *idx, const float *query_vecs, const uint32_t *query_terms,
+                           const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth,
+                           int location, uint32_t *packed_out);
+int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t n_shards, uint32_t n_queries,
+                   uint32_t depth, uint32_t k, int location, float *scores_out, uint32_t *docs_out,
+                   uint32_t *counts_out);
+
 /* Reciprocal-rank fusion of two ranked lists per query (row stride `depth`):
  * rrf(d) = sum over lists containing d of 1/(60 + rank), rank from 1; output top-k
  * by (rrf desc, doc id asc), row stride k. */

@@ -12,11 +12,13 @@ from .context import HipContext
 from .domain import (Alignment, AnalyzerMismatch, Confidence, DomainError, EngineConfig, MarketSnapshot,
                      PostSignal, PostText, SocialPost, SourceFailure, SourceKind, Ticker)
 from .engine import SpeculationEngine
-from .retriever import HybridIndex, PostRetriever, SearchResult, merge_lists, pack_query_terms, rrf_fuse
+from .retriever import (HybridIndex, PostRetriever, SearchResult, fuse_packed, merge_lists, pack_query_terms,
+                        packed_words, rrf_fuse, unpack_lists)
 
 __all__ = [
     "HipContext", "HipLexiconAnalyzer", "PostAnalyzer", "pack_posts", "SpeculationEngine", "HybridIndex",
-    "PostRetriever", "SearchResult", "merge_lists", "rrf_fuse", "pack_query_terms", "Alignment",
+    "PostRetriever", "SearchResult", "merge_lists", "rrf_fuse", "pack_query_terms", "fuse_packed", "packed_words",
+    "unpack_lists", "Alignment",
     "AnalyzerMismatch", "Confidence", "DomainError", "EngineConfig", "MarketSnapshot", "PostSignal", "PostText",
     "SocialPost", "SourceFailure", "SourceKind", "Ticker",
 ]

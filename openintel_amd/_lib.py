@@ -65,6 +65,8 @@ SIGNATURES = {
     "oi_index_local_stats": (_I, [_P, C.POINTER(_U64), _P]),
     "oi_index_finalize": (_I, [_P, _U64, _U64, _P]),
     "oi_search_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P, _P, _P, _P, _P, _P]),
+    "oi_search_lists_packed": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P]),
+    "oi_fuse_packed": (_I, [_P, _P, _U32, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_merge_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_rrf_fuse": (_I, [_P, _P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_search": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),

@@ -532,7 +532,7 @@ extern "C" int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *
                   depth, n_shards, n_shards, flag.as<uint32_t>()};
     const size_t Lin = (size_t)n_shards * B * depth, Cin = (size_t)n_shards * B, L = (size_t)B * depth;
     if (location == OI_DEVICE) {
-        OI_CHECK(oi_launch_lists_to_pool(ctx, scores, docs, counts, n_shards, B, depth, pool));
+        OI_CHECK(oi_launch_lists_to_pool(ctx, scores, docs, counts, (uint64_t)B * depth, B, n_shards, B, depth, pool));
         return oi_launch_select(ctx, pool, B, depth, false, scores_out, docs_out, counts_out, depth);
     }
     DevBuf &w = ctx->buf("merge_io");
@@ -545,7 +545,7 @@ extern "C" int oi_merge_lists(oi_ctx *ctx, const float *scores, const uint32_t *
     OI_HIP_CHECK(hipMemcpyAsync(d_d, docs, Lin * 4, hipMemcpyHostToDevice, st));
     OI_HIP_CHECK(hipMemcpyAsync(d_c, counts, Cin * 4, hipMemcpyHostToDevice, st));
     OI_HIP_CHECK(hipMemsetAsync(d_so, 0, (2 * L + B) * 4, st));
-    OI_CHECK(oi_launch_lists_to_pool(ctx, d_s, d_d, d_c, n_shards, B, depth, pool));
+    OI_CHECK(oi_launch_lists_to_pool(ctx, d_s, d_d, d_c, (uint64_t)B * depth, B, n_shards, B, depth, pool));
     OI_CHECK(oi_launch_select(ctx, pool, B, depth, false, d_so, d_do, d_co, depth));
     OI_HIP_CHECK(hipMemcpyAsync(scores_out, d_so, L * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipMemcpyAsync(docs_out, d_do, L * 4, hipMemcpyDeviceToHost, st));
@@ -589,4 +589,90 @@ extern "C" int oi_search(oi_index *idx, const float *qv, const uint32_t *qt, con
     OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));
     return check_overflow_locked(ctx);
+}
+
+// ---------------------------------------------------------------- packed multi-GPU exchange
+extern "C" int oi_search_lists_packed(oi_index *idx, const float *qv, const uint32_t *qt, const uint32_t *qo,
+                                      uint32_t B, uint32_t depth, int location, uint32_t *packed_out) {
+    OI_CHECK(check_search_args(idx, qv, qt, qo, B, depth));
+    OI_REQUIRE(packed_out, "search_lists_packed: null output buffer");
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    QueryStage q;
+    OI_CHECK(stage_queries(idx, qv, qt, qo, B, location, &q));
+    const size_t L = (size_t)B * depth, W = (size_t)OI_PACKED_WORDS(B, depth);
+    uint32_t *d_out = packed_out;
+    if (location != OI_DEVICE) {
+        DevBuf &o = ctx->buf("packed_out");
+        OI_CHECK(o.ensure(W * 4));
+        d_out = o.as<uint32_t>();
+    }
+    OI_HIP_CHECK(hipMemsetAsync(d_out + 4 * L, 0, (size_t)B * 8, st)); // counts
+    float *sc = reinterpret_cast<float *>(d_out);
+    uint32_t *dc = d_out + 2 * L, *cn = d_out + 4 * L;
+    OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, sc, dc, cn, sc + L, dc + L, cn + B));
+    if (location == OI_DEVICE) return OI_OK;
+    OI_HIP_CHECK(hipMemcpyAsync(packed_out, d_out, W * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return check_overflow_locked(ctx);
+}
+
+extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t n_shards, uint32_t B, uint32_t depth,
+                              uint32_t k, int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(packed_all && scores_out && docs_out && counts_out, "fuse_packed: null buffer");
+    OI_REQUIRE(n_shards >= 1 && n_shards <= 1024, "fuse_packed: n_shards=%u outside [1,1024]", n_shards);
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH && k >= 1 && k <= OI_MAX_DEPTH, "fuse_packed: depth/k out of range");
+    if (B == 0) return OI_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t L = (size_t)B * depth, W = (size_t)OI_PACKED_WORDS(B, depth), K = (size_t)B * k;
+    const uint32_t *d_in = packed_all;
+    if (location != OI_DEVICE) {
+        DevBuf &in = ctx->buf("packed_in");
+        OI_CHECK(in.ensure(W * 4 * n_shards));
+        OI_HIP_CHECK(hipMemcpyAsync(in.p, packed_all, W * 4 * n_shards, hipMemcpyHostToDevice, st));
+        d_in = in.as<uint32_t>();
+    }
+    DevBuf &flag = ctx->buf("state_flag");
+    if (!flag.p) {
+        OI_CHECK(flag.ensure(16));
+        OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, st));
+    }
+    const uint32_t carry_cap = OI_MAX_DEPTH;
+    const uint64_t mstride = (uint64_t)carry_cap + (uint64_t)n_shards * depth;
+    DevBuf &pk = ctx->buf("merge_pool"), &pc = ctx->buf("merge_counts"), &ml = ctx->buf("merged_lists");
+    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * mstride));
+    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)B * (1 + n_shards)));
+    OI_CHECK(ml.ensure((4 * L + 2 * (size_t)B) * 4 + (2 * K + B) * 4));
+    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), pc.as<uint32_t>() + B, nullptr, mstride, carry_cap,
+                  depth, n_shards, n_shards, flag.as<uint32_t>()};
+    float *m_s = ml.as<float>();                       // [2][B][depth]
+    uint32_t *m_d = ml.as<uint32_t>() + 2 * L;          // [2][B][depth]
+    uint32_t *m_c = m_d + 2 * L;                        // [2][B]
+    for (int l = 0; l < 2; ++l) { // list 0 = cosine, 1 = BM25
+        const float *sc = reinterpret_cast<const float *>(d_in) + (size_t)l * L;
+        const uint32_t *dc = d_in + 2 * L + (size_t)l * L, *cn = d_in + 4 * L + (size_t)l * B;
+        OI_CHECK(oi_launch_lists_to_pool(ctx, sc, dc, cn, W, W, n_shards, B, depth, pool));
+        OI_CHECK(oi_launch_select(ctx, pool, B, depth, false, m_s + (size_t)l * L, m_d + (size_t)l * L,
+                                  m_c + (size_t)l * B, depth));
+    }
+    float *o_s = scores_out;
+    uint32_t *o_d = docs_out, *o_c = counts_out;
+    if (location != OI_DEVICE) {
+        o_s = reinterpret_cast<float *>(m_c + 2 * (size_t)B);
+        o_d = reinterpret_cast<uint32_t *>(o_s + K);
+        o_c = o_d + K;
+        OI_HIP_CHECK(hipMemsetAsync(o_s, 0, (2 * K + B) * 4, st));
+    }
+    OI_CHECK(oi_launch_rrf(ctx, m_d, m_c, m_d + L, m_c + B, B, depth, k, o_s, o_d, o_c));
+    if (location == OI_DEVICE) return OI_OK;
+    OI_HIP_CHECK(hipMemcpyAsync(scores_out, o_s, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(docs_out, o_d, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(counts_out, o_c, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
 }

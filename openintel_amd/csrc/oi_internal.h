@@ -139,9 +139,10 @@ struct PoolView {
 };
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
                      float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride);
+// shard s's lists start at scores + s*shard_stride (same for docs) and counts + s*count_stride
 int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
-                            const uint32_t *counts, uint32_t n_shards, uint32_t n_queries,
-                            uint32_t depth, const PoolView &pool);
+                            const uint32_t *counts, uint64_t shard_stride, uint64_t count_stride,
+                            uint32_t n_shards, uint32_t n_queries, uint32_t depth, const PoolView &pool);
 int oi_launch_rrf(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a, const uint32_t *docs_b,
                   const uint32_t *counts_b, uint32_t n_queries, uint32_t depth, uint32_t k,
                   float *scores_out, uint32_t *docs_out, uint32_t *counts_out);

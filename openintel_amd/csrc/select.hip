@@ -200,13 +200,14 @@ int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint
 
 // [n_shards][n_queries][depth] lists -> pool segment s of query q = shard s's list (keys rebuilt).
 __global__ void lists_to_pool_kernel(const float *scores, const uint32_t *docs, const uint32_t *counts,
-                                     uint32_t n_queries, uint32_t depth, uint64_t *pools, uint32_t *carry_cnt,
+                                     uint64_t shard_stride, uint64_t count_stride, uint32_t n_queries,
+                                     uint32_t depth, uint64_t *pools, uint32_t *carry_cnt,
                                      uint32_t *seg_cnt, uint64_t pool_stride, uint32_t carry_cap,
                                      uint32_t seg_cnt_stride) {
     const uint32_t q = blockIdx.x, sh = blockIdx.y;
-    uint32_t c = counts[(uint64_t)sh * n_queries + q];
+    uint32_t c = counts[(uint64_t)sh * count_stride + q];
     if (c > depth) c = depth;
-    const uint64_t src = ((uint64_t)sh * n_queries + q) * depth;
+    const uint64_t src = (uint64_t)sh * shard_stride + (uint64_t)q * depth;
     uint64_t *seg = pools + (uint64_t)q * pool_stride + carry_cap + (uint64_t)sh * depth;
     for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) seg[i] = oi_rank_key(scores[src + i], docs[src + i]);
     if (threadIdx.x == 0) {
@@ -216,12 +217,12 @@ __global__ void lists_to_pool_kernel(const float *scores, const uint32_t *docs, 
 }
 
 int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
-                            const uint32_t *counts, uint32_t n_shards, uint32_t n_queries,
-                            uint32_t depth, const PoolView &pool) {
+                            const uint32_t *counts, uint64_t shard_stride, uint64_t count_stride,
+                            uint32_t n_shards, uint32_t n_queries, uint32_t depth, const PoolView &pool) {
     if (n_queries == 0) return OI_OK;
     OI_REQUIRE(pool.seg_cap == depth && pool.n_segs == n_shards, "merge: pool geometry mismatch");
     hipLaunchKernelGGL(lists_to_pool_kernel, dim3(n_queries, n_shards), dim3(256), 0, ctx->stream, scores, docs,
-                       counts, n_queries, depth, pool.keys, pool.carry_cnt, pool.seg_cnt, pool.stride,
+                       counts, shard_stride, count_stride, n_queries, depth, pool.keys, pool.carry_cnt, pool.seg_cnt, pool.stride,
                        pool.carry_cap, pool.seg_cnt_stride);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;

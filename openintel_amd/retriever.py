@@ -48,6 +48,24 @@ class PostRetriever(abc.ABC):
         ...
 
 
+def packed_words(n_queries: int, depth: int) -> int:
+    """OI_PACKED_WORDS of include/openintel_hip.h."""
+    return 4 * n_queries * depth + 2 * n_queries
+
+
+def unpack_lists(packed, n_queries: int, depth: int) -> "RankedLists":
+    """Views into one shard's packed buffer (numpy array or torch tensor of 32-bit words)."""
+    L = n_queries * depth
+    if hasattr(packed, "data_ptr"):
+        import torch
+        sc = packed[:2 * L].view(torch.float32).reshape(2, n_queries, depth)
+    else:
+        sc = packed[:2 * L].view(np.float32).reshape(2, n_queries, depth)
+    dc = packed[2 * L:4 * L].reshape(2, n_queries, depth)
+    cn = packed[4 * L:].reshape(2, n_queries)
+    return RankedLists(sc[0], dc[0], cn[0], sc[1], dc[1], cn[1])
+
+
 def _is_dev(x) -> bool:
     return hasattr(x, "data_ptr")
 
@@ -147,6 +165,18 @@ class HybridIndex(PostRetriever):
             _lib.ptr(out.bm25_counts)))
         return out
 
+    def search_lists_packed(self, query_vecs, query_terms, q_term_offsets, depth: int = DEFAULT_DEPTH, out=None):
+        """The shard's two lists in the multi-GPU exchange format (include/openintel_hip.h,
+        OI_PACKED_WORDS): one flat int32/uint32 buffer, ready for all_gather_into_tensor."""
+        dev, B, qv, qt, qo = self._queries(query_vecs, query_terms, q_term_offsets)
+        words = packed_words(B, depth)
+        if out is None:
+            out = self._alloc(dev, (words,), np.uint32)
+        _lib.check(self.lib.oi_search_lists_packed(self.handle, _lib.ptr(qv), _lib.ptr(qt), _lib.ptr(qo), B,
+                                                   int(depth), _lib.OI_DEVICE if dev else _lib.OI_HOST,
+                                                   _lib.ptr(out)))
+        return out
+
     def search(self, query_vecs, query_terms, q_term_offsets, k: int = DEFAULT_K,
                depth: int = DEFAULT_DEPTH, out: Optional[SearchResult] = None) -> SearchResult:
         dev, B, qv, qt, qo = self._queries(query_vecs, query_terms, q_term_offsets)
@@ -188,6 +218,27 @@ def rrf_fuse(ctx: HipContext, docs_a, counts_a, docs_b, counts_b, k: int) -> Sea
                                    _lib.ptr(counts_b), B, depth, int(k),
                                    _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.scores),
                                    _lib.ptr(out.docs), _lib.ptr(out.counts)))
+    return out
+
+
+def fuse_packed(ctx: HipContext, packed_all, n_shards: int, n_queries: int, depth: int, k: int,
+                out: Optional[SearchResult] = None) -> SearchResult:
+    """All shards' packed lists ([n_shards * OI_PACKED_WORDS] words) -> global top-depth per list -> RRF top-k."""
+    dev = _is_dev(packed_all)
+    if not dev:
+        packed_all = np.ascontiguousarray(packed_all).view(np.uint32)
+    if out is None:
+        if dev:
+            import torch
+            mk = lambda shape, dt: torch.zeros(shape, dtype=dt, device=packed_all.device)
+            out = SearchResult(mk((n_queries, k), torch.float32), mk((n_queries, k), torch.int32),
+                               mk((n_queries,), torch.int32))
+        else:
+            out = SearchResult(np.zeros((n_queries, k), np.float32), np.zeros((n_queries, k), np.uint32),
+                               np.zeros(n_queries, np.uint32))
+    _lib.check(ctx.lib.oi_fuse_packed(ctx.handle, _lib.ptr(packed_all), int(n_shards), int(n_queries), int(depth),
+                                      int(k), _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.scores),
+                                      _lib.ptr(out.docs), _lib.ptr(out.counts)))
     return out
 
 

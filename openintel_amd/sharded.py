@@ -33,9 +33,12 @@ class ShardedRetriever:
     """`local` needs: local_stats() -> (tokens, df ndarray), finalize(N, tokens, df),
     search_lists(qv, qt, qo, depth) -> RankedLists (torch tensors on `device`), n_docs, vocab."""
 
-    def __init__(self, local, device, merge: Callable, fuse: Callable, group=None):
+    def __init__(self, local, device, merge: Callable, fuse: Callable, group=None,
+                 fuse_packed: Optional[Callable] = None):
         import torch.distributed as dist
         self.local, self.device, self.merge, self.fuse, self.group = local, device, merge, fuse, group
+        # fast path: the engine emits the packed exchange format and one call merges + fuses it
+        self.fuse_packed = fuse_packed if hasattr(local, "search_lists_packed") else None
         self.dist = dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -57,6 +60,15 @@ class ShardedRetriever:
     def search(self, qv, qt, qo, k: int, depth: int):
         """Returns (scores [B,k], docs [B,k], counts [B]) -- identical on every rank."""
         import torch
+        if self.fuse_packed is not None:
+            B = int(qv.shape[0])
+            packed = self.local.search_lists_packed(qv, qt, qo, depth=depth)
+            if self.world > 1:
+                flat = torch.empty(self.world * packed.numel(), dtype=packed.dtype, device=packed.device)
+                self.dist.all_gather_into_tensor(flat, packed, group=self.group)   # the ONE exchange per batch
+            else:
+                flat = packed
+            return self.fuse_packed(flat, self.world, B, depth, k)
         L = self.local.search_lists(qv, qt, qo, depth=depth)
         if self.world == 1:
             cos_d, cos_c, bm_d, bm_c = L.cos_docs, L.cos_counts, L.bm25_docs, L.bm25_counts
@@ -81,10 +93,14 @@ class ShardedRetriever:
 
 def make_hip_sharded(ctx, index, device, group=None) -> ShardedRetriever:
     """Wire the HIP merge / RRF kernels of `ctx` around a HybridIndex shard."""
-    from .retriever import merge_lists, rrf_fuse
+    from .retriever import fuse_packed, merge_lists, rrf_fuse
 
     def fuse(cd, cc, bd, bc, k):
         r = rrf_fuse(ctx, cd, cc, bd, bc, k)
         return r.scores, r.docs, r.counts
 
-    return ShardedRetriever(index, device, lambda s, d, c: merge_lists(ctx, s, d, c), fuse, group)
+    def fuse_p(flat, n_shards, B, depth, k):
+        r = fuse_packed(ctx, flat, n_shards, B, depth, k)
+        return r.scores, r.docs, r.counts
+
+    return ShardedRetriever(index, device, lambda s, d, c: merge_lists(ctx, s, d, c), fuse, group, fuse_packed=fuse_p)

@@ -390,6 +390,12 @@ def test_full_size_two_shards_equal_one(ctx, O):
     bs2, bd2, bc2 = oi.merge_lists(ctx, st("bm25_scores"), st("bm25_docs"), st("bm25_counts"))
     ctx.synchronize()
     assert np.array_equal(md.cpu().numpy(), cd) and np.array_equal(ms.cpu().numpy(), cs)
+    # the packed exchange path (what the sharded retriever all-gathers) gives the same fused answer
+    packed = torch.cat([ix.search_lists_packed(qv, qt, qo, depth=depth) for ix in shards])
+    Rp = oi.fuse_packed(ctx, packed, 2, B, depth, k)
+    Rl = oi.rrf_fuse(ctx, md, mc, bd2, bc2, k)
+    ctx.synchronize()
+    assert torch.equal(Rp.docs, Rl.docs) and torch.equal(Rp.scores, Rl.scores) and torch.equal(Rp.counts, Rl.counts)
     assert np.array_equal(bc2.cpu().numpy(), bc)
     for b in range(B):   # BM25 with global statistics is bit-identical to the unsharded index
         assert np.array_equal(bd2.cpu().numpy()[b, :bc[b]], bd[b, :bc[b]])

@@ -61,6 +61,28 @@ class OracleShard:
         return RankedLists(*[torch.from_numpy(x) for x in out])
 
 
+def _search_lists_packed(self, qv, qt, qo, depth):
+    L = self.search_lists(qv, qt, qo, depth)
+    sc = torch.stack([L.cos_scores, L.bm25_scores]).contiguous().view(torch.int32).reshape(-1)
+    dc = torch.stack([L.cos_docs, L.bm25_docs]).reshape(-1)
+    cn = torch.stack([L.cos_counts, L.bm25_counts]).reshape(-1)
+    return torch.cat([sc, dc, cn])           # the OI_PACKED_WORDS layout
+
+
+class OraclePackedShard(OracleShard):
+    search_lists_packed = _search_lists_packed
+
+
+def _fuse_packed(flat, n_shards, nb, depth, k):
+    from openintel_amd.retriever import packed_words, unpack_lists
+    W = packed_words(nb, depth)
+    shards = [unpack_lists(flat[s * W:(s + 1) * W], nb, depth) for s in range(n_shards)]
+    st = lambda f: torch.stack([getattr(x, f) for x in shards])
+    _, cd, cc = _merge(st("cos_scores"), st("cos_docs"), st("cos_counts"))
+    _, bd, bc = _merge(st("bm25_scores"), st("bm25_docs"), st("bm25_counts"))
+    return _fuse(cd, cc, bd, bc, k)
+
+
 def _merge(scores, docs, counts):
     S, nb, depth = scores.shape
     so, do, co = np.zeros((nb, depth), np.float32), np.zeros((nb, depth), np.int32), np.zeros(nb, np.int32)
@@ -80,15 +102,17 @@ def _fuse(cd, cc, bd, bc, k):
     return torch.from_numpy(fs), torch.from_numpy(fd), torch.from_numpy(fc)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, packed=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rows, terms, offs, q, qt, qo = _corpus()
         lo, hi = shard_bounds(N, world, rank)
         t_lo, t_hi = int(offs[lo]), int(offs[hi])
-        shard = OracleShard(rows[lo:hi], terms[t_lo:t_hi], (offs[lo:hi + 1] - offs[lo]).astype(np.uint64), lo)
-        sr = ShardedRetriever(shard, torch.device("cpu"), _merge, _fuse)
+        cls = OraclePackedShard if packed else OracleShard
+        shard = cls(rows[lo:hi], terms[t_lo:t_hi], (offs[lo:hi + 1] - offs[lo]).astype(np.uint64), lo)
+        sr = ShardedRetriever(shard, torch.device("cpu"), _merge, _fuse, fuse_packed=_fuse_packed if packed else None)
+        assert (sr.fuse_packed is not None) == packed
         sr.finalize()
         assert shard.n_global == N and shard.tok_global == int(offs[-1])
         s, d, c = sr.search(torch.from_numpy(q), torch.from_numpy(qt.astype(np.int32)),
@@ -113,11 +137,12 @@ def test_shard_bounds_cover_and_align():
 
 
 @pytest.mark.timeout(180)
-def test_two_ranks_match_unsharded_oracle():
+@pytest.mark.parametrize("packed", [False, True], ids=["lists", "packed-exchange"])
+def test_two_ranks_match_unsharded_oracle(packed):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, packed), nprocs=world, join=True)
     rows, terms, offs, q, qt, qo = _corpus()
     df, _ = O.bm25_df(terms, offs, VOCAB)
     for rank in range(world):
