@@ -198,8 +198,10 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d posts x %d-d f32, batch %d queries x 4 BM25 terms, "
+            "config": {"workload": "%s: %d posts x %d-d f32, batch %d queries x 4 BM25 terms, "
                                    "per-list depth %d, RRF top-%d; corpus row-sharded over %d GPU(s)" % (
+                                       "BASELINE configs[2]" if (args.docs, args.batch) == (10_000_000, 64) else
+                                       "BASELINE configs[1]" if (args.docs, args.batch) == (1_000_000, 1) else "custom",
                                        args.docs, args.dim, args.batch, args.depth, args.k, world),
                        "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
                        "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
