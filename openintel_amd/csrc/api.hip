@@ -645,21 +645,19 @@ extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t 
     const uint32_t carry_cap = OI_MAX_DEPTH;
     const uint64_t mstride = (uint64_t)carry_cap + (uint64_t)n_shards * depth;
     DevBuf &pk = ctx->buf("merge_pool"), &pc = ctx->buf("merge_counts"), &ml = ctx->buf("merged_lists");
-    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * mstride));
-    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)B * (1 + n_shards)));
+    OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)2 * B * mstride));
+    OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)2 * B * (1 + n_shards)));
     OI_CHECK(ml.ensure((4 * L + 2 * (size_t)B) * 4 + (2 * K + B) * 4));
-    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), pc.as<uint32_t>() + B, nullptr, mstride, carry_cap,
-                  depth, n_shards, n_shards, flag.as<uint32_t>()};
+    PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), pc.as<uint32_t>() + 2 * (size_t)B, nullptr, mstride,
+                  carry_cap, depth, n_shards, n_shards, flag.as<uint32_t>()};
     float *m_s = ml.as<float>();                       // [2][B][depth]
     uint32_t *m_d = ml.as<uint32_t>() + 2 * L;          // [2][B][depth]
     uint32_t *m_c = m_d + 2 * L;                        // [2][B]
-    for (int l = 0; l < 2; ++l) { // list 0 = cosine, 1 = BM25
-        const float *sc = reinterpret_cast<const float *>(d_in) + (size_t)l * L;
-        const uint32_t *dc = d_in + 2 * L + (size_t)l * L, *cn = d_in + 4 * L + (size_t)l * B;
-        OI_CHECK(oi_launch_lists_to_pool(ctx, sc, dc, cn, W, W, n_shards, B, depth, pool));
-        OI_CHECK(oi_launch_select(ctx, pool, B, depth, false, m_s + (size_t)l * L, m_d + (size_t)l * L,
-                                  m_c + (size_t)l * B, depth));
-    }
+    // scores[2][B][depth] is [2B][depth]: both lists of every query are merged by ONE pair of launches
+    // (2B virtual queries; list 0 = cosine, 1 = BM25)
+    OI_CHECK(oi_launch_lists_to_pool(ctx, reinterpret_cast<const float *>(d_in), d_in + 2 * L, d_in + 4 * L, W, W,
+                                     n_shards, 2 * B, depth, pool));
+    OI_CHECK(oi_launch_select(ctx, pool, 2 * B, depth, false, m_s, m_d, m_c, depth));
     float *o_s = scores_out;
     uint32_t *o_d = docs_out, *o_c = counts_out;
     if (location != OI_DEVICE) {

@@ -19,6 +19,8 @@
 // into the lowercased text: A-Z -> a-z, U+212A (E2 84 AA) -> 'k', U+0130 (C4 B0) ->
 // 'i' + U+0307.  All other non-ASCII bytes separate tokens.  A lane whose window holds
 // a 0xAA or 0xB0 byte takes a (rare) exact per-char path.
+#include <cstdlib>
+
 #include "oi_device.h"
 #include "oi_internal.h"
 
@@ -137,7 +139,7 @@ __device__ void lex_slow_chunk(const uint8_t *blob, uint64_t lo, uint64_t hi, ui
     }
 }
 
-__global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
+__global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel_v1(const uint8_t *blob, const uint64_t *offsets,
                                                               uint64_t n, uint64_t blob_bytes,
                                                               const LexEntry *table, uint32_t mult,
                                                               double *pol_out, uint8_t *spec_out) {
@@ -272,6 +274,280 @@ __global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blo
     }
 }
 
+// =====================================================================================
+// v2 scan: 64 bytes per lane, cheap per-token filter, dense candidate pass.
+//
+// PMC on v1 (16 bytes per lane): 794 VALU wave-instructions per 1 KiB of text, VALU-bound at 10 % of
+// the HBM roof.  Three things made it so: (1) per-lane fixed work (window load, SWAR masks, the
+// post binary search) paid per 16 bytes; (2) the full token extraction (4 LDS reads + 3 SWAR
+// lowercase/alnum passes) paid for EVERY token although 97 % are not lexicon words; (3) with 64
+// lanes each holding a token, some lane almost always needs the expensive path, so a per-token
+// early-out does not help a wave.  v2: (1) a lane owns 64 bytes; (2) tokens are screened by length
+// (2..9, from the alnum bit mask alone) and by a 2048-bit Bloom filter on their first two
+// case-folded chars (one ds_read2 + one ds_read); (3) survivors (~5 %) are queued per wave in LDS
+// and looked up afterwards with all lanes busy.
+#define LX_CH 64                      // bytes per lane
+#define LX_SUB (LEX_THREADS * LX_CH)  // 16 KiB sub-tile
+#define LX_PPT 512                    // posts per workgroup tile
+#define LX_QCAP 160                   // candidate queue entries per wave and sub-tile
+
+struct Lex2Shared {
+    LexEntry table[LEX_SLOTS];
+    uint32_t off[LX_PPT + 1];          // post offsets relative to the tile's first byte
+    uint32_t bull[LX_PPT], bear[LX_PPT], spec[LX_PPT];
+    // [g0-16, g0+LX_SUB+16) with ONE PAD DWORD after every 64-byte lane chunk: lane c's chunk starts at
+    // dword 4 + 17c, so lanes reading the same offset of their chunks hit 32 different banks (an
+    // unpadded 64-byte lane stride put them on 2 banks: 74 % of the LDS cycles were conflicts).
+    uint32_t text[(LX_SUB + 32) / 4 + LEX_THREADS];
+    uint32_t q_cnt[LEX_THREADS / 64];
+    uint2 queue[LEX_THREADS / 64][LX_QCAP];
+};
+
+// 256-bit Bloom filter on a token's first two case-folded chars, held in 8 registers per lane
+// (39 words -> <= 15 % false positives; the dense pass resolves them exactly).
+// logical dword D of the staged text (D = 0..3 left halo, 4.. the sub-tile) -> physical LDS dword
+__device__ __forceinline__ uint32_t lx_phys(uint32_t D) { return D + ((D - 4u) >> 4); } // D >= 4
+__device__ __forceinline__ uint32_t lex_bloom_slot(uint32_t two_chars_folded) {
+    return (two_chars_folded * 0x9E3779B1u) >> 24; // 8 bits
+}
+
+__device__ __forceinline__ void lex2_hit(Lex2Shared &s, uint32_t mult, uint32_t k0, uint32_t k1, uint32_t c8,
+                                         uint32_t len, uint32_t post) {
+    const uint32_t c8_len = c8 | (len << 8);
+    const LexEntry e = s.table[lex_hash(k0, k1, c8_len, mult)];
+    if (e.flags != 0 && e.k0 == k0 && e.k1 == k1 && e.c8_len == c8_len) {
+        if (e.flags & 1u) atomicAdd(&s.bull[post], 1u);
+        if (e.flags & 2u) atomicAdd(&s.bear[post], 1u);
+        if (e.flags & 4u) atomicOr(&s.spec[post], 1u);
+    }
+}
+
+// Exact per-char path (possible U+212A / U+0130 nearby); positions relative to the tile's first byte.
+__device__ void lex2_slow_chunk(const uint8_t *tb, uint32_t lo, uint32_t hi, uint32_t j, Lex2Shared &s,
+                                uint32_t mult) {
+    for (uint32_t pos = lo; pos < hi; ++pos) {
+        while (pos >= s.off[j + 1]) ++j;
+        const uint32_t pstart = s.off[j], pend = s.off[j + 1];
+        const uint32_t b = tb[pos];
+        if ((b & 0xC0u) == 0x80u) continue;
+        uint32_t first;
+        if (b < 0x80u) first = (b - 'A' < 26u) ? b + 32u : b;
+        else if (b == 0xE2u && pos + 2 < pend && tb[pos + 1] == 0x84u && tb[pos + 2] == 0xAAu) first = 'k';
+        else if (b == 0xC4u && pos + 1 < pend && tb[pos + 1] == 0xB0u) first = 'i';
+        else first = 0;
+        if (!lex_is_alnum(first)) continue;
+        if (pos > pstart) {
+            uint32_t p = pos - 1;
+            while (p > pstart && (tb[p] & 0xC0u) == 0x80u) --p;
+            const uint32_t pb = tb[p];
+            uint32_t last;
+            if (pb < 0x80u) last = (pb - 'A' < 26u) ? pb + 32u : pb;
+            else if (pb == 0xE2u && p + 3 == pos && tb[p + 1] == 0x84u && tb[p + 2] == 0xAAu) last = 'k';
+            else last = 0;
+            if (lex_is_alnum(last)) continue;
+        }
+        uint32_t len = 0, k0 = 0, k1 = 0, c8 = 0, p = pos;
+        while (p < pend) {
+            uint32_t c, adv;
+            bool ends = false;
+            const uint32_t bb = tb[p];
+            if (bb < 0x80u) { c = (bb - 'A' < 26u) ? bb + 32u : bb; adv = 1; }
+            else if (bb == 0xE2u && p + 2 < pend && tb[p + 1] == 0x84u && tb[p + 2] == 0xAAu) { c = 'k'; adv = 3; }
+            else if (bb == 0xC4u && p + 1 < pend && tb[p + 1] == 0xB0u) { c = 'i'; adv = 2; ends = true; }
+            else break;
+            if (!lex_is_alnum(c)) break;
+            if (len < 4) k0 |= c << (8 * len);
+            else if (len < 8) k1 |= c << (8 * (len - 4));
+            else if (len == 8) c8 = c;
+            ++len;
+            p += adv;
+            if (ends) break;
+        }
+        if (len <= 9) lex2_hit(s, mult, k0, k1, c8, len, j);
+    }
+}
+
+// alnum flags of 4 ASCII bytes, one bit per byte (letters by case folding: |0x20 maps A-Z onto a-z
+// and nothing else into that range; bytes >= 0x80 never match)
+__device__ __forceinline__ uint32_t lex2_alnum4(uint32_t w) {
+    const uint32_t hi = w & 0x80808080u;
+    const uint32_t w7 = w & 0x7F7F7F7Fu;
+    const uint32_t f = (swar_range(w7 | 0x20202020u, 'a', 'z') | swar_range(w7, '0', '9')) & ~hi;
+    return swar_movemask(f);
+}
+
+// Look one queued candidate up: 12 bytes at LDS byte index `ti`, `len` alnum chars, post `j`.
+__device__ __forceinline__ void lex2_lookup(Lex2Shared &s, uint32_t mult, uint32_t ti, uint32_t len, uint32_t j) {
+    const uint32_t wi = ti >> 2, sh = ti & 3u;
+    const uint32_t x0 = s.text[lx_phys(wi)], x1 = s.text[lx_phys(wi + 1)], x2 = s.text[lx_phys(wi + 2)],
+                   x3 = s.text[lx_phys(wi + 3)];
+    // every char inside `len` is ASCII alphanumeric: |0x20 lowercases letters and leaves digits alone
+    const uint32_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh) | 0x20202020u;
+    const uint32_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh) | 0x20202020u;
+    const uint32_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh) | 0x20202020u;
+    const uint32_t k0 = t0 & byte_mask(len);
+    const uint32_t k1 = len > 4 ? (t1 & byte_mask(len - 4)) : 0u;
+    const uint32_t c8 = len == 9 ? (t2 & 0xFFu) : 0u;
+    lex2_hit(s, mult, k0, k1, c8, len, j);
+}
+
+__global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
+                                                              uint64_t n, uint64_t blob_bytes,
+                                                              const LexEntry *table, const uint32_t *bloom,
+                                                              uint32_t mult, double *pol_out, uint8_t *spec_out) {
+    __shared__ __attribute__((aligned(16))) Lex2Shared s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    reinterpret_cast<uint4 *>(s.table)[tid] = reinterpret_cast<const uint4 *>(table)[tid];
+    uint32_t bl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bl[i] = bloom[i];
+
+    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * LX_PPT;
+        const uint32_t np = (uint32_t)((n - p0) < LX_PPT ? (n - p0) : LX_PPT);
+        __syncthreads(); // previous tile fully written out
+        const uint64_t byte_begin = offsets[p0];
+        for (uint32_t i = tid; i <= np; i += LEX_THREADS) s.off[i] = (uint32_t)(offsets[p0 + i] - byte_begin);
+        for (uint32_t i = tid; i < LX_PPT; i += LEX_THREADS) { s.bull[i] = 0; s.bear[i] = 0; s.spec[i] = 0; }
+        __syncthreads();
+        const uint32_t n_bytes = s.off[np];
+        const uint8_t *tb = blob + byte_begin;
+        // sub-tiles start 16-byte aligned in the blob: rel position of sub-tile start may be negative
+        const uint32_t head = (uint32_t)(byte_begin & 15u); // bytes of the first sub-tile before byte_begin
+        for (uint32_t sb = 0; sb < n_bytes + head; sb += LX_SUB) {
+            // this sub-tile covers tile-relative positions [sb - head, sb - head + LX_SUB)
+            const uint64_t g0 = byte_begin - head + sb; // absolute, 16-byte aligned
+            // ---- stage [g0-16, g0+LX_SUB+16) -> LDS, 16 B per lane per step, zeros outside the blob
+            for (uint32_t v = tid; v < LX_SUB / 16 + 2; v += LEX_THREADS) {
+                uint4 x = make_uint4(0, 0, 0, 0);
+                const uint64_t a = g0 + (uint64_t)v * 16; // absolute address + 16 (slot 0 = g0-16)
+                if (a >= 16) {
+                    const uint64_t src = a - 16;
+                    if (src + 16 <= blob_bytes) x = *reinterpret_cast<const uint4 *>(blob + src);
+                    else if (src < blob_bytes) {
+                        uint32_t w[4] = {0, 0, 0, 0};
+                        for (uint32_t i = 0; src + i < blob_bytes; ++i) w[i >> 2] |= (uint32_t)blob[src + i] << (8 * (i & 3));
+                        x = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                }
+                const uint32_t D = 4u * v; // logical dword of this 16-byte unit
+                const uint32_t P = v == 0 ? 0u : lx_phys(D);
+                s.text[P] = x.x; s.text[P + 1] = x.y; s.text[P + 2] = x.z; s.text[P + 3] = x.w;
+            }
+            if (lane == 0) s.q_cnt[wv] = 0;
+            __syncthreads();
+
+            // lane chunk: tile-relative positions [c0, c0+64); may start before 0 in the first sub-tile
+            const int64_t c0s = (int64_t)sb - head + (int64_t)tid * LX_CH;
+            const int64_t lo_s = c0s > 0 ? c0s : 0;
+            const int64_t hi_s = (c0s + LX_CH) < (int64_t)n_bytes ? (c0s + LX_CH) : (int64_t)n_bytes;
+            if (lo_s < hi_s) {
+                const uint32_t lo = (uint32_t)lo_s, hi = (uint32_t)hi_s;
+                const uint32_t tbase = 16 + tid * LX_CH; // LDS byte index of the chunk's first byte
+                // post containing lo: largest j with off[j] <= lo
+                uint32_t jl = 0, jr = np;
+                while (jr - jl > 1) {
+                    const uint32_t mid = (jl + jr) >> 1;
+                    if (s.off[mid] <= lo) jl = mid; else jr = mid;
+                }
+                uint32_t j = jl;
+                // window: bytes [c0-16, c0+80) = 24 dwords (six aligned 16-byte LDS reads)
+                uint32_t W[24];
+                {
+                    const uint32_t pc = 4u + 17u * tid; // physical dword of this lane's chunk
+                    const uint32_t ph = tid == 0 ? 0u : pc - 5u; // the 4 dwords before it (skip the pad)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) W[i] = s.text[ph + i];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) W[4 + i] = s.text[pc + i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) W[20 + i] = s.text[pc + 17 + i]; // next chunk / right halo
+                }
+                uint32_t any = 0;
+#pragma unroll
+                for (int i = 3; i < 23; ++i) any |= W[i];
+                bool special = false;
+                if (any & 0x80808080u) {
+#pragma unroll
+                    for (int i = 3; i < 23; ++i) special = special || swar_has_byte(W[i], 0xAAu) || swar_has_byte(W[i], 0xB0u);
+                }
+                if (special) {
+                    lex2_slow_chunk(tb, lo, hi, j, s, mult);
+                } else {
+                    // alnum bit per byte: `cand` = my 64 bytes, `ext` = the 12 after, prev = the byte before
+                    uint64_t cand = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cand |= (uint64_t)lex2_alnum4(W[4 + i]) << (4 * i);
+                    const uint64_t ext = (uint64_t)lex2_alnum4(W[20]) | ((uint64_t)lex2_alnum4(W[21]) << 4) |
+                                         ((uint64_t)lex2_alnum4(W[22]) << 8);
+                    const uint64_t prevbit = (lex2_alnum4(W[3]) >> 3) & 1u;
+                    uint64_t starts = cand & ~((cand << 1) | prevbit);
+                    // a post's first byte starts a token whatever precedes it
+                    {
+                        uint32_t jj = j;
+                        uint32_t e = s.off[jj + 1];
+                        while (e < hi) {
+                            if ((int64_t)e >= c0s) starts |= cand & (1ull << (uint32_t)((int64_t)e - c0s));
+                            ++jj;
+                            e = s.off[jj + 1];
+                        }
+                        if ((int64_t)s.off[j] >= c0s && s.off[j] < hi) starts |= cand & (1ull << (uint32_t)((int64_t)s.off[j] - c0s));
+                    }
+                    // keep [lo, hi)
+                    const uint32_t lb = (uint32_t)((int64_t)lo - c0s), hb = (uint32_t)((int64_t)hi - c0s);
+                    if (lb) starts &= ~((1ull << lb) - 1ull);
+                    if (hb < 64) starts &= (1ull << hb) - 1ull;
+                    uint32_t pend = s.off[j + 1]; // end of the current post, kept in a register
+                    while (starts) {
+                        const uint32_t b = __builtin_ctzll(starts);
+                        starts &= starts - 1;
+                        // run of alnum bytes from b: bits of cand above b, then ext
+                        uint64_t x = cand >> b;
+                        if (b) x |= ext << (64 - b);
+                        uint32_t len = (uint32_t)__builtin_ctzll(~x);
+                        const uint32_t pos = (uint32_t)(c0s + b);
+                        while (pos >= pend) { ++j; pend = s.off[j + 1]; }
+                        const uint32_t room = pend - pos;
+                        if (len > room) len = room;
+                        if (len < 2 || len > 9) continue; // lexicon words are 2..9 chars
+                        // first two chars, case-folded, against the Bloom filter (the only LDS access here)
+                        const uint32_t ti = tbase + b, wi = ti >> 2;
+                        const uint32_t y0 = s.text[lx_phys(wi)], y1 = s.text[lx_phys(wi + 1)];
+                        const uint32_t two = (__builtin_amdgcn_alignbyte(y1, y0, ti & 3u) & 0xFFFFu) | 0x2020u;
+                        const uint32_t slot = lex_bloom_slot(two);
+                        const uint32_t sel = slot >> 5;
+                        const uint32_t lo4 = (sel & 1u) ? ((sel & 2u) ? bl[3] : bl[1]) : ((sel & 2u) ? bl[2] : bl[0]);
+                        const uint32_t hi4 = (sel & 1u) ? ((sel & 2u) ? bl[7] : bl[5]) : ((sel & 2u) ? bl[6] : bl[4]);
+                        const uint32_t bw = (sel & 4u) ? hi4 : lo4;
+                        if (!((bw >> (slot & 31u)) & 1u)) continue;
+                        const uint32_t qp = atomicAdd(&s.q_cnt[wv], 1u);
+                        if (qp < LX_QCAP) s.queue[wv][qp] = make_uint2(ti | (len << 16), j);
+                        else lex2_lookup(s, mult, ti, len, j); // queue full: look it up in place
+                    }
+                }
+            }
+            // ---- dense pass over this wave's queue (LDS ops of one wave complete in order)
+            {
+                uint32_t nq = s.q_cnt[wv];
+                if (nq > LX_QCAP) nq = LX_QCAP;
+                for (uint32_t c = lane; c < nq; c += 64) {
+                    const uint2 e = s.queue[wv][c];
+                    lex2_lookup(s, mult, e.x & 0xFFFFu, e.x >> 16, e.y);
+                }
+            }
+            __syncthreads(); // LDS text is restaged next iteration
+        }
+        // ---- one PostSignal per post (lexicon.rs:62-72; Polarity::new is the identity on [-1,1])
+        for (uint32_t i = tid; i < np; i += LEX_THREADS) {
+            const double bh = (double)s.bull[i], rh = (double)s.bear[i];
+            const double p = (bh + rh == 0.0) ? 0.0 : (bh - rh) / (bh + rh);
+            pol_out[p0 + i] = p;
+            spec_out[p0 + i] = (uint8_t)(s.spec[i] != 0);
+        }
+    }
+}
+
 // ---- host: word table ------------------------------------------------------------
 // openintel src/adapters/analyzer/lexicon.rs:9-44 (`calls`/`squeeze` are bull+jargon, `puts` bear+jargon)
 static const char *const kBull[] = {"moon", "calls", "long", "buy", "bullish", "squeeze", "breakout",
@@ -287,7 +563,7 @@ static uint32_t host_lex_hash(uint32_t k0, uint32_t k1, uint32_t c8_len, uint32_
     return (x * mult) >> 24;
 }
 
-static bool build_lex_table(LexEntry *table, uint32_t *mult_out) {
+static bool build_lex_table(LexEntry *table, uint32_t *mult_out, uint32_t *bloom) {
     struct Word { uint32_t k0, k1, c8_len, flags; };
     std::vector<Word> words;
     auto add = [&](const char *w, uint32_t flag) {
@@ -307,6 +583,11 @@ static bool build_lex_table(LexEntry *table, uint32_t *mult_out) {
     for (auto w : kBull) add(w, 1);
     for (auto w : kBear) add(w, 2);
     for (auto w : kJargon) add(w, 4);
+    memset(bloom, 0, 64 * sizeof(uint32_t));
+    for (auto &w : words) { // first two chars (already lowercase; |0x20 is the kernel's case fold)
+        const uint32_t slot = (((w.k0 & 0xFFFFu) | 0x2020u) * 0x9E3779B1u) >> 24;
+        bloom[slot >> 5] |= 1u << (slot & 31u);
+    }
     // smallest odd multiplier that makes the hash perfect over the 39 distinct words
     for (uint32_t mult = 1; mult < (1u << 24); mult += 2) {
         memset(table, 0, sizeof(LexEntry) * LEX_SLOTS);
@@ -325,24 +606,36 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
                       uint64_t blob_bytes, double *d_pol, uint8_t *d_spec) {
     if (n == 0) return OI_OK;
     OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "lexicon: text blob must be 16-byte aligned in HBM");
-    static LexEntry h_table[LEX_SLOTS];
+    struct HostTables { LexEntry table[LEX_SLOTS]; uint32_t bloom[64]; };
+    static HostTables h;
     static uint32_t h_mult = 0;
     static bool built = false;
     if (!built) {
-        if (!build_lex_table(h_table, &h_mult)) { oi_set_error("lexicon: no perfect hash found"); return OI_ERR_STATE; }
+        if (!build_lex_table(h.table, &h_mult, h.bloom)) { oi_set_error("lexicon: no perfect hash found"); return OI_ERR_STATE; }
         built = true;
     }
     DevBuf &tb = ctx->buf("lex_table");
     if (!tb.p) {
-        OI_CHECK(tb.ensure(sizeof(h_table)));
-        OI_HIP_CHECK(hipMemcpyAsync(tb.p, h_table, sizeof(h_table), hipMemcpyHostToDevice, ctx->stream));
+        OI_CHECK(tb.ensure(sizeof(h)));
+        OI_HIP_CHECK(hipMemcpyAsync(tb.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
     }
-    const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;
-    const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u; // 2 WGs of 4 waves resident per CU, 4 deep
-    const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
+    const LexEntry *d_table = tb.as<LexEntry>();
+    const uint32_t *d_bloom = reinterpret_cast<const uint32_t *>(d_table + LEX_SLOTS);
+    static const bool v1 = getenv("OI_LEXICON_V1") != nullptr; // A/B switch: the first-generation scan
     ProfScope ps(ctx, "lexicon");
-    hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                       blob_bytes, tb.as<LexEntry>(), h_mult, d_pol, d_spec);
+    if (v1) {
+        const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;
+        const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
+        const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
+        hipLaunchKernelGGL(lexicon_kernel_v1, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                           blob_bytes, d_table, h_mult, d_pol, d_spec);
+    } else {
+        const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+        const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
+        const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
+        hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                           blob_bytes, d_table, d_bloom, h_mult, d_pol, d_spec);
+    }
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

@@ -32,7 +32,7 @@ __device__ void bitonic_sort_desc(uint64_t *a, uint32_t P) {
 // alone in its bin) then runs out of LDS.  Large pools are scanned in place, one wave per segment.
 // compact: the pool is rewritten as carry = the selected keys, all segments empty, and the
 // threshold raised to the k-th score, so the next corpus chunk appends after them.
-#define SEL_LDS_KEYS 4096
+#define SEL_LDS_KEYS 8192
 
 struct SelSource {
     const uint64_t *pool;      // this query's pool
@@ -156,20 +156,34 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
         __syncthreads();
         m = s_cnt < k ? s_cnt : k;
     }
-    uint32_t P = 2;
-    while (P < m) P <<= 1;
-    for (uint32_t i = m + tid; i < P; i += SEL_THREADS) sel[i] = 0; // lowest possible key
-    __syncthreads();
-    bitonic_sort_desc(sel, P);
-
+    // Sorted output is needed only for a final list; an intermediate compaction just needs the set
+    // and its smallest key (the new threshold).
+    __shared__ unsigned long long s_min;
     if (out_scores) {
+        uint32_t P = 2;
+        while (P < m) P <<= 1;
+        for (uint32_t i = m + tid; i < P; i += SEL_THREADS) sel[i] = 0; // lowest possible key
+        __syncthreads();
+        bitonic_sort_desc(sel, P);
         for (uint32_t i = tid; i < m; i += SEL_THREADS) {
             const uint64_t key = sel[i];
             out_scores[(uint64_t)q * out_stride + i] = oi_rank_key_score(key);
             out_docs[(uint64_t)q * out_stride + i] = oi_rank_key_doc(key);
         }
-        if (tid == 0) out_counts[q] = m;
+        if (tid == 0) { out_counts[q] = m; s_min = m ? sel[m - 1] : 0; }
+    } else {
+        if (tid == 0) s_min = ~0ull;
+        __syncthreads();
+        unsigned long long lo = ~0ull;
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) lo = sel[i] < lo ? sel[i] : lo;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long v = __shfl_xor(lo, o, OI_WAVE);
+            lo = v < lo ? v : lo;
+        }
+        if ((tid & 63) == 0 && lo != ~0ull) atomicMin(&s_min, lo);
     }
+    __syncthreads();
     if (compact) {
         for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = sel[i];
         for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) segc[sg] = 0;
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
             if (m == k && tau_keys) {
                 // k docs at or above this score exist: a valid lower bound for the final
                 // k-th score, so later chunks may drop anything strictly below it.
-                const uint32_t t = (uint32_t)(sel[k - 1] >> 32);
+                const uint32_t t = (uint32_t)(s_min >> 32);
                 if (t > tau_keys[q]) tau_keys[q] = t;
             }
         }
