@@ -240,6 +240,19 @@ __device__ void bm_find_kth_from_top(const uint32_t *hist, uint32_t nbins, uint3
     }
 }
 
+// Wave-aggregated append: one LDS atomic per wave instead of one per lane on the same word.
+// Must be called by all active lanes of a converged region; returns the slot of lanes with pred.
+__device__ __forceinline__ uint32_t bm_wave_slot(bool pred, uint32_t *counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader, OI_WAVE);
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
 #define BM_TB 4 // query terms handled per batch (their cell bounds and postings are fetched together)
 
 __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
@@ -259,42 +272,102 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
     const uint32_t blk = block0 + blockIdx.x;
     const uint64_t cell0 = (uint64_t)blk * vocab;
     const uint32_t doc0 = doc_id_base + blk * BM_R;
-    uint32_t *t_s = sh + 8, *t_e = sh + 8 + BM_TB;
-    float *t_w = reinterpret_cast<float *>(sh + 8 + 2 * BM_TB);
+    // term info records: [0],[1] = the pipeline's double buffer (first batch of a query), [2] = scratch
+    // for the later batches of queries with more than BM_TB terms.  Record = s[TB] e[TB] w[TB] tb te.
+    constexpr uint32_t REC = 3 * BM_TB + 2;
+    auto rec_s = [&](uint32_t b) { return sh + 8 + b * REC; };
+    auto rec_e = [&](uint32_t b) { return sh + 8 + b * REC + BM_TB; };
+    auto rec_w = [&](uint32_t b) { return reinterpret_cast<float *>(sh + 8 + b * REC + 2 * BM_TB); };
+    auto rec_t = [&](uint32_t b) { return sh + 8 + b * REC + 3 * BM_TB; };
 
     for (uint32_t i = tid; i < BM_R / 4; i += BM_THREADS) reinterpret_cast<float4 *>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (uint32_t q = blockIdx.y; q < n_queries; q += gridDim.y) {
-        if (tid < 8) sh[tid] = 0;
-        const uint32_t t_begin = q_offsets[q], t_end = q_offsets[q + 1];
-        const uint32_t tau = tau_keys ? tau_keys[q] : 0u;
-        Posting pr[BM_TB]; // the first 1024 postings of each run of the LAST batch stay in registers
-        // ---- accumulate: term batches; within a batch all bounds, then all postings, are in flight
-        // together (one memory latency each), accumulation itself is term by term (fixed order; a
-        // doc occurs at most once per run, so no two lanes touch the same accumulator)
-        for (uint32_t tb = t_begin; tb < t_end; tb += BM_TB) {
-            __syncthreads(); // previous batch done with the term info; sh reset visible
-            if (tid < BM_TB) {
-                uint32_t s0 = 0, e0 = 0;
-                float w0 = 0.f;
-                if (tb + tid < t_end) {
-                    const uint32_t t = q_terms[tb + tid];
-                    if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; w0 = idf[t]; }
-                }
-                t_s[tid] = s0; t_e[tid] = e0; t_w[tid] = w0;
+    // ---- software pipeline over this workgroup's queries q0, q0+G, q0+2G, ...:
+    //   stage A (two queries ahead): the first batch's term ids -> (block, term) bounds and idf, into
+    //            registers of threads 0..TB-1 (three dependent loads);
+    //   stage B (one query ahead): the heads of those runs, one posting per thread and term;
+    //   stage C: accumulate / emit the current query out of registers and LDS.
+    // A (block, query) task is ~5 dependent memory steps; unpipelined they dominated the kernel.
+    const uint32_t G = gridDim.y;
+    uint32_t r_s = 0, r_e = 0, r_tb = 0, r_te = 0;
+    float r_w = 0.f;
+    auto stage_a = [&](uint32_t qa) { // threads 0..TB-1 (+ everyone gets tb/te of their own copy)
+        r_s = r_e = r_tb = r_te = 0; r_w = 0.f;
+        if (tid < BM_TB && qa < n_queries) {
+            r_tb = q_offsets[qa]; r_te = q_offsets[qa + 1];
+            if (r_tb + tid < r_te) {
+                const uint32_t t = q_terms[r_tb + tid];
+                if (t < vocab) { r_s = cell_start[cell0 + t]; r_e = cell_start[cell0 + t + 1]; r_w = idf[t]; }
             }
-            __syncthreads();
+        }
+    };
+    auto store_a = [&](uint32_t b) {
+        if (tid < BM_TB) {
+            rec_s(b)[tid] = r_s; rec_e(b)[tid] = r_e; rec_w(b)[tid] = r_w;
+            if (tid == 0) { rec_t(b)[0] = r_tb; rec_t(b)[1] = r_te; }
+        }
+    };
+    auto stage_b = [&](uint32_t b, Posting (&p)[BM_TB]) {
 #pragma unroll
-            for (int j = 0; j < BM_TB; ++j) {
-                pr[j].dib = 0xFFFFFFFFu;
-                if (t_s[j] + tid < t_e[j]) pr[j] = postings[t_s[j] + tid];
+        for (int j = 0; j < BM_TB; ++j) {
+            p[j].dib = 0xFFFFFFFFu;
+            p[j].impact = 0.f;
+            if (rec_s(b)[j] + tid < rec_e(b)[j]) p[j] = postings[rec_s(b)[j] + tid];
+        }
+    };
+    Posting pr[BM_TB], pr_nxt[BM_TB];
+    {
+        stage_a(blockIdx.y);
+        __syncthreads();
+        store_a(0);
+        __syncthreads();
+        stage_b(0, pr);
+        stage_a(blockIdx.y + G);
+    }
+
+    uint32_t it = 0;
+    for (uint32_t q = blockIdx.y; q < n_queries; q += G, ++it) {
+        const uint32_t cb = it & 1u; // record holding THIS query's first batch
+        __syncthreads();             // everyone is done with the previous query (record cb^1, sh, list)
+        store_a(cb ^ 1u);            // first batch of query q+G
+        if (tid < 8) sh[tid] = 0;
+        __syncthreads();
+        stage_b(cb ^ 1u, pr_nxt);    // in flight while this query is processed
+        stage_a(q + 2 * G);          // dto.
+        const uint32_t t_begin = rec_t(cb)[0], t_end = rec_t(cb)[1];
+        const uint32_t tau = tau_keys ? tau_keys[q] : 0u;
+        const bool single_batch = t_end - t_begin <= BM_TB; // then `pr` holds every run's head
+        uint32_t *t_s = rec_s(cb), *t_e = rec_e(cb);
+        float *t_w = rec_w(cb);
+        // ---- accumulate: term by term (fixed order; a doc occurs at most once per run, so no two
+        // lanes touch the same accumulator)
+        uint32_t fresh = 0; // docs this thread touched first (summed per wave, then ONE LDS atomic per wave:
+                            // a per-thread atomic on one LDS word serialised 4096 times per task)
+        for (uint32_t tb = t_begin; tb < t_end; tb += BM_TB) {
+            if (tb != t_begin) { // later batches of a long query: not pipelined
+                t_s = rec_s(2); t_e = rec_e(2); t_w = rec_w(2);
+                __syncthreads();
+                if (tid < BM_TB) {
+                    uint32_t s0 = 0, e0 = 0;
+                    float w0 = 0.f;
+                    if (tb + tid < t_end) {
+                        const uint32_t t = q_terms[tb + tid];
+                        if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; w0 = idf[t]; }
+                    }
+                    t_s[tid] = s0; t_e[tid] = e0; t_w[tid] = w0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < BM_TB; ++j) {
+                    pr[j].dib = 0xFFFFFFFFu;
+                    if (t_s[j] + tid < t_e[j]) pr[j] = postings[t_s[j] + tid];
+                }
             }
 #pragma unroll
             for (int j = 0; j < BM_TB; ++j) {
                 const uint32_t s = t_s[j], e = t_e[j];
                 if (s == e) continue; // uniform
                 const float w = t_w[j];
-                uint32_t fresh = 0;
                 if (pr[j].dib != 0xFFFFFFFFu) {
                     const float old = acc[pr[j].dib];
                     acc[pr[j].dib] = __fadd_rn(old, __fmul_rn(w, pr[j].impact));
@@ -306,20 +379,25 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                     acc[p.dib] = __fadd_rn(old, __fmul_rn(w, p.impact));
                     fresh += old == 0.0f;
                 }
-                if (fresh) atomicAdd(&sh[0], fresh);
                 __syncthreads();
             }
         }
+        fresh = oi_wave_sum(fresh);
+        if (lane == 0 && fresh) atomicAdd(&sh[0], fresh);
         __syncthreads();
         const uint32_t touched = sh[0];
-        if (touched == 0) { __syncthreads(); continue; }
+        if (touched == 0) {
+#pragma unroll
+            for (int j = 0; j < BM_TB; ++j) pr[j] = pr_nxt[j];
+            continue;
+        }
 
         // Walk every run of the query again, run by run (a doc occurs once per run, so within a run
         // no two lanes touch the same accumulator; the barrier orders the runs).
-        const bool single_batch = t_end - t_begin <= BM_TB; // then `pr` still holds every run's head
         auto walk = [&](auto &&visit) {
             for (uint32_t tb = t_begin; tb < t_end; tb += BM_TB) {
                 if (!single_batch) {
+                    t_s = rec_s(2); t_e = rec_e(2);
                     __syncthreads();
                     if (tid < BM_TB) {
                         uint32_t s0 = 0, e0 = 0;
@@ -340,30 +418,38 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                 for (int j = 0; j < BM_TB; ++j) {
                     const uint32_t s = t_s[j], e = t_e[j];
                     if (s == e) continue;
-                    if (pr[j].dib != 0xFFFFFFFFu) visit(pr[j].dib);
-                    for (uint32_t i = s + BM_THREADS + tid; i < e; i += BM_THREADS) visit(postings[i].dib);
+                    visit(pr[j].dib); // every lane calls (wave-aggregated appends inside); sentinel = no posting
+                    for (uint32_t i0 = s + BM_THREADS; i0 < e; i0 += BM_THREADS) // uniform trip count
+                        visit(i0 + tid < e ? postings[i0 + tid].dib : 0xFFFFFFFFu);
                     __syncthreads();
                 }
             }
         };
         // emit + clear: the first run to reach a doc takes it (|acc|: a marking walk may have negated it)
-        auto emit_visit = [&](uint32_t dib) {
-            const float v = fabsf(acc[dib]);
-            if (v != 0.0f) {
-                acc[dib] = 0.0f;
-                if (oi_f32_key(v) >= tau) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + dib);
+        auto emit_visit = [&](uint32_t dib) { // dib == 0xFFFFFFFF: this lane has no posting in this step
+            float v = 0.0f;
+            if (dib != 0xFFFFFFFFu) {
+                v = fabsf(acc[dib]);
+                if (v != 0.0f) acc[dib] = 0.0f;
             }
+            const bool keep = v != 0.0f && oi_f32_key(v) >= tau;
+            const uint32_t slot = bm_wave_slot(keep, &sh[1]);
+            if (keep) list[slot] = oi_rank_key(v, doc0 + dib);
         };
         bool dense = touched > depth;
         if (dense && tau != 0u) {
             // Many docs touched, but a threshold is known: count the docs at or above it (marking each
             // visited accumulator by its sign so that a doc is counted once); they almost always fit.
             walk([&](uint32_t dib) {
-                const float v = acc[dib];
-                if (v > 0.0f) {
-                    acc[dib] = -v;
-                    if (oi_f32_key(v) >= tau) atomicAdd(&sh[5], 1u);
+                bool hit = false;
+                if (dib != 0xFFFFFFFFu) {
+                    const float v = acc[dib];
+                    if (v > 0.0f) {
+                        acc[dib] = -v;
+                        hit = oi_f32_key(v) >= tau;
+                    }
                 }
+                (void)bm_wave_slot(hit, &sh[5]);
             });
             dense = sh[5] > depth;
         }
@@ -416,7 +502,9 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                 const uint32_t bits = __float_as_uint(v);
                 bool take = bits > T;
                 if (bits == T) { take = before < n_ties; ++before; }
-                if (take && oi_f32_key(v) >= tau) list[atomicAdd(&sh[1], 1u)] = oi_rank_key(v, doc0 + base + i);
+                const bool keep = take && oi_f32_key(v) >= tau;
+                const uint32_t slot = bm_wave_slot(keep, &sh[1]);
+                if (keep) list[slot] = oi_rank_key(v, doc0 + base + i);
                 acc[base + i] = 0.0f;
             }
             __syncthreads();
@@ -426,11 +514,12 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
         uint64_t *seg = pools + (uint64_t)q * pool_stride + carry_cap + (uint64_t)blk * depth;
         for (uint32_t i = tid; i < cnt; i += BM_THREADS) seg[i] = list[i];
         if (tid == 0) seg_cnt[(uint64_t)q * seg_cnt_stride + blk] = cnt;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < BM_TB; ++j) pr[j] = pr_nxt[j];
     }
 }
 
-#define BM_SMEM (BM_R * 4 + 2048 * 4 + OI_MAX_DEPTH * 8 + 32 * 4 + (8 + 3 * BM_TB) * 4)
+#define BM_SMEM (BM_R * 4 + 2048 * 4 + OI_MAX_DEPTH * 8 + 32 * 4 + (8 + 3 * (3 * BM_TB + 2)) * 4)
 
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
                    uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,
