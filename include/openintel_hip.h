@@ -137,6 +137,12 @@ int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df
 int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                       const uint32_t *global_df_host);
 
+/* Contract for the batch BM25 scan (used for batches of >= 16 queries): no query of a batch has more
+ * than `max_terms` terms (default 16).  The scan handles 1024 / max_terms queries per pass over the
+ * forward index; a longer query sets the ctx's error flag (OI_ERR_OVERFLOW at the next host-visible
+ * point).  The term-at-a-time path (smaller batches, or OI_BM25_MODE=taat) has no such limit. */
+int oi_index_set_max_query_terms(oi_index *idx, uint32_t max_terms);
+
 /*
  * Per-shard ranked lists for a batch of queries.
  *   query_vecs      n_queries x dim f32 (normalised by the caller if cosine is wanted)

@@ -1,5 +1,7 @@
 // api.hip -- the extern "C" surface of libopenintel_hip.so (see include/openintel_hip.h).
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "oi_internal.h"
 
@@ -234,6 +236,7 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
         idx->postings.release(); idx->cell_start.release(); idx->idf.release();
+        idx->fwd_terms.release(); idx->fwd_offsets.release();
     }
     delete idx;
 }
@@ -279,6 +282,14 @@ extern "C" int oi_index_set_forward(oi_index *idx, const uint32_t *term_ids, con
     t.release();
     o.release();
     return rc;
+}
+
+extern "C" int oi_index_set_max_query_terms(oi_index *idx, uint32_t max_terms) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(max_terms >= 1 && max_terms <= 1024, "max_query_terms=%u outside [1,1024]", max_terms);
+    std::lock_guard<std::mutex> g(idx->ctx->mu);
+    idx->max_query_terms = max_terms;
+    return OI_OK;
 }
 
 extern "C" int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df_out_host) {
@@ -396,17 +407,65 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // ---- BM25 list
     if (bm_s) {
         OI_REQUIRE(idx->finalized, "search: index not finalized");
-        // Two phases, like the cosine chunks: the first eighth of the doc blocks fixes a per-query
-        // threshold (the depth-th score seen so far is a lower bound of the final one); the remaining
-        // blocks then emit only candidates at or above it, so the final selection scans little.
-        const uint32_t nb = idx->n_blocks;
-        const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / 8) : nb;
-        OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, 0, first));
-        if (first < nb) {
-            OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth));
-            OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, first, nb));
+        static const char *mode_env = getenv("OI_BM25_MODE"); // "taat" | "scan" | unset = by batch size
+        const bool have_fwd = idx->fwd_terms.p && idx->total_tokens > 0;
+        const bool scan = have_fwd && (mode_env ? strcmp(mode_env, "scan") == 0 : B >= 16);
+        if (!scan) {
+            // Term-at-a-time over the blocked inverted index.  Two phases, like the cosine chunks: the
+            // first eighth of the doc blocks fixes a per-query threshold (the depth-th score seen so far
+            // is a lower bound of the final one); the remaining blocks then emit only candidates at or
+            // above it, so the final selection scans little.
+            const uint32_t nb = idx->n_blocks;
+            const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / 8) : nb;
+            OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, 0, first));
+            if (first < nb) {
+                OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth));
+                OI_CHECK(oi_launch_bm25(idx, d_qt, d_qo, B, depth, P.bm, first, nb));
+            }
+            OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, false, bm_s, bm_d, bm_c, depth));
+        } else {
+            // Batch scan of the forward index (bm25_scan.hip): the whole batch in passes of up to
+            // 1024 / max_query_terms queries; docs in chunks sized from the pool's free room, the first
+            // chunk (1/8 of the docs) fixing the thresholds.  Same worst-case rule as the cosine pools:
+            // a chunk can append at most one entry per doc and query.
+            const uint32_t segs = 2u * (uint32_t)ctx->num_cus;
+            const uint64_t sslack = 512ull * (segs + 1);
+            uint64_t sstride = carry_cap + std::min<uint64_t>(n, 1ull << 23) + sslack;
+            const uint64_t sbudget = (4ull << 30) / 8 / B;
+            if (sstride > sbudget) sstride = std::max<uint64_t>(sbudget, carry_cap + 4 * sslack);
+            DevBuf &sp = ctx->buf("pool_bm_scan"), &sc = ctx->buf("pool_bm_scan_state");
+            OI_CHECK(sp.ensure(sizeof(uint64_t) * (size_t)B * sstride));
+            const size_t swords = (size_t)B * (2 + segs);
+            OI_CHECK(sc.ensure(sizeof(uint32_t) * swords));
+            OI_HIP_CHECK(hipMemsetAsync(sc.p, 0, sizeof(uint32_t) * swords, st));
+            uint32_t *w = sc.as<uint32_t>();
+            PoolView SP{sp.as<uint64_t>(), w, w + 2 * (size_t)B, w + B, sstride, carry_cap, 0, 0, segs, P.bm.overflow};
+            const uint64_t max_chunk = sstride - carry_cap - sslack;
+            const uint32_t pass = oi_bm25_scan_pass_queries(idx->max_query_terms);
+            for (uint32_t q0 = 0; q0 < B; q0 += pass) {
+                const uint32_t nq = std::min(pass, B - q0);
+                PoolView V = SP;
+                V.carry_cnt += q0; V.tau_keys += q0; // keys / seg_cnt are offset inside the kernel by q_begin
+                uint64_t r = 0, chunk = std::max<uint64_t>(n / 8, 65536);
+                bool first_chunk = true;
+                while (r < n) {
+                    if (chunk > max_chunk) chunk = max_chunk;
+                    const uint64_t e = std::min(n, r + chunk);
+                    oi_bm25_scan_geometry(ctx, e - r, &V.n_segs, &V.seg_cap);
+                    SP.n_segs = V.n_segs; SP.seg_cap = V.seg_cap;
+                    OI_CHECK(oi_launch_bm25_scan(idx, d_qt, d_qo, q0, nq, r, e, idx->avgdl, first_chunk, SP));
+                    const bool last = e == n;
+                    PoolView S2 = SP; // select works on this pass's queries only
+                    S2.keys += (uint64_t)q0 * sstride; S2.carry_cnt += q0; S2.tau_keys += q0;
+                    S2.seg_cnt += (uint64_t)q0 * segs;
+                    OI_CHECK(oi_launch_select(ctx, S2, nq, depth, /*compact=*/!last, last ? bm_s + (size_t)q0 * depth : nullptr,
+                                              last ? bm_d + (size_t)q0 * depth : nullptr, last ? bm_c + q0 : nullptr, depth));
+                    r = e;
+                    chunk = n; // everything that is left, as far as the pool allows
+                    first_chunk = false;
+                }
+            }
         }
-        OI_CHECK(oi_launch_select(ctx, P.bm, B, depth, false, bm_s, bm_d, bm_c, depth));
     }
     return OI_OK;
 }

@@ -93,6 +93,12 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
     OI_HIP_CHECK(hipStreamSynchronize(st));
     OI_REQUIRE(total < 0xFFFFFFFFull, "bm25: %llu tokens in one shard (limit 2^32-1)", (unsigned long long)total);
     idx->total_tokens = total;
+    // keep a copy of the forward index for the batch scan (4 B/token + 8 B/doc; +64 B so that the
+    // scan's last aligned 16-byte group may read past the end)
+    OI_CHECK(idx->fwd_terms.ensure(sizeof(uint32_t) * total + 64));
+    OI_CHECK(idx->fwd_offsets.ensure(sizeof(uint64_t) * (n + 1)));
+    if (total) OI_HIP_CHECK(hipMemcpyAsync(idx->fwd_terms.p, d_terms, sizeof(uint32_t) * total, hipMemcpyDeviceToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(idx->fwd_offsets.p, d_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToDevice, st));
     idx->n_blocks = (uint32_t)((n + BM_R - 1) / BM_R);
     OI_REQUIRE(idx->n_blocks < (1u << 17), "bm25: too many doc blocks");
     OI_REQUIRE((uint64_t)idx->n_blocks * idx->vocab < 0xFFFFFFFFull, "bm25: blocks x vocab exceeds 2^32");
@@ -194,6 +200,7 @@ int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, c
     OI_CHECK(idx->idf.ensure(sizeof(float) * idx->vocab));
     OI_HIP_CHECK(hipMemcpyAsync(idx->idf.p, idf.data(), sizeof(float) * idx->vocab, hipMemcpyHostToDevice, st));
     const float avgdl = (float)((double)global_tokens / (double)global_n);
+    idx->avgdl = avgdl;
     if (idx->n_postings) {
         OI_CHECK(idx->postings.ensure(sizeof(Posting) * idx->n_postings));
         uint64_t blocks = (idx->n_postings + 255) / 256;

@@ -1,0 +1,384 @@
+// bm25_scan.hip -- BM25 for a query BATCH as one coalesced HBM scan of the forward index.
+//
+// Builder-defined (the reference has no BM25); same score definition, bit for bit, as bm25.hip and
+// the CPU oracle: score(q, d) = sum over q's terms in query order of idf_t * (tf*(k1+1))/(tf+Kd).
+//
+// Why a second BM25 kernel.  The term-at-a-time kernel (bm25.hip) touches only the postings of the
+// query terms (115 MB for 64 queries at 10M docs) but is bound by its ~20 K (block, query) tasks of
+// dependent steps, far from any roofline.  For a batch, the union of the query terms (256 of 131072
+// here) makes a different trade attractive: stream the WHOLE forward index (4 B per token, 1.15 GB at
+// 10M docs) once per batch at HBM speed and test every token against the batch's term set in LDS.
+// Algorithmic bytes per batch: 4*T + 8*N (tokens + doc offsets); HBM-bound by construction.
+//
+//   phase 1  token-parallel: every lane loads 8 consecutive tokens (two 16-byte loads, fully
+//            coalesced), probes each in an LDS hash table of the batch's terms (2048 slots); a hit
+//            (~5 % of tokens) finds its doc by binary search in the tile's LDS-staged offsets and is
+//            pushed on that doc's LDS linked list (wave-aggregated slot allocation, atomicExch on the
+//            list head).
+//   phase 2  lane-per-doc over the tile's 512 docs: walk the list -> (term slot, tf) pairs (<= 6 distinct
+//            in registers), impacts from the doc length, then for every query that uses a matched term
+//            the f32 sum over its terms IN QUERY ORDER; survivors of the per-query threshold go to the
+//            workgroup's private pool segment (LDS fill counters, no global atomics).
+#include <cstdlib>
+
+#include "oi_device.h"
+#include "oi_internal.h"
+
+#define BS_THREADS 512
+#define BS_DPT 512          // docs per workgroup tile (one per lane in phase 2)
+#define BS_TPT 8            // tokens per thread and step in phase 1
+#define BS_HASH 2048        // term hash table slots (power of two)
+#define BS_MAX_TERMS 1024   // distinct batch terms (load factor <= 50 %)
+#define BS_MAX_Q 256        // queries per pass
+#define BS_MAX_QT 2048      // total (query, term) pairs per pass
+#define BS_HITCAP 8192      // hit entries per tile
+#define BS_NM 6             // distinct matched terms per doc kept in registers
+#define BS_NIL 0xFFFFu
+#define BS_K1 1.2f
+#define BS_B 0.75f
+
+struct BsBatch { // built once per batch by bm25_scan_setup (global memory, ~40 KB)
+    uint32_t key[BS_HASH];          // term id or 0xFFFFFFFF
+    float idf[BS_HASH];             // idf of the term in that slot
+    uint32_t users_off[BS_HASH + 1]; // CSR over slots: which (query, position) pairs use the term
+    uint32_t users[BS_MAX_QT];      // query << 16 | position
+    uint32_t q_off[BS_MAX_Q + 1];   // CSR over queries: their terms' slots in query order
+    uint32_t q_slot[BS_MAX_QT];     // slot or 0xFFFF (term outside the vocabulary: contributes nothing)
+    uint32_t n_queries, n_pairs, error, pad;
+};
+
+__device__ __forceinline__ uint32_t bs_hash(uint32_t t) { return (t * 0x9E3779B1u) >> 21; } // 11 bits
+
+// ------------------------------------------------------------------ batch setup (one workgroup)
+__global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms, const uint32_t *q_offsets,
+                                                         uint32_t q_begin, uint32_t n_queries, uint32_t vocab,
+                                                         uint32_t max_terms_per_query, const float *idf,
+                                                         BsBatch *out) {
+    __shared__ uint32_t cnt[BS_HASH];
+    __shared__ uint32_t scan_tmp[1024];
+    __shared__ uint32_t n_distinct;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t base = q_offsets[q_begin];
+    const uint32_t n_pairs = q_offsets[q_begin + n_queries] - base;
+    for (uint32_t i = tid; i < BS_HASH; i += 1024) { out->key[i] = 0xFFFFFFFFu; out->idf[i] = 0.f; cnt[i] = 0; }
+    if (tid == 0) { n_distinct = 0; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
+    for (uint32_t q = tid; q <= n_queries; q += 1024) out->q_off[q] = q_offsets[q_begin + q] - base;
+    __syncthreads();
+    __shared__ uint32_t too_long;
+    if (tid == 0) too_long = 0;
+    __syncthreads();
+    for (uint32_t q = tid; q < n_queries; q += 1024)
+        if (q_offsets[q_begin + q + 1] - q_offsets[q_begin + q] > max_terms_per_query) too_long = 1;
+    __syncthreads();
+    // the pass size was chosen as 1024 / max_terms_per_query queries, so these hold unless a query
+    // has more terms than the index was told to expect
+    if (too_long || n_pairs > BS_MAX_TERMS || n_queries > BS_MAX_Q) { if (tid == 0) out->error = 1; return; }
+    // insert every (query, position) pair's term; the hash POSITION is the term's slot id
+    for (uint32_t p = tid; p < n_pairs; p += 1024) {
+        const uint32_t t = q_terms[base + p];
+        uint32_t slot = BS_NIL;
+        if (t < vocab) {
+            uint32_t h = bs_hash(t);
+            for (;;) {
+                const uint32_t prev = atomicCAS(&out->key[h], 0xFFFFFFFFu, t);
+                if (prev == 0xFFFFFFFFu) { atomicAdd(&n_distinct, 1u); out->idf[h] = idf[t]; slot = h; break; }
+                if (prev == t) { slot = h; break; }
+                h = (h + 1) & (BS_HASH - 1);
+            }
+            atomicAdd(&cnt[slot], 1u);
+        }
+        out->q_slot[p] = slot;
+    }
+    __syncthreads();
+    if (n_distinct > BS_MAX_TERMS) { if (tid == 0) out->error = 2; return; }
+    // exclusive scan of cnt[2048] (two entries per thread)
+    const uint32_t a = cnt[2 * tid], b = cnt[2 * tid + 1];
+    scan_tmp[tid] = a + b;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? scan_tmp[tid - o] : 0u;
+        __syncthreads();
+        scan_tmp[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = scan_tmp[tid] - (a + b);
+    out->users_off[2 * tid] = excl;
+    out->users_off[2 * tid + 1] = excl + a;
+    if (tid == 1023) out->users_off[BS_HASH] = scan_tmp[1023];
+    cnt[2 * tid] = excl;       // reuse as fill cursors
+    cnt[2 * tid + 1] = excl + a;
+    __syncthreads();
+    // users: filled in pair order per query so that a term repeated in one query keeps its positions
+    // ascending (the order inside a slot's list is otherwise irrelevant)
+    for (uint32_t q = tid; q < n_queries; q += 1024) {
+        const uint32_t lo = out->q_off[q], hi = out->q_off[q + 1];
+        for (uint32_t p = lo; p < hi; ++p) {
+            const uint32_t slot = out->q_slot[p];
+            if (slot != BS_NIL) out->users[atomicAdd(&cnt[slot], 1u)] = (q << 16) | (p - lo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the scan
+struct BsShared {
+    uint32_t key[BS_HASH];
+    float idf[BS_HASH];
+    uint32_t users_off[BS_HASH + 1];
+    uint32_t users[BS_MAX_QT];
+    uint32_t q_off[BS_MAX_Q + 1];
+    uint32_t q_slot[BS_MAX_QT];
+    uint32_t tau[BS_MAX_Q];
+    uint32_t seg_fill[BS_MAX_Q];
+    uint32_t off[BS_DPT + 1];      // token offsets of the tile's docs, relative to the tile's first token
+    uint32_t head[BS_DPT];         // per-doc list head (entry index) or BS_NIL
+    uint32_t hit[BS_HITCAP];       // slot (low 16) | next entry (high 16)
+    uint32_t hit_cnt, overflow_tile;
+};
+
+__device__ __forceinline__ uint32_t bs_wave_slot(bool pred, uint32_t *counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = __shfl(base, leader, OI_WAVE);
+    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
+    const uint32_t *__restrict__ terms, const uint64_t *__restrict__ doc_offsets, uint64_t doc_begin,
+    uint64_t doc_end, float avgdl, const BsBatch *__restrict__ batch, const uint32_t *tau_keys, uint32_t q_begin,
+    uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride, uint64_t pool_stride,
+    uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    BsShared &s = *reinterpret_cast<BsShared *>(smem_raw);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (batch->error) { // a query broke the pass limits (see oi_index_set_max_query_terms): fail loudly
+        if (tid == 0) *overflow = 1u;
+        return;
+    }
+    const uint32_t nq = batch->n_queries;
+    // ---- batch tables -> LDS (once per workgroup)
+    for (uint32_t i = tid; i < BS_HASH; i += BS_THREADS) { s.key[i] = batch->key[i]; s.idf[i] = batch->idf[i]; s.users_off[i] = batch->users_off[i]; }
+    if (tid == 0) s.users_off[BS_HASH] = batch->users_off[BS_HASH];
+    for (uint32_t i = tid; i < batch->n_pairs; i += BS_THREADS) { s.users[i] = batch->users[i]; s.q_slot[i] = batch->q_slot[i]; }
+    for (uint32_t i = tid; i <= nq; i += BS_THREADS) s.q_off[i] = batch->q_off[i];
+    for (uint32_t i = tid; i < nq; i += BS_THREADS) { s.tau[i] = tau_keys ? tau_keys[q_begin + i] : 0u; s.seg_fill[i] = 0; }
+    __syncthreads();
+
+    uint64_t *my_seg = pools + (uint64_t)q_begin * pool_stride + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+    const uint64_t n_tiles = (doc_end - doc_begin + BS_DPT - 1) / BS_DPT;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t d0 = doc_begin + tile * BS_DPT;
+        const uint32_t nd = (uint32_t)((doc_end - d0) < BS_DPT ? (doc_end - d0) : BS_DPT);
+        const uint64_t t0 = doc_offsets[d0];
+        __syncthreads(); // previous tile done
+        if (tid < nd) s.off[tid] = (uint32_t)(doc_offsets[d0 + tid] - t0);
+        if (tid < BS_DPT) s.head[tid] = BS_NIL;
+        if (tid == 0) { // (nd may equal the block size: the end offset needs its own writer)
+            s.off[nd] = (uint32_t)(doc_offsets[d0 + nd] - t0);
+            s.hit_cnt = 0;
+            s.overflow_tile = 0;
+        }
+        __syncthreads();
+        const uint32_t n_tok = s.off[nd];
+
+        // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.
+        const uint32_t headpad = (uint32_t)(t0 & 3u); // tokens before t0 in the first aligned group
+        for (uint32_t sb = 0; sb < n_tok + headpad; sb += BS_THREADS * BS_TPT) {
+            const int64_t rel0 = (int64_t)sb - headpad + (int64_t)tid * BS_TPT; // tile-relative index of my first token
+            uint32_t tk[BS_TPT];
+            {
+                const uint64_t g = t0 - headpad + sb + (uint64_t)tid * BS_TPT; // absolute token index, multiple of 4
+#pragma unroll
+                for (int v = 0; v < BS_TPT / 4; ++v) {
+                    uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    const int64_t r = rel0 + 4 * v;
+                    if (r + 4 > 0 && r < (int64_t)n_tok) x = *reinterpret_cast<const uint4 *>(terms + g + 4 * v);
+                    tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BS_TPT; ++i) {
+                const int64_t r = rel0 + i;
+                const uint32_t t = tk[i];
+                bool hit = false;
+                uint32_t slot = 0;
+                if (r >= 0 && r < (int64_t)n_tok) {
+                    uint32_t h = bs_hash(t);
+                    for (;;) {
+                        const uint32_t k = s.key[h];
+                        if (k == t) { hit = true; slot = h; break; }
+                        if (k == 0xFFFFFFFFu) break;
+                        h = (h + 1) & (BS_HASH - 1);
+                    }
+                }
+                const uint32_t e = bs_wave_slot(hit, &s.hit_cnt);
+                if (hit) {
+                    if (e < BS_HITCAP) {
+                        // doc of token r: largest d with off[d] <= r
+                        uint32_t lo = 0, hi = nd;
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s.off[mid] <= (uint32_t)r) lo = mid; else hi = mid;
+                        }
+                        const uint32_t prev = atomicExch(&s.head[lo], e);
+                        s.hit[e] = slot | (prev << 16);
+                    } else {
+                        s.overflow_tile = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: one lane per doc
+        if (tid < nd) {
+            const uint32_t dlen = s.off[tid + 1] - s.off[tid];
+            uint32_t ms[BS_NM], mt[BS_NM];
+            uint32_t nm = 0;
+            bool slow = s.overflow_tile != 0;
+#pragma unroll
+            for (int k = 0; k < BS_NM; ++k) { ms[k] = 0xFFFFFFFFu; mt[k] = 0; }
+            if (!slow) {
+                for (uint32_t h = s.head[tid]; h != BS_NIL;) {
+                    const uint32_t ent = s.hit[h];
+                    const uint32_t sl = ent & 0xFFFFu;
+                    h = ent >> 16;
+                    bool found = false;
+#pragma unroll
+                    for (int k = 0; k < BS_NM; ++k)
+                        if (ms[k] == sl) { ++mt[k]; found = true; }
+                    if (!found) {
+                        if (nm < BS_NM) {
+#pragma unroll
+                            for (int k = 0; k < BS_NM; ++k)
+                                if ((uint32_t)k == nm) { ms[k] = sl; mt[k] = 1; }
+                            ++nm;
+                        } else {
+                            slow = true;
+                        }
+                    }
+                }
+            }
+            const float ratio = __fdiv_rn((float)dlen, avgdl);
+            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
+            const uint32_t doc = doc_id_base + (uint32_t)(d0 + tid);
+            auto emit = [&](uint32_t q, float score) {
+                if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
+                    const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
+                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc);
+                    else *overflow = 1u;
+                }
+            };
+            if (!slow) {
+                float imp[BS_NM];
+#pragma unroll
+                for (int k = 0; k < BS_NM; ++k) {
+                    const float ftf = (float)mt[k];
+                    imp[k] = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                }
+#pragma unroll
+                for (int k = 0; k < BS_NM; ++k) {
+                    if ((uint32_t)k >= nm) continue;
+                    const uint32_t ub = s.users_off[ms[k]], ue = s.users_off[ms[k] + 1];
+                    for (uint32_t u = ub; u < ue; ++u) {
+                        const uint32_t q = s.users[u] >> 16, pos_in_q = s.users[u] & 0xFFFFu;
+                        const uint32_t qb = s.q_off[q], qe = s.q_off[q + 1];
+                        // handle q exactly once per doc: at its FIRST term position whose slot matched
+                        bool first = true;
+                        for (uint32_t p = qb; p < qb + pos_in_q; ++p) {
+                            const uint32_t sl = s.q_slot[p];
+#pragma unroll
+                            for (int k2 = 0; k2 < BS_NM; ++k2)
+                                if (ms[k2] == sl && sl != BS_NIL) first = false;
+                        }
+                        if (!first) continue;
+                        float score = 0.0f;
+                        for (uint32_t p = qb; p < qe; ++p) {
+                            const uint32_t sl = s.q_slot[p];
+#pragma unroll
+                            for (int k2 = 0; k2 < BS_NM; ++k2)
+                                if (ms[k2] == sl && sl != BS_NIL) score = __fadd_rn(score, __fmul_rn(s.idf[sl], imp[k2]));
+                        }
+                        emit(q, score);
+                    }
+                }
+            } else {
+                // rare: too many hits in the tile or more than BS_NM distinct batch terms in this doc.
+                // Exact per-query evaluation straight from the doc's tokens.
+                const uint32_t *dt = terms + t0 + s.off[tid];
+                for (uint32_t q = 0; q < nq; ++q) {
+                    float score = 0.0f;
+                    for (uint32_t p = s.q_off[q]; p < s.q_off[q + 1]; ++p) {
+                        const uint32_t sl = s.q_slot[p];
+                        if (sl == BS_NIL) continue;
+                        const uint32_t t = s.key[sl];
+                        uint32_t tf = 0;
+                        for (uint32_t i = 0; i < dlen; ++i) tf += dt[i] == t;
+                        if (tf == 0) continue;
+                        const float ftf = (float)tf;
+                        const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                        score = __fadd_rn(score, __fmul_rn(s.idf[sl], im));
+                    }
+                    emit(q, score);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < nq; q += BS_THREADS) {
+        const uint32_t c = s.seg_fill[q];
+        seg_cnt[(uint64_t)(q_begin + q) * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
+// ------------------------------------------------------------------ host
+void oi_bm25_scan_geometry(const oi_ctx *ctx, uint64_t n_docs, uint32_t *n_segs, uint32_t *seg_cap) {
+    const uint64_t n_tiles = (n_docs + BS_DPT - 1) / BS_DPT;
+    uint64_t grid = 2ull * (uint64_t)ctx->num_cus; // two 512-thread workgroups per CU
+    if (grid > n_tiles) grid = n_tiles;
+    if (grid == 0) grid = 1;
+    *n_segs = (uint32_t)grid;
+    *seg_cap = (uint32_t)(((n_tiles + grid - 1) / grid) * BS_DPT);
+}
+
+uint32_t oi_bm25_scan_max_queries() { return BS_MAX_Q; }
+
+// One pass: queries [q_begin, q_begin + nq) of the batch over docs [doc_begin, doc_end).
+// pool.n_segs / pool.seg_cap must come from oi_bm25_scan_geometry(doc_end - doc_begin).
+uint32_t oi_bm25_scan_pass_queries(uint32_t max_terms_per_query) {
+    uint32_t m = max_terms_per_query ? max_terms_per_query : 1;
+    uint32_t p = BS_MAX_TERMS / m; // pairs per pass <= BS_MAX_TERMS, hence distinct terms too
+    if (p > BS_MAX_Q) p = BS_MAX_Q;
+    return p ? p : 1;
+}
+
+int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
+                        uint32_t nq, uint64_t doc_begin, uint64_t doc_end, float avgdl, bool run_setup,
+                        const PoolView &pool) {
+    oi_ctx *ctx = idx->ctx;
+    if (nq == 0 || doc_end <= doc_begin) return OI_OK;
+    OI_REQUIRE(nq <= BS_MAX_Q, "bm25 scan: %u queries in one pass (limit %u)", nq, BS_MAX_Q);
+    DevBuf &bb = ctx->buf("bm25_scan_batch");
+    OI_CHECK(bb.ensure(sizeof(BsBatch)));
+    static bool attr = false;
+    if (!attr) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BsShared)));
+        attr = true;
+    }
+    if (run_setup) {
+        hipLaunchKernelGGL(bm25_scan_setup, dim3(1), dim3(1024), 0, ctx->stream, d_q_terms, d_q_offsets, q_begin, nq,
+                           idx->vocab, idx->max_query_terms, idx->idf.as<float>(), bb.as<BsBatch>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    ProfScope ps(ctx, "bm25");
+    hipLaunchKernelGGL(bm25_scan_kernel, dim3(pool.n_segs), dim3(BS_THREADS), sizeof(BsShared), ctx->stream,
+                       idx->fwd_terms.as<uint32_t>(), idx->fwd_offsets.as<uint64_t>(), doc_begin, doc_end, avgdl,
+                       bb.as<BsBatch>(), pool.tau_keys, q_begin, idx->doc_id_base, pool.keys, pool.seg_cnt,
+                       pool.seg_cnt_stride, pool.stride, pool.carry_cap, pool.seg_cap, pool.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

@@ -110,6 +110,11 @@ struct oi_index {
     DevBuf postings;   // {u32 doc_in_block, f32 impact} per unique key, (block, term, doc) order
     DevBuf cell_start; // u32 [n_blocks * vocab + 1]
     DevBuf idf;        // f32 per term
+    // forward index kept for the batch scan (bm25_scan.hip)
+    DevBuf fwd_terms;   // u32 per token
+    DevBuf fwd_offsets; // u64 per doc + 1
+    float avgdl = 0.f;  // global average doc length fixed at finalize
+    uint32_t max_query_terms = 16; // contract for the batch-scan path (oi_index_set_max_query_terms)
 };
 
 // ---------------------------------------------------------------- kernels (host launchers)
@@ -164,6 +169,12 @@ int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, 
 // bm25.hip
 int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets);
 int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, const uint32_t *global_df_host);
+// bm25_scan.hip
+void oi_bm25_scan_geometry(const oi_ctx *ctx, uint64_t n_docs, uint32_t *n_segs, uint32_t *seg_cap);
+uint32_t oi_bm25_scan_pass_queries(uint32_t max_terms_per_query);
+int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
+                        uint32_t nq, uint64_t doc_begin, uint64_t doc_end, float avgdl, bool run_setup,
+                        const PoolView &pool);
 // Doc blocks [block_begin, block_end); candidates below pool.tau_keys (if set) are dropped.
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
                    uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,

@@ -118,6 +118,10 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
 
+    def set_max_query_terms(self, max_terms: int) -> None:
+        """Contract for the batch BM25 scan: no query has more terms than this (default 16)."""
+        _lib.check(self.lib.oi_index_set_max_query_terms(self.handle, int(max_terms)))
+
     def local_stats(self) -> Tuple[int, np.ndarray]:
         tot = C.c_uint64()
         df = np.zeros(self.vocab, dtype=np.uint32)

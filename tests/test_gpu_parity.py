@@ -273,6 +273,45 @@ def test_bm25_edge_cases(ctx, O):
     idx.close()
 
 
+@pytest.mark.parametrize("n,vocab,B,max_terms,depth", [
+    (70_000, 40, 33, 8, 100),     # heavy terms: most docs match several batch terms (> 6 distinct -> exact slow path)
+    (70_000, 5000, 70, 8, 1000),  # sparse terms, two passes of the batch (1024/8 = 128 ... B=70 fits one; see next)
+    (20_000, 300, 40, 64, 50),    # max_terms 64 -> 16 queries per pass -> three passes
+    (600_000, 2000, 24, 6, 100),  # several doc chunks with thresholds
+])
+def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
+    """Batches of >= 16 queries take the forward-index scan (bm25_scan.hip); same bits as the oracle.
+    Queries have 0..max_terms terms, with repeats and out-of-vocabulary ids."""
+    import openintel_amd as oi
+    rng = np.random.default_rng(n + B)
+    rows = rng.integers(-2, 3, size=(n, 8)).astype(np.float32)
+    terms, offs = _small_forward(rng, n, vocab, max_len=14)
+    idx = oi.HybridIndex(ctx, n, 8, vocab, doc_id_base=77)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    idx.set_max_query_terms(max_terms)
+    queries = []
+    for b in range(B):
+        k = int(rng.integers(0, min(max_terms, 8) + 1))
+        t = rng.integers(0, min(vocab, 40), size=k).tolist()
+        if k >= 2 and b % 3 == 0:
+            t[1] = t[0]                    # repeated term counts twice
+        if k >= 1 and b % 5 == 0:
+            t[-1] = vocab + 3              # outside the vocabulary: contributes nothing
+        queries.append(t)
+    qt, qo = oi.pack_query_terms(queries)
+    q = rng.integers(-2, 3, size=(B, 8)).astype(np.float32)
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    for b, tb in enumerate(queries):
+        tv = np.array([t for t in tb if t < vocab], np.uint32)
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, 77)
+        assert int(L.bm25_counts[b]) == bd.size, (b, tb)
+        assert np.array_equal(L.bm25_docs[b][:bd.size], bd), (b, tb)
+        assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), (b, tb)
+    idx.close()
+
+
 def test_merge_and_rrf_kernels_bit_exact(ctx, O):
     from openintel_amd import merge_lists, rrf_fuse
     rng = np.random.default_rng(2)
