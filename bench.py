@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--depth", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=131072)
+    ap.add_argument("--bm25", choices=["taat", "scan"], default="taat", help="BM25 kernel (default: term-at-a-time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -108,6 +109,8 @@ def main():
     idx = oi.HybridIndex(ctx, n_local, args.dim, args.vocab, doc_id_base=lo)
     idx.set_embeddings(rows, normalize=False)          # rows are generated unit-norm
     idx.set_forward(terms, offs)
+    idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
+    idx.set_bm25_mode(idx.BM25_SCAN if args.bm25 == "scan" else idx.BM25_TAAT)
     n_tokens_local = int(offs[-1].item())
     del terms, offs
     torch.cuda.empty_cache()

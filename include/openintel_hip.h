@@ -137,7 +137,11 @@ int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df
 int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                       const uint32_t *global_df_host);
 
-/* Contract for the batch BM25 scan (used for batches of >= 16 queries): no query of a batch has more
+/* BM25 kernel choice: 0 = default (term-at-a-time over the blocked inverted index), 1 = term-at-a-time,
+ * 2 = batch scan of the forward index (bm25_scan.hip).  All produce bit-identical lists. */
+int oi_index_set_bm25_mode(oi_index *idx, int mode);
+
+/* Contract for the batch BM25 scan (mode 2): no query of a batch has more
  * than `max_terms` terms (default 16).  The scan handles 1024 / max_terms queries per pass over the
  * forward index; a longer query sets the ctx's error flag (OI_ERR_OVERFLOW at the next host-visible
  * point).  The term-at-a-time path (smaller batches, or OI_BM25_MODE=taat) has no such limit. */

@@ -25,7 +25,7 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result",
     "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-]
+] + ([x for x in os.environ.get("OI_EXTRA_HIPCC_FLAGS", "").split() if x])
 
 
 def sources():

@@ -15,10 +15,10 @@
 //            (~5 % of tokens) finds its doc by binary search in the tile's LDS-staged offsets and is
 //            pushed on that doc's LDS linked list (wave-aggregated slot allocation, atomicExch on the
 //            list head).
-//   phase 2  lane-per-doc over the tile's 512 docs: walk the list -> (term slot, tf) pairs (<= 6 distinct
-//            in registers), impacts from the doc length, then for every query that uses a matched term
-//            the f32 sum over its terms IN QUERY ORDER; survivors of the per-query threshold go to the
-//            workgroup's private pool segment (LDS fill counters, no global atomics).
+//   phase 2  lane-per-hit: walk the hit's doc list; every query that uses a matched term is scored
+//            exactly once (f32 sum over its terms IN QUERY ORDER, tf counted
+//            from the list, impact from the doc length); survivors of the per-query threshold go to
+//            the workgroup's private pool segment (LDS fill counters, no global atomics).
 #include <cstdlib>
 
 #include "oi_device.h"
@@ -31,8 +31,7 @@
 #define BS_MAX_TERMS 1024   // distinct batch terms (load factor <= 50 %)
 #define BS_MAX_Q 256        // queries per pass
 #define BS_MAX_QT 2048      // total (query, term) pairs per pass
-#define BS_HITCAP 8192      // hit entries per tile
-#define BS_NM 6             // distinct matched terms per doc kept in registers
+#define BS_HITCAP 4096      // hit entries per tile (typ. ~650); beyond: exact per-doc fallback
 #define BS_NIL 0xFFFFu
 #define BS_K1 1.2f
 #define BS_B 0.75f
@@ -132,6 +131,7 @@ struct BsShared {
     uint32_t off[BS_DPT + 1];      // token offsets of the tile's docs, relative to the tile's first token
     uint32_t head[BS_DPT];         // per-doc list head (entry index) or BS_NIL
     uint32_t hit[BS_HITCAP];       // slot (low 16) | next entry (high 16)
+    uint16_t hit_doc[BS_HITCAP];   // doc (index in the tile) of each hit
     uint32_t hit_cnt, overflow_tile;
 };
 
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
         }
         __syncthreads();
         const uint32_t n_tok = s.off[nd];
+        if (n_tok >= (1u << 21) && tid == 0) s.overflow_tile = 1; // token index would not fit a hit entry
 
         // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.
         const uint32_t headpad = (uint32_t)(t0 & 3u); // tokens before t0 in the first aligned group
@@ -199,130 +200,129 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                     tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
                 }
             }
+            // probe all 8 tokens first (independent LDS reads), then allocate hit entries per token
+            // position with one LDS atomic per wave; an entry temporarily holds (slot, token index)
+            uint32_t hslot[BS_TPT];
+            uint32_t hmask = 0;
 #pragma unroll
             for (int i = 0; i < BS_TPT; ++i) {
                 const int64_t r = rel0 + i;
                 const uint32_t t = tk[i];
-                bool hit = false;
-                uint32_t slot = 0;
+                hslot[i] = 0;
                 if (r >= 0 && r < (int64_t)n_tok) {
                     uint32_t h = bs_hash(t);
                     for (;;) {
                         const uint32_t k = s.key[h];
-                        if (k == t) { hit = true; slot = h; break; }
+                        if (k == t) { hmask |= 1u << i; hslot[i] = h; break; }
                         if (k == 0xFFFFFFFFu) break;
                         h = (h + 1) & (BS_HASH - 1);
                     }
                 }
-                const uint32_t e = bs_wave_slot(hit, &s.hit_cnt);
-                if (hit) {
-                    if (e < BS_HITCAP) {
-                        // doc of token r: largest d with off[d] <= r
-                        uint32_t lo = 0, hi = nd;
-                        while (hi - lo > 1) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            if (s.off[mid] <= (uint32_t)r) lo = mid; else hi = mid;
-                        }
-                        const uint32_t prev = atomicExch(&s.head[lo], e);
-                        s.hit[e] = slot | (prev << 16);
-                    } else {
-                        s.overflow_tile = 1;
+            }
+            if (__ballot(hmask != 0)) {
+#pragma unroll
+                for (int i = 0; i < BS_TPT; ++i) {
+                    const bool hit = (hmask >> i) & 1u;
+                    const uint32_t e = bs_wave_slot(hit, &s.hit_cnt);
+                    if (hit) {
+                        if (e < BS_HITCAP) s.hit[e] = hslot[i] | ((uint32_t)(rel0 + i) << 11); // slot < 2^11, index < 2^21
+                        else s.overflow_tile = 1;
                     }
                 }
             }
         }
         __syncthreads();
-
-        // ---- phase 2: one lane per doc
-        if (tid < nd) {
-            const uint32_t dlen = s.off[tid + 1] - s.off[tid];
-            uint32_t ms[BS_NM], mt[BS_NM];
-            uint32_t nm = 0;
-            bool slow = s.overflow_tile != 0;
-#pragma unroll
-            for (int k = 0; k < BS_NM; ++k) { ms[k] = 0xFFFFFFFFu; mt[k] = 0; }
-            if (!slow) {
-                for (uint32_t h = s.head[tid]; h != BS_NIL;) {
-                    const uint32_t ent = s.hit[h];
-                    const uint32_t sl = ent & 0xFFFFu;
-                    h = ent >> 16;
-                    bool found = false;
-#pragma unroll
-                    for (int k = 0; k < BS_NM; ++k)
-                        if (ms[k] == sl) { ++mt[k]; found = true; }
-                    if (!found) {
-                        if (nm < BS_NM) {
-#pragma unroll
-                            for (int k = 0; k < BS_NM; ++k)
-                                if ((uint32_t)k == nm) { ms[k] = sl; mt[k] = 1; }
-                            ++nm;
-                        } else {
-                            slow = true;
-                        }
-                    }
+        // ---- link pass: every hit finds its doc (binary search in the tile's offsets) and pushes itself
+        // on that doc's list; one hit per lane, no divergence between hit and miss lanes
+        {
+            const uint32_t nh = s.hit_cnt < BS_HITCAP ? s.hit_cnt : BS_HITCAP;
+            for (uint32_t e = tid; e < nh; e += BS_THREADS) {
+                const uint32_t ent = s.hit[e];
+                const uint32_t r = ent >> 11;
+                uint32_t lo = 0, hi = nd; // largest d with off[d] <= r
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (s.off[mid] <= r) lo = mid; else hi = mid;
                 }
+                const uint32_t prev = atomicExch(&s.head[lo], e);
+                s.hit[e] = (ent & 0x7FFu) | (prev << 16);
+                s.hit_doc[e] = (uint16_t)lo;
             }
-            const float ratio = __fdiv_rn((float)dlen, avgdl);
-            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
-            const uint32_t doc = doc_id_base + (uint32_t)(d0 + tid);
-            auto emit = [&](uint32_t q, float score) {
-                if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
-                    const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
-                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc);
-                    else *overflow = 1u;
-                }
-            };
-            if (!slow) {
-                float imp[BS_NM];
-#pragma unroll
-                for (int k = 0; k < BS_NM; ++k) {
-                    const float ftf = (float)mt[k];
-                    imp[k] = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
-                }
-#pragma unroll
-                for (int k = 0; k < BS_NM; ++k) {
-                    if ((uint32_t)k >= nm) continue;
-                    const uint32_t ub = s.users_off[ms[k]], ue = s.users_off[ms[k] + 1];
-                    for (uint32_t u = ub; u < ue; ++u) {
-                        const uint32_t q = s.users[u] >> 16, pos_in_q = s.users[u] & 0xFFFFu;
-                        const uint32_t qb = s.q_off[q], qe = s.q_off[q + 1];
-                        // handle q exactly once per doc: at its FIRST term position whose slot matched
-                        bool first = true;
-                        for (uint32_t p = qb; p < qb + pos_in_q; ++p) {
-                            const uint32_t sl = s.q_slot[p];
-#pragma unroll
-                            for (int k2 = 0; k2 < BS_NM; ++k2)
-                                if (ms[k2] == sl && sl != BS_NIL) first = false;
-                        }
-                        if (!first) continue;
-                        float score = 0.0f;
-                        for (uint32_t p = qb; p < qe; ++p) {
-                            const uint32_t sl = s.q_slot[p];
-#pragma unroll
-                            for (int k2 = 0; k2 < BS_NM; ++k2)
-                                if (ms[k2] == sl && sl != BS_NIL) score = __fadd_rn(score, __fmul_rn(s.idf[sl], imp[k2]));
-                        }
-                        emit(q, score);
+        }
+        __syncthreads();
+
+        // ---- phase 2: one lane per HIT (balanced: a long doc's hits spread over many lanes).  A doc's
+        // hits form a short LDS linked list; for every query using the hit's term, the hit that comes
+        // first in the list among all hits carrying one of that query's terms scores the (doc, query)
+        // pair -- exactly once -- as the f32 sum over the query's terms IN QUERY ORDER, tf counted by
+        // walking the list, impact from the doc length.
+        if (s.overflow_tile == 0) {
+            const uint32_t nh = s.hit_cnt;
+            for (uint32_t e = tid; e < nh; e += BS_THREADS) {
+                const uint32_t sl = s.hit[e] & 0xFFFFu;
+                const uint32_t d = s.hit_doc[e];
+                const uint32_t list_head = s.head[d];
+                const uint32_t ub = s.users_off[sl], ue = s.users_off[sl + 1];
+                float kd = 0.f;
+                bool have_kd = false;
+                for (uint32_t u = ub; u < ue; ++u) {
+                    const uint32_t q = s.users[u] >> 16, pos_in_q = s.users[u] & 0xFFFFu;
+                    const uint32_t qb = s.q_off[q], qe = s.q_off[q + 1];
+                    bool mine = true;
+                    for (uint32_t p = qb; p < qb + pos_in_q; ++p) mine = mine && s.q_slot[p] != sl;
+                    for (uint32_t h2 = list_head; mine && h2 != e; h2 = s.hit[h2] >> 16) {
+                        const uint32_t sl2 = s.hit[h2] & 0xFFFFu;
+                        for (uint32_t p = qb; p < qe; ++p) mine = mine && s.q_slot[p] != sl2;
                     }
-                }
-            } else {
-                // rare: too many hits in the tile or more than BS_NM distinct batch terms in this doc.
-                // Exact per-query evaluation straight from the doc's tokens.
-                const uint32_t *dt = terms + t0 + s.off[tid];
-                for (uint32_t q = 0; q < nq; ++q) {
+                    if (!mine) continue;
+                    if (!have_kd) {
+                        const uint32_t dlen = s.off[d + 1] - s.off[d];
+                        const float ratio = __fdiv_rn((float)dlen, avgdl);
+                        kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
+                        have_kd = true;
+                    }
                     float score = 0.0f;
-                    for (uint32_t p = s.q_off[q]; p < s.q_off[q + 1]; ++p) {
-                        const uint32_t sl = s.q_slot[p];
-                        if (sl == BS_NIL) continue;
-                        const uint32_t t = s.key[sl];
+                    for (uint32_t p = qb; p < qe; ++p) { // q's terms in query order
+                        const uint32_t slp = s.q_slot[p];
+                        if (slp == BS_NIL) continue;
                         uint32_t tf = 0;
-                        for (uint32_t i = 0; i < dlen; ++i) tf += dt[i] == t;
+                        for (uint32_t h = list_head; h != BS_NIL; h = s.hit[h] >> 16) tf += (s.hit[h] & 0xFFFFu) == slp;
                         if (tf == 0) continue;
                         const float ftf = (float)tf;
                         const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
-                        score = __fadd_rn(score, __fmul_rn(s.idf[sl], im));
+                        score = __fadd_rn(score, __fmul_rn(s.idf[slp], im));
                     }
-                    emit(q, score);
+                    if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
+                        const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
+                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + d));
+                        else *overflow = 1u;
+                    }
+                }
+            }
+        } else if (tid < nd) {
+            // the tile produced more than BS_HITCAP hits (a batch whose terms cover a large share of the
+            // text) or is too long: exact per-query evaluation straight from each doc's tokens
+            const uint32_t dlen = s.off[tid + 1] - s.off[tid];
+            const float ratio = __fdiv_rn((float)dlen, avgdl);
+            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
+            const uint32_t *dt = terms + t0 + s.off[tid];
+            for (uint32_t q = 0; q < nq; ++q) {
+                float score = 0.0f;
+                for (uint32_t p = s.q_off[q]; p < s.q_off[q + 1]; ++p) {
+                    const uint32_t sl = s.q_slot[p];
+                    if (sl == BS_NIL) continue;
+                    const uint32_t t = s.key[sl];
+                    uint32_t tf = 0;
+                    for (uint32_t i = 0; i < dlen; ++i) tf += dt[i] == t;
+                    if (tf == 0) continue;
+                    const float ftf = (float)tf;
+                    const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                    score = __fadd_rn(score, __fmul_rn(s.idf[sl], im));
+                }
+                if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
+                    const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
+                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + tid));
+                    else *overflow = 1u;
                 }
             }
         }

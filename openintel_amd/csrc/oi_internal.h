@@ -115,6 +115,7 @@ struct oi_index {
     DevBuf fwd_offsets; // u64 per doc + 1
     float avgdl = 0.f;  // global average doc length fixed at finalize
     uint32_t max_query_terms = 16; // contract for the batch-scan path (oi_index_set_max_query_terms)
+    int bm25_mode = 0;             // 0 default (term-at-a-time unless OI_BM25_MODE=scan), 1 term-at-a-time, 2 scan
 };
 
 // ---------------------------------------------------------------- kernels (host launchers)

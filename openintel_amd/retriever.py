@@ -118,6 +118,12 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
 
+    BM25_DEFAULT, BM25_TAAT, BM25_SCAN = 0, 1, 2
+
+    def set_bm25_mode(self, mode: int) -> None:
+        """BM25_TAAT (term-at-a-time, the default) or BM25_SCAN (batch scan of the forward index)."""
+        _lib.check(self.lib.oi_index_set_bm25_mode(self.handle, int(mode)))
+
     def set_max_query_terms(self, max_terms: int) -> None:
         """Contract for the batch BM25 scan: no query has more terms than this (default 16)."""
         _lib.check(self.lib.oi_index_set_max_query_terms(self.handle, int(max_terms)))

@@ -280,7 +280,7 @@ def test_bm25_edge_cases(ctx, O):
     (600_000, 2000, 24, 6, 100),  # several doc chunks with thresholds
 ])
 def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
-    """Batches of >= 16 queries take the forward-index scan (bm25_scan.hip); same bits as the oracle.
+    """The forward-index scan (bm25_scan.hip, selected per index); same bits as the oracle and the TAAT kernel.
     Queries have 0..max_terms terms, with repeats and out-of-vocabulary ids."""
     import openintel_amd as oi
     rng = np.random.default_rng(n + B)
@@ -291,6 +291,7 @@ def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
     idx.set_forward(terms, offs)
     idx.finalize()
     idx.set_max_query_terms(max_terms)
+    idx.set_bm25_mode(idx.BM25_SCAN)
     queries = []
     for b in range(B):
         k = int(rng.integers(0, min(max_terms, 8) + 1))
@@ -303,6 +304,9 @@ def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
     qt, qo = oi.pack_query_terms(queries)
     q = rng.integers(-2, 3, size=(B, 8)).astype(np.float32)
     L = idx.search_lists(q, qt, qo, depth=depth)
+    idx.set_bm25_mode(idx.BM25_TAAT)
+    L2 = idx.search_lists(q, qt, qo, depth=depth)
+    assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
     for b, tb in enumerate(queries):
         tv = np.array([t for t in tb if t < vocab], np.uint32)
         bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, 77)
