@@ -11,10 +11,11 @@
 // Algorithmic bytes per batch: 4*T + 8*N (tokens + doc offsets); HBM-bound by construction.
 //
 //   phase 1  token-parallel: every lane loads 8 consecutive tokens (two 16-byte loads, fully
-//            coalesced), probes each in an LDS hash table of the batch's terms (2048 slots); a hit
-//            (~5 % of tokens) finds its doc by binary search in the tile's LDS-staged offsets and is
-//            pushed on that doc's LDS linked list (wave-aggregated slot allocation, atomicExch on the
-//            list head).
+//            coalesced) and tests each against a 4 KiB Bloom filter of the batch's terms in LDS (one
+//            LDS read per token); the ~5 % that pass are compacted per wave into the tile's hit array.
+//   link     one lane per hit: exact term -> slot lookup in the LDS hash table (2048 slots; Bloom false
+//            positives die here), the doc by binary search in the tile's LDS-staged offsets, and a push
+//            on that doc's LDS linked list (atomicExch on the list head).
 //   phase 2  lane-per-hit: walk the hit's doc list; every query that uses a matched term is scored
 //            exactly once (f32 sum over its terms IN QUERY ORDER, tf counted
 //            from the list, impact from the doc length); survivors of the per-query threshold go to
@@ -32,6 +33,7 @@
 #define BS_MAX_Q 256        // queries per pass
 #define BS_MAX_QT 2048      // total (query, term) pairs per pass
 #define BS_HITCAP 4096      // hit entries per tile (typ. ~650); beyond: exact per-doc fallback
+#define BS_BLOOM_WORDS 1024  // 4 KiB: <= 1024 keys in 32768 bits -> < 3 % false positives
 #define BS_NIL 0xFFFFu
 #define BS_K1 1.2f
 #define BS_B 0.75f
@@ -43,8 +45,10 @@ struct BsBatch { // built once per batch by bm25_scan_setup (global memory, ~40 
     uint32_t users[BS_MAX_QT];      // query << 16 | position
     uint32_t q_off[BS_MAX_Q + 1];   // CSR over queries: their terms' slots in query order
     uint32_t q_slot[BS_MAX_QT];     // slot or 0xFFFF (term outside the vocabulary: contributes nothing)
+    uint32_t bloom[BS_BLOOM_WORDS]; // 32768-bit filter over the batch's term ids (1 hash)
     uint32_t n_queries, n_pairs, error, pad;
 };
+__device__ __forceinline__ uint32_t bs_bloom_bit(uint32_t t) { return (t * 0x85EBCA77u) >> 17; } // 15 bits
 
 __device__ __forceinline__ uint32_t bs_hash(uint32_t t) { return (t * 0x9E3779B1u) >> 21; } // 11 bits
 
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
     const uint32_t base = q_offsets[q_begin];
     const uint32_t n_pairs = q_offsets[q_begin + n_queries] - base;
     for (uint32_t i = tid; i < BS_HASH; i += 1024) { out->key[i] = 0xFFFFFFFFu; out->idf[i] = 0.f; cnt[i] = 0; }
+    for (uint32_t i = tid; i < BS_BLOOM_WORDS; i += 1024) out->bloom[i] = 0;
     if (tid == 0) { n_distinct = 0; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
     for (uint32_t q = tid; q <= n_queries; q += 1024) out->q_off[q] = q_offsets[q_begin + q] - base;
     __syncthreads();
@@ -80,7 +85,14 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
             uint32_t h = bs_hash(t);
             for (;;) {
                 const uint32_t prev = atomicCAS(&out->key[h], 0xFFFFFFFFu, t);
-                if (prev == 0xFFFFFFFFu) { atomicAdd(&n_distinct, 1u); out->idf[h] = idf[t]; slot = h; break; }
+                if (prev == 0xFFFFFFFFu) {
+                    atomicAdd(&n_distinct, 1u);
+                    out->idf[h] = idf[t];
+                    const uint32_t bb = bs_bloom_bit(t);
+                    atomicOr(&out->bloom[bb >> 5], 1u << (bb & 31u));
+                    slot = h;
+                    break;
+                }
                 if (prev == t) { slot = h; break; }
                 h = (h + 1) & (BS_HASH - 1);
             }
@@ -130,6 +142,7 @@ struct BsShared {
     uint32_t seg_fill[BS_MAX_Q];
     uint32_t off[BS_DPT + 1];      // token offsets of the tile's docs, relative to the tile's first token
     uint32_t head[BS_DPT];         // per-doc list head (entry index) or BS_NIL
+    uint32_t bloom[BS_BLOOM_WORDS];
     uint32_t hit[BS_HITCAP];       // slot (low 16) | next entry (high 16)
     uint16_t hit_doc[BS_HITCAP];   // doc (index in the tile) of each hit
     uint32_t hit_cnt, overflow_tile;
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
     // ---- batch tables -> LDS (once per workgroup)
     for (uint32_t i = tid; i < BS_HASH; i += BS_THREADS) { s.key[i] = batch->key[i]; s.idf[i] = batch->idf[i]; s.users_off[i] = batch->users_off[i]; }
     if (tid == 0) s.users_off[BS_HASH] = batch->users_off[BS_HASH];
+    for (uint32_t i = tid; i < BS_BLOOM_WORDS; i += BS_THREADS) s.bloom[i] = batch->bloom[i];
     for (uint32_t i = tid; i < batch->n_pairs; i += BS_THREADS) { s.users[i] = batch->users[i]; s.q_slot[i] = batch->q_slot[i]; }
     for (uint32_t i = tid; i <= nq; i += BS_THREADS) s.q_off[i] = batch->q_off[i];
     for (uint32_t i = tid; i < nq; i += BS_THREADS) { s.tau[i] = tau_keys ? tau_keys[q_begin + i] : 0u; s.seg_fill[i] = 0; }
@@ -200,34 +214,35 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                     tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
                 }
             }
-            // probe all 8 tokens first (independent LDS reads), then allocate hit entries per token
-            // position with one LDS atomic per wave; an entry temporarily holds (slot, token index)
-            uint32_t hslot[BS_TPT];
+            // phase 1 proper: ONE LDS read per token (Bloom bit of its term id); ~4.5 % pass.  The
+            // passing tokens' indices are compacted per wave (popcount + wave prefix, one LDS atomic per
+            // wave and step); everything else about a hit is resolved in the link pass below.
             uint32_t hmask = 0;
 #pragma unroll
             for (int i = 0; i < BS_TPT; ++i) {
                 const int64_t r = rel0 + i;
-                const uint32_t t = tk[i];
-                hslot[i] = 0;
-                if (r >= 0 && r < (int64_t)n_tok) {
-                    uint32_t h = bs_hash(t);
-                    for (;;) {
-                        const uint32_t k = s.key[h];
-                        if (k == t) { hmask |= 1u << i; hslot[i] = h; break; }
-                        if (k == 0xFFFFFFFFu) break;
-                        h = (h + 1) & (BS_HASH - 1);
-                    }
-                }
+                const uint32_t bb = bs_bloom_bit(tk[i]);
+                const uint32_t wbits = s.bloom[bb >> 5];
+                if (r >= 0 && r < (int64_t)n_tok && ((wbits >> (bb & 31u)) & 1u)) hmask |= 1u << i;
             }
             if (__ballot(hmask != 0)) {
+                const uint32_t cnt = __builtin_popcount(hmask);
+                uint32_t incl = cnt;
 #pragma unroll
-                for (int i = 0; i < BS_TPT; ++i) {
-                    const bool hit = (hmask >> i) & 1u;
-                    const uint32_t e = bs_wave_slot(hit, &s.hit_cnt);
-                    if (hit) {
-                        if (e < BS_HITCAP) s.hit[e] = hslot[i] | ((uint32_t)(rel0 + i) << 11); // slot < 2^11, index < 2^21
-                        else s.overflow_tile = 1;
-                    }
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o, OI_WAVE);
+                    if ((int)lane >= o) incl += v;
+                }
+                const uint32_t total = __shfl(incl, 63, OI_WAVE);
+                uint32_t base = 0;
+                if (lane == 63) base = atomicAdd(&s.hit_cnt, total);
+                base = __shfl(base, 63, OI_WAVE) + incl - cnt;
+                while (hmask) {
+                    const uint32_t i = __builtin_ctz(hmask);
+                    hmask &= hmask - 1;
+                    if (base < BS_HITCAP) s.hit[base] = (uint32_t)(rel0 + i); // pending: the token's index
+                    else s.overflow_tile = 1;
+                    ++base;
                 }
             }
         }
@@ -237,8 +252,20 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
         {
             const uint32_t nh = s.hit_cnt < BS_HITCAP ? s.hit_cnt : BS_HITCAP;
             for (uint32_t e = tid; e < nh; e += BS_THREADS) {
-                const uint32_t ent = s.hit[e];
-                const uint32_t r = ent >> 11;
+                const uint32_t r = s.hit[e];
+                const uint32_t t = terms[t0 + r]; // just streamed: an L2 hit
+                uint32_t slot = BS_NIL;
+                for (uint32_t h = bs_hash(t);; h = (h + 1) & (BS_HASH - 1)) {
+                    const uint32_t k = s.key[h];
+                    if (k == t) { slot = h; break; }
+                    if (k == 0xFFFFFFFFu) break;
+                }
+                if (slot == BS_NIL) { // Bloom false positive: a dead entry, never linked
+                    s.hit[e] = BS_NIL | (BS_NIL << 16);
+                    s.hit_doc[e] = (uint16_t)BS_NIL;
+                    continue;
+                }
+                const uint32_t ent = slot;
                 uint32_t lo = 0, hi = nd; // largest d with off[d] <= r
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
@@ -261,6 +288,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
             for (uint32_t e = tid; e < nh; e += BS_THREADS) {
                 const uint32_t sl = s.hit[e] & 0xFFFFu;
                 const uint32_t d = s.hit_doc[e];
+                if (d == BS_NIL) continue; // Bloom false positive
                 const uint32_t list_head = s.head[d];
                 const uint32_t ub = s.users_off[sl], ue = s.users_off[sl + 1];
                 float kd = 0.f;
