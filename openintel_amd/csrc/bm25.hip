@@ -55,15 +55,37 @@ __global__ void bm_make_keys_kernel(const uint32_t *terms, const uint64_t *offse
     }
 }
 
-__global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t vocab, uint32_t *df,
-                                uint32_t *cell_count) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t k = uniq[i];
-        const uint32_t term = (uint32_t)(k >> BM_R_LOG2);
-        const uint64_t block = k >> 47;
-        atomicAdd(&df[term], 1u);
-        atomicAdd(&cell_count[block * vocab + term], 1u);
+// (block, term) cell histogram of the sorted unique keys.  Entries of one cell are consecutive, so a
+// wave first folds its lanes' runs (ballot of run heads) and issues ONE atomic per run and wave: the
+// per-entry version serialised millions of adds on the cells of frequent terms (670 ms at 10M docs).
+__global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t vocab, uint32_t *cell_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(uint64_t)63; i0 < n;
+         i0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = i0 + lane;
+        const bool valid = i < n;
+        const uint64_t cell_key = valid ? (uniq[i] >> BM_R_LOG2) : ~0ull; // block << 32 | term
+        const uint64_t prev = __shfl_up(cell_key, 1, OI_WAVE);
+        const bool head = valid && (lane == 0 || prev != cell_key);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long valids = __ballot(valid);
+        if (head) {
+            // run = lanes [lane, next head or first invalid lane)
+            const unsigned long long above = lane == 63 ? 0ull : ((heads | ~valids) >> (lane + 1));
+            const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+            const uint64_t block = cell_key >> 32;
+            const uint32_t term = (uint32_t)cell_key;
+            atomicAdd(&cell_count[block * vocab + term], run);
+        }
+    }
+}
+
+// df[t] = sum over blocks of the cell histogram (before it is scanned): no atomics, coalesced over terms
+__global__ void bm_df_kernel(const uint32_t *cell_count, uint32_t n_blocks, uint32_t vocab, uint32_t *df) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < vocab; t += gridDim.x * blockDim.x) {
+        uint32_t s = 0;
+        for (uint32_t b = 0; b < n_blocks; ++b) s += cell_count[(uint64_t)b * vocab + t];
+        df[t] = s;
     }
 }
 
@@ -159,8 +181,10 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
         uint64_t blocks = (idx->n_postings + 255) / 256;
         if (blocks > 65535) blocks = 65535;
         hipLaunchKernelGGL(bm_count_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),
-                           idx->n_postings, idx->vocab, idx->df_local.as<uint32_t>(),
-                           idx->cell_start.as<uint32_t>());
+                           idx->n_postings, idx->vocab, idx->cell_start.as<uint32_t>());
+        OI_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(bm_df_kernel, dim3((idx->vocab + 255) / 256), dim3(256), 0, st,
+                           idx->cell_start.as<uint32_t>(), idx->n_blocks, idx->vocab, idx->df_local.as<uint32_t>());
         OI_HIP_CHECK(hipGetLastError());
     }
     // exclusive scan in place -> cell_start[c] = first posting of cell c; last entry = n_postings
