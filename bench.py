@@ -186,7 +186,8 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # the committed PMC pass was taken on the default workload at N=1 only
+        if os.path.exists(pmc) and (args.docs, args.dim, args.batch, world) == (10_000_000, 768, 64, 1):
             try:
                 roof["traffic"] = json.load(open(pmc)).get("cosine_hbm_bytes_per_launch")
             except Exception:
