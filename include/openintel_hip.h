@@ -14,6 +14,8 @@
  *                               (called at src/application/analyze.rs:62-63)
  *   oi_social_summary*       <- SpeculationEngine::social_summary
  *                               src/domain/engine/speculation_engine.rs:70-125
+ *   oi_headline_scan*        <- catalyst_hits + headline_mentions_company over the dip
+ *                               gate's titles   src/domain/dip.rs:247-272 (loop at :617-626)
  *   oi_index_* / oi_search*  <- NO reference interface exists: the
  *   oi_rrf_fuse / oi_merge_lists  reference has no retrieval port.  New, builder-defined
  *                               API styled after the reference's ports (borrowed inputs,
@@ -110,6 +112,40 @@ typedef struct {
 int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts,
                       const double *polarity, const uint8_t *speculative, uint64_t n_signals,
                       double bull_bear_threshold, int location, oi_social_counters *out_host);
+
+/* ------------------------------------------------------------------------- */
+/* Headline gate (src/domain/dip.rs:204-272)                                   */
+/* ------------------------------------------------------------------------- */
+
+/* CATALYST_KEYWORDS (dip.rs:38-55) in declaration order; NULL past the end. */
+#define OI_N_CATALYST_KEYWORDS 16
+const char *oi_catalyst_keyword(uint32_t index);
+
+/*
+ * For each title i = blob[offsets[i] .. offsets[i+1]) (UTF-8, offsets[0] == 0):
+ *   mask_out[i]   bit k set iff keyword k occurs as a whole word        catalyst_hits(&[title])
+ *   order_out[i]  nibble j = keyword index of the j-th distinct hit,    (dip.rs:261-272; the
+ *                 first-occurrence order of the reference's Vec          multi-text call is the
+ *                                                                        deduped concatenation)
+ *   about_out[i]  headline_mentions_company(title, ticker, name_forms)  dip.rs:247-258
+ * ticker is the raw symbol (ticker_len bytes, compared ASCII-lowercased, ignored when
+ * shorter than 2 bytes -- dip.rs:250); form i is forms_blob[form_offsets[i] ..
+ * form_offsets[i+1]) exactly as company_name_forms returned it (n_forms may be 0; the
+ * caller keeps the reference's `name_forms.is_empty() ||` short-circuit, dip.rs:624).
+ * At most 32 usable patterns / 1024 pattern bytes per call -> OI_ERR_INVALID_ARG beyond.
+ */
+int oi_headline_scan(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n_titles,
+                     const uint8_t *ticker, uint64_t ticker_len, const uint8_t *forms_blob,
+                     const uint32_t *form_offsets, uint32_t n_forms, uint16_t *mask_out,
+                     uint64_t *order_out, uint8_t *about_out);
+
+/* Same, titles and outputs already in HBM (blob 16-byte aligned, each title < 4 GiB);
+ * ticker/forms stay host pointers.  Asynchronous on the ctx stream. */
+int oi_headline_scan_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets,
+                            uint64_t n_titles, uint64_t blob_bytes, const uint8_t *ticker,
+                            uint64_t ticker_len, const uint8_t *forms_blob,
+                            const uint32_t *form_offsets, uint32_t n_forms, uint16_t *d_mask_out,
+                            uint64_t *d_order_out, uint8_t *d_about_out);
 
 /* ------------------------------------------------------------------------- */
 /* Hybrid retrieval (builder-defined; parity unpinned vs the reference)        */

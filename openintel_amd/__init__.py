@@ -9,6 +9,7 @@ calls raise.
 from . import _lib
 from .analyzer import HipLexiconAnalyzer, PostAnalyzer, pack_posts
 from .context import HipContext
+from .dip import HeadlineScanner, company_name_forms
 from .domain import (Alignment, AnalyzerMismatch, Confidence, DomainError, EngineConfig, MarketSnapshot,
                      PostSignal, PostText, SocialPost, SourceFailure, SourceKind, Ticker)
 from .engine import SpeculationEngine
@@ -18,7 +19,7 @@ from .retriever import (HybridIndex, PostRetriever, SearchResult, fuse_packed, m
 __all__ = [
     "HipContext", "HipLexiconAnalyzer", "PostAnalyzer", "pack_posts", "SpeculationEngine", "HybridIndex",
     "PostRetriever", "SearchResult", "merge_lists", "rrf_fuse", "pack_query_terms", "fuse_packed", "packed_words",
-    "unpack_lists", "Alignment",
+    "unpack_lists", "HeadlineScanner", "company_name_forms", "Alignment",
     "AnalyzerMismatch", "Confidence", "DomainError", "EngineConfig", "MarketSnapshot", "PostSignal", "PostText",
     "SocialPost", "SourceFailure", "SourceKind", "Ticker",
 ]

@@ -15,6 +15,7 @@ OI_HOST, OI_DEVICE = 0, 1
 OI_MAX_DEPTH = 1024
 OI_MAX_DIM = 1024
 OI_BM25_BLOCK_DOCS = 32768
+OI_N_CATALYST_KEYWORDS = 16
 
 OI_ERR_INVALID_ARG = -1
 OI_ERR_HIP = -2
@@ -57,6 +58,9 @@ SIGNATURES = {
     "oi_synchronize": (_I, [_P]),
     "oi_lexicon_analyze": (_I, [_P, _P, _P, _U64, _P, _P]),
     "oi_lexicon_analyze_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P]),
+    "oi_catalyst_keyword": (C.c_char_p, [_U32]),
+    "oi_headline_scan": (_I, [_P, _P, _P, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
+    "oi_headline_scan_device": (_I, [_P, _P, _P, _U64, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
     "oi_social_summary": (_I, [_P, _P, _U64, _P, _P, _U64, C.c_double, _I, C.POINTER(SocialCounters)]),
     "oi_index_create": (_I, [_P, _U64, _U32, _U32, _U32, C.POINTER(_P)]),
     "oi_index_destroy": (None, [_P]),

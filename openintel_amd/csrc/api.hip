@@ -186,6 +186,57 @@ extern "C" int oi_lexicon_analyze(oi_ctx *ctx, const uint8_t *blob, const uint64
     return OI_OK;
 }
 
+extern "C" int oi_headline_scan_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                                       uint64_t blob_bytes, const uint8_t *ticker, uint64_t ticker_len,
+                                       const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms,
+                                       uint16_t *d_mask, uint64_t *d_order, uint8_t *d_about) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(d_offsets && d_mask && d_order && d_about && (d_blob || blob_bytes == 0), "headline scan: null buffer");
+    OI_REQUIRE((ticker || ticker_len == 0) && (n_forms == 0 || (forms_blob && form_offsets)),
+               "headline scan: null ticker/forms");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    return oi_launch_headline_scan(ctx, d_blob, d_offsets, n, blob_bytes, ticker, ticker_len, forms_blob,
+                                   form_offsets, n_forms, d_mask, d_order, d_about);
+}
+
+extern "C" int oi_headline_scan(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                                const uint8_t *ticker, uint64_t ticker_len, const uint8_t *forms_blob,
+                                const uint32_t *form_offsets, uint32_t n_forms, uint16_t *mask_out,
+                                uint64_t *order_out, uint8_t *about_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(offsets && mask_out && order_out && about_out, "headline scan: null buffer");
+    OI_REQUIRE(offsets[0] == 0, "headline scan: offsets[0] must be 0");
+    OI_REQUIRE((ticker || ticker_len == 0) && (n_forms == 0 || (forms_blob && form_offsets)),
+               "headline scan: null ticker/forms");
+    const uint64_t bytes = offsets[n];
+    OI_REQUIRE(blob || bytes == 0, "headline scan: null title blob");
+    for (uint64_t i = 0; i < n; ++i)
+        OI_REQUIRE(offsets[i + 1] >= offsets[i] && offsets[i + 1] - offsets[i] < (1ull << 32),
+                   "headline scan: offsets must ascend and a title must be shorter than 4 GiB");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf &b = ctx->buf("hl_blob"), &o = ctx->buf("hl_off"), &m = ctx->buf("hl_mask"), &r = ctx->buf("hl_order"),
+           &a = ctx->buf("hl_about");
+    OI_CHECK(b.ensure(bytes + 64));
+    OI_CHECK(o.ensure(sizeof(uint64_t) * (n + 1)));
+    OI_CHECK(m.ensure(sizeof(uint16_t) * n));
+    OI_CHECK(r.ensure(sizeof(uint64_t) * n));
+    OI_CHECK(a.ensure(n));
+    if (bytes) OI_HIP_CHECK(hipMemcpyAsync(b.p, blob, bytes, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemcpyAsync(o.p, offsets, sizeof(uint64_t) * (n + 1), hipMemcpyHostToDevice, st));
+    OI_CHECK(oi_launch_headline_scan(ctx, b.as<uint8_t>(), o.as<uint64_t>(), n, bytes, ticker, ticker_len, forms_blob,
+                                     form_offsets, n_forms, m.as<uint16_t>(), r.as<uint64_t>(), a.as<uint8_t>()));
+    OI_HIP_CHECK(hipMemcpyAsync(mask_out, m.p, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(order_out, r.p, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(about_out, a.p, n, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
+}
+
 extern "C" int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts, const double *polarity,
                                  const uint8_t *speculative, uint64_t n_signals, double tau, int location,
                                  oi_social_counters *out) {

@@ -125,6 +125,11 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
 int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol,
                              const uint8_t *d_spec, uint64_t n, double tau,
                              oi_social_counters *out_host);
+// headline.hip
+int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                            uint64_t blob_bytes, const uint8_t *ticker, uint64_t ticker_len,
+                            const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms,
+                            uint16_t *d_mask, uint64_t *d_order, uint8_t *d_about);
 // select.hip
 // Candidate pools, one per query, never touched by a global atomic in the batch kernels:
 //   keys[q*stride + 0 .. carry_cap)                    the top-k carried over from earlier corpus chunks

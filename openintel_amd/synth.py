@@ -92,6 +92,74 @@ def posts_np(n_posts: int, seed: int = SEED_LEX) -> List[str]:
     return out
 
 
+# ------------------------------------------------------------------ headlines (dip gate)
+HEADLINE_COMPANY = "Ultra Clean Holdings, Inc."
+HEADLINE_TICKER = "UCTT"
+_CATALYST = ["earnings", "miss", "guidance", "cut", "offering", "dilution", "downgrade", "halt", "fraud", "lawsuit",
+             "recall", "fda", "bankruptcy", "delisting", "investigation", "resign"]
+_NEAR = ["dismissal", "cuts", "missed", "halts", "recalls", "offerings", "earning", "resigned", "fdas", "cutter",
+         "lawsuits", "guidances", "investigations", "ultra", "clean", "cleanse", "ultraclean", "uctt", "UCTT", "Ultra",
+         "Clean", "uct", "ucttx", "Ultra Clean", "ULTRA CLEAN", "ultra-clean", "Ultra  Clean", "ultra cleanse",
+         "ultra, clean"]
+
+
+def headline_words(n_words: int = 2048, seed: int = SEED_LEX) -> Tuple[List[str], np.ndarray]:
+    """Words of synthetic titles: catalyst keywords in three casings (4 % of the mass), near
+    misses and the company's words (6 %), random filler for the rest."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    hot = [f(w) for w in _CATALYST for f in (str.lower, str.upper, str.capitalize)]
+    words = hot + list(_NEAR)
+    seen = set(words)
+    letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+    while len(words) < n_words:
+        w = "".join(rng.choice(letters, size=int(rng.integers(2, 11))))
+        if rng.random() < 0.3:
+            w = w.capitalize()
+        if rng.random() < 0.05:
+            w = str(int(rng.integers(1, 5000)))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    p = np.full(n_words, 0.90 / (n_words - len(hot) - len(_NEAR)))
+    p[:len(hot)] = 0.04 / len(hot)
+    p[len(hot):len(hot) + len(_NEAR)] = 0.06 / len(_NEAR)
+    return words, p
+
+
+_SEPARATORS = [" ", " ", " ", " ", ", ", ": ", " - ", "'s ", "  ", ".", " $", "%, ", " — ", "é", "/", "\t", " (", ") "]
+
+
+def headlines_np(n_titles: int, seed: int = SEED_LEX, ragged: bool = True) -> List[str]:
+    """Titles with mixed separators (punctuation, doubled spaces, non-ASCII); when `ragged`,
+    also empty titles, separator-only titles and titles that begin/end mid-word so that
+    adjacent titles in the packed blob touch without a separator."""
+    words, p = headline_words(seed=seed)
+    rng = np.random.Generator(np.random.PCG64(seed + 8))
+    n_tok = rng.integers(1, 17, size=n_titles)
+    ids = rng.choice(len(words), size=int(n_tok.sum()), p=p)
+    seps = rng.integers(0, len(_SEPARATORS), size=int(n_tok.sum()))
+    kind = rng.random(n_titles)
+    out, pos = [], 0
+    for t in range(n_titles):
+        k = int(n_tok[t])
+        parts = []
+        for j in range(k):
+            parts.append(words[ids[pos + j]])
+            if j + 1 < k:
+                parts.append(_SEPARATORS[seps[pos + j]])
+        pos += k
+        title = "".join(parts)
+        if ragged:
+            if kind[t] < 0.01:
+                title = ""
+            elif kind[t] < 0.02:
+                title = " —  !"
+            elif kind[t] < 0.10:
+                title = _SEPARATORS[seps[pos - 1]] + title + _SEPARATORS[seps[pos - k]]
+        out.append(title)
+    return out
+
+
 # ------------------------------------------------------------------ torch (bench, in HBM)
 def embeddings_torch(n: int, dim: int, device, seed: int = SEED_EMB, chunk: int = 1 << 20):
     import torch
@@ -138,8 +206,18 @@ def query_batch_torch(n_queries: int, dim: int, device, vocab: int = VOCAB, seed
 
 def posts_torch(n_posts: int, device, seed: int = SEED_LEX, chunk_posts: int = 1 << 19):
     """(blob uint8 [bytes], offsets int64 [n_posts+1]) on `device`, same distribution as posts_np."""
-    import torch
     words, p = word_list(seed=seed)
+    return texts_torch(words, p, n_posts, 8, 41, device, seed, chunk_posts)
+
+
+def headlines_torch(n_titles: int, device, seed: int = SEED_LEX, chunk_titles: int = 1 << 19):
+    """Synthetic headline titles in HBM: headline_words() joined by single spaces, 6..16 words."""
+    words, p = headline_words(seed=seed)
+    return texts_torch(words, p, n_titles, 6, 17, device, seed, chunk_titles)
+
+
+def texts_torch(words, p, n_posts: int, tok_lo: int, tok_hi: int, device, seed: int, chunk_posts: int = 1 << 19):
+    import torch
     maxlen = max(len(w) for w in words) + 1
     table = np.full((len(words), maxlen), ord(" "), dtype=np.uint8)
     wl = np.zeros(len(words), dtype=np.int64)
@@ -154,7 +232,7 @@ def posts_torch(n_posts: int, device, seed: int = SEED_LEX, chunk_posts: int = 1
     blobs, lens_all = [], []
     for s in range(0, n_posts, chunk_posts):
         m = min(chunk_posts, n_posts - s)
-        n_tok = torch.randint(8, 41, (m,), generator=g, device=device)
+        n_tok = torch.randint(tok_lo, tok_hi, (m,), generator=g, device=device)
         T = int(n_tok.sum().item())
         ids = torch.multinomial(d_p, T, replacement=True, generator=g)
         tl = d_wl[ids]                                   # bytes per token (word + separator)

@@ -5,7 +5,7 @@ import ctypes as C
 import os
 import subprocess
 from dataclasses import dataclass
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -189,6 +189,61 @@ def lexicon_analyze(blob: np.ndarray, offsets: np.ndarray):
     rc = _L().oio_lexicon_analyze(_p(blob), _p(offsets), C.c_uint64(n), _p(pol), _p(spec))
     assert rc == 0
     return pol, spec
+
+
+# ---- headline gate (dip.rs:204-272) ----------------------------------------------
+def catalyst_keywords() -> List[str]:
+    arr = (C.c_char_p * 16).in_dll(_L(), "OIO_CATALYST_KEYWORDS")
+    return [a.decode() for a in arr]
+
+
+def pack_forms(forms: Sequence[bytes | str]):
+    enc = [f.encode("utf-8") if isinstance(f, str) else bytes(f) for f in forms]
+    offs = np.zeros(len(enc) + 1, dtype=np.uint32)
+    if enc:
+        offs[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint32)
+    blob = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8).copy()
+    return blob, offs
+
+
+def headline_scan(blob: np.ndarray, offsets: np.ndarray, ticker: bytes | str, forms: Sequence[bytes | str]):
+    """(mask u16[n], order u64[n], about u8[n]) over a batch of titles."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    if blob.size == 0:
+        blob = np.zeros(1, np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    tk = ticker.encode("utf-8") if isinstance(ticker, str) else bytes(ticker)
+    tkb = np.frombuffer(tk + b"\0", dtype=np.uint8)
+    fblob, foffs = pack_forms(forms)
+    mask = np.zeros(n, np.uint16)
+    order = np.zeros(n, np.uint64)
+    about = np.zeros(n, np.uint8)
+    _L().oio_headline_scan(_p(blob), _p(offsets), C.c_uint64(n), _p(tkb), C.c_uint64(len(tk)), _p(fblob),
+                           _p(foffs), C.c_uint32(len(forms)), _p(mask), _p(order), _p(about))
+    return mask, order, about
+
+
+def hits_from_order(mask: int, order: int) -> List[str]:
+    kw = catalyst_keywords()
+    return [kw[(int(order) >> (4 * j)) & 15] for j in range(bin(int(mask)).count("1"))]
+
+
+def catalyst_hits(texts: Sequence[bytes | str]) -> List[str]:
+    """dip.rs:261-272: keyword hits across the texts, deduped, first-occurrence order."""
+    blob, offs = pack_texts(texts)
+    mask, order, _ = headline_scan(blob, offs, b"", [])
+    hits: List[str] = []
+    for m, o in zip(mask, order):
+        for h in hits_from_order(m, o):
+            if h not in hits:
+                hits.append(h)
+    return hits
+
+
+def headline_mentions_company(title: bytes | str, ticker: bytes | str, forms: Sequence[bytes | str]) -> bool:
+    blob, offs = pack_texts([title])
+    return bool(headline_scan(blob, offs, ticker, forms)[2][0])
 
 
 def social_summary(sources, polarity, speculative, cfg: Optional[EngineConfig] = None) -> SocialSummary:

@@ -173,6 +173,125 @@ int oio_lexicon_analyze(const uint8_t *blob, const uint64_t *offsets, uint64_t n
     return OIO_OK;
 }
 
+/* ---- headline gate ------------------------------------------------- */
+
+/* src/domain/dip.rs:38-55 */
+const char *const OIO_CATALYST_KEYWORDS[OIO_N_CATALYST] = {
+    "earnings", "miss", "guidance", "cut", "offering", "dilution", "downgrade",
+    "halt", "fraud", "lawsuit", "recall", "fda", "bankruptcy", "delisting",
+    "investigation", "resign"};
+
+static int oio_ascii_alnum(uint8_t c) { /* char::is_ascii_alphanumeric */
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z');
+}
+static uint8_t oio_ascii_lower(uint8_t c) { /* u8::to_ascii_lowercase */
+    return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
+}
+
+/* src/domain/dip.rs:261-272.  Every byte of a non-ASCII char is >= 0x80, hence
+ * not ASCII alphanumeric: splitting on bytes equals splitting on chars. */
+uint32_t oio_catalyst_hits(const uint8_t *text, uint64_t len, uint16_t *mask,
+                           uint64_t *order) {
+    uint16_t m = 0;
+    uint64_t ord = 0;
+    uint32_t n = 0;
+    uint64_t i = 0;
+    while (i <= len) {
+        uint64_t start = i;
+        while (i < len && oio_ascii_alnum(text[i])) i++;
+        uint64_t tl = i - start; /* token = text[start..i), possibly empty */
+        for (int k = 0; k < OIO_N_CATALYST && tl; k++) {
+            const char *kw = OIO_CATALYST_KEYWORDS[k];
+            if (strlen(kw) != tl) continue;
+            uint64_t j = 0;
+            while (j < tl && oio_ascii_lower(text[start + j]) == (uint8_t)kw[j]) j++;
+            if (j == tl && !(m & (1u << k))) { /* :266 contains && not yet in hits */
+                m |= (uint16_t)(1u << k);
+                ord |= (uint64_t)k << (4 * n);
+                n++;
+            }
+        }
+        i++; /* the separator */
+    }
+    *mask = m;
+    *order = ord;
+    return n;
+}
+
+/* normalize_words (:204-210) + join(" ") padded with one space each side (:254) */
+static uint8_t *oio_title_joined(const uint8_t *title, uint64_t len, uint64_t *out_len) {
+    uint8_t *buf = (uint8_t *)malloc(len + 3);
+    uint64_t o = 0;
+    int first = 1;
+    buf[o++] = ' ';
+    for (uint64_t i = 0; i < len;) {
+        if (!oio_ascii_alnum(title[i])) { i++; continue; }
+        if (!first) buf[o++] = ' ';
+        first = 0;
+        while (i < len && oio_ascii_alnum(title[i])) buf[o++] = oio_ascii_lower(title[i++]);
+    }
+    buf[o++] = ' ';
+    *out_len = o;
+    return buf;
+}
+
+static int oio_contains(const uint8_t *hay, uint64_t hl, const uint8_t *a, uint64_t al,
+                        int pad) {
+    /* does hay contain (pad ? " a " : a) */
+    uint64_t nl = al + (pad ? 2 : 0);
+    if (nl > hl) return 0;
+    for (uint64_t s = 0; s + nl <= hl; s++) {
+        uint64_t j = 0;
+        if (pad) {
+            if (hay[s] != ' ' || hay[s + nl - 1] != ' ') continue;
+            while (j < al && hay[s + 1 + j] == a[j]) j++;
+        } else {
+            while (j < al && hay[s + j] == a[j]) j++;
+        }
+        if (j == al) return 1;
+    }
+    return 0;
+}
+
+/* src/domain/dip.rs:247-258 */
+int oio_headline_mentions_company(const uint8_t *title, uint64_t len,
+                                  const uint8_t *ticker, uint64_t ticker_len,
+                                  const uint8_t *forms_blob,
+                                  const uint32_t *form_offsets, uint32_t n_forms) {
+    uint64_t jl;
+    uint8_t *joined = oio_title_joined(title, len, &jl);
+    int hit = 0;
+    if (ticker_len >= 2) { /* :250 title_words.contains(&ticker_lower) */
+        uint8_t *tl = (uint8_t *)malloc(ticker_len);
+        int wordlike = 1; /* a word never holds a space; a ticker with one cannot equal a word */
+        for (uint64_t i = 0; i < ticker_len; i++) {
+            tl[i] = oio_ascii_lower(ticker[i]);
+            if (tl[i] == ' ') wordlike = 0;
+        }
+        if (wordlike) hit = oio_contains(joined, jl, tl, ticker_len, 1);
+        free(tl);
+    }
+    for (uint32_t f = 0; f < n_forms && !hit; f++) /* :255-257 */
+        hit = oio_contains(joined, jl, forms_blob + form_offsets[f],
+                           form_offsets[f + 1] - form_offsets[f], 1);
+    free(joined);
+    return hit;
+}
+
+void oio_headline_scan(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                       const uint8_t *ticker, uint64_t ticker_len,
+                       const uint8_t *forms_blob, const uint32_t *form_offsets,
+                       uint32_t n_forms, uint16_t *mask_out, uint64_t *order_out,
+                       uint8_t *about_out) {
+    for (uint64_t i = 0; i < n; i++) {
+        const uint8_t *t = blob + offsets[i];
+        uint64_t l = offsets[i + 1] - offsets[i];
+        oio_catalyst_hits(t, l, &mask_out[i], &order_out[i]);
+        about_out[i] = (uint8_t)oio_headline_mentions_company(t, l, ticker, ticker_len, forms_blob,
+                                                              form_offsets, n_forms);
+    }
+}
+
 /* src/domain/engine/speculation_engine.rs:70-125 */
 void oio_social_summary_compute(const uint8_t *sources, const double *polarity,
                                 const uint8_t *speculative, uint64_t n,

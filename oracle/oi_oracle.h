@@ -163,6 +163,36 @@ int oio_aggregate(const char *ticker, const uint8_t *sources, uint64_t n_posts,
                   const char *market_ticker, const oio_engine_config *cfg,
                   oio_report *out);
 
+/* ---- headline gate, reference-pinned ------- */
+
+/* src/domain/dip.rs:38-55, in declaration order (index = bit / nibble value). */
+#define OIO_N_CATALYST 16
+extern const char *const OIO_CATALYST_KEYWORDS[OIO_N_CATALYST];
+
+/* src/domain/dip.rs:261-272 on ONE text: ASCII-lowercase, split on every char
+ * that is not ASCII alphanumeric, keep tokens that are catalyst keywords,
+ * deduped in first-occurrence order.  *mask: bit i set iff keyword i hit.
+ * *order: nibble j (bits 4j..4j+3) = keyword index of the j-th distinct hit.
+ * Returns the number of distinct hits.  (The multi-text call of the reference
+ * is the concatenation of per-text results with the same dedupe.) */
+uint32_t oio_catalyst_hits(const uint8_t *text, uint64_t len, uint16_t *mask,
+                           uint64_t *order);
+
+/* src/domain/dip.rs:247-258 (with normalize_words, :204-210).  Form i is
+ * forms_blob[form_offsets[i] .. form_offsets[i+1]).  Returns 0/1. */
+int oio_headline_mentions_company(const uint8_t *title, uint64_t len,
+                                  const uint8_t *ticker, uint64_t ticker_len,
+                                  const uint8_t *forms_blob,
+                                  const uint32_t *form_offsets,
+                                  uint32_t n_forms);
+
+/* Both of the above over a batch of titles (the dip gate's loop, dip.rs:619-626). */
+void oio_headline_scan(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                       const uint8_t *ticker, uint64_t ticker_len,
+                       const uint8_t *forms_blob, const uint32_t *form_offsets,
+                       uint32_t n_forms, uint16_t *mask_out, uint64_t *order_out,
+                       uint8_t *about_out);
+
 /* ------------------------------------------------------------------ */
 /* (2) PARITY UNPINNED -- builder-chosen retrieval definitions          */
 /* ------------------------------------------------------------------ */

@@ -57,3 +57,45 @@ def score(text: str):
     pol = 0.0 if bull + bear == 0.0 else (bull - bear) / (bull + bear)
     spec = any(t in JARGON for t in toks)
     return polarity_new(pol), spec, int(bull), int(bear)
+
+
+# ---- headline gate (src/domain/dip.rs:38-55, :204-272) -- small-case cross-check of the C
+CATALYST_KEYWORDS = ["earnings", "miss", "guidance", "cut", "offering", "dilution", "downgrade", "halt", "fraud",
+                     "lawsuit", "recall", "fda", "bankruptcy", "delisting", "investigation", "resign"]
+
+
+def _ascii_lower(text: str) -> str:  # str::to_ascii_lowercase
+    return "".join(chr(ord(c) + 32) if "A" <= c <= "Z" else c for c in text)
+
+
+def _split_non_alnum(text: str):
+    out, cur = [], []
+    for c in text:
+        if _is_ascii_alnum(c):
+            cur.append(c)
+        else:
+            out.append("".join(cur))
+            cur = []
+    out.append("".join(cur))
+    return out
+
+
+def normalize_words(text: str):  # dip.rs:204-210
+    return [w for w in _split_non_alnum(_ascii_lower(text)) if w]
+
+
+def catalyst_hits(texts):  # dip.rs:261-272
+    hits = []
+    for text in texts:
+        for token in _split_non_alnum(_ascii_lower(text)):
+            if token in CATALYST_KEYWORDS and token not in hits:
+                hits.append(token)
+    return hits
+
+
+def headline_mentions_company(title: str, ticker: str, name_forms) -> bool:  # dip.rs:247-258
+    words = normalize_words(title)
+    if len(ticker.encode("utf-8")) >= 2 and _ascii_lower(ticker) in words:
+        return True
+    joined = " %s " % " ".join(words)
+    return any((" %s " % form) in joined for form in name_forms)

@@ -173,6 +173,57 @@ def main():
                  n_posts=1, signals=[[0.0, False, 1]], market=[100.0, 100.0, 10, 10, None],
                  expect=dict(crowding_approx=0.125)),
         ],
+        # ---- headline gate, src/domain/dip.rs (inputs + the values its tests assert) ----
+        "dip": {
+            "catalyst_keywords": ["earnings", "miss", "guidance", "cut", "offering", "dilution", "downgrade",
+                                  "halt", "fraud", "lawsuit", "recall", "fda", "bankruptcy", "delisting",
+                                  "investigation", "resign"],  # :38-55
+            "catalyst_hits": [  # :850-855 catalyst_hits_are_whole_word_and_deduped
+                dict(texts=["Earnings miss shocks", "dismissal of claims", "MISS again"],
+                     expect=["earnings", "miss"]),
+                dict(texts=["a quiet day"], expect=[]),
+            ],
+            "company_name_forms": [  # :1003-1004, :1027, :1038-1039
+                dict(names=["Ultra Clean Holdings, Inc."], expect=["ultra clean"]),
+                dict(names=["The Viking Holdings Ltd"], expect=["viking"]),
+                dict(names=[" "], expect=[]),
+                dict(names=["Inc."], expect=[]),
+            ],
+            "headline_mentions_company": [  # :1005-1037 headline_company_matching
+                dict(title="Ultra Clean Shares Fall After $400 Million Offering", ticker="UCTT",
+                     forms=["ultra clean"], expect=True),
+                dict(title="Why UCTT dropped today", ticker="UCTT", forms=["ultra clean"], expect=True),
+                dict(title="Target Stock Flies To New Highs As Earnings Approach", ticker="UCTT",
+                     forms=["ultra clean"], expect=False),
+                dict(title="An ultra cleanse fad", ticker="UCTT", forms=["ultra clean"], expect=False),
+                dict(title="Viking slides on bookings", ticker="VIK", forms=["viking"], expect=True),
+                dict(title="Norse history special", ticker="VIK", forms=["viking"], expect=False),
+            ],
+            # gate cases: (ticker, company_names, [(publisher, title)]) -> status of no_catalyst_headline.
+            # The reference asserts the verdict; Fail <=> NoSetup (:702), Unknown caps at Watch.
+            "gate": [
+                dict(name="catalyst_headline_is_no_setup_with_evidence",  # :986-999; default inputs :882,:901
+                     ticker="TEST", company_names=[],
+                     headlines=[["Wire", "Company cuts guidance after earnings miss"]],
+                     expect=dict(status="fail", evidence0_contains="guidance")),
+                dict(name="blank_company_names_keep_strict_headline_behavior",  # :1043-1057
+                     ticker="TEST", company_names=[" "], headlines=[["Wire", "Retail earnings week ahead"]],
+                     expect=dict(status="fail")),
+                dict(name="roundup_headline_is_unknown_not_kill_when_names_known (roundup)",  # :1059-1078
+                     ticker="VIK", company_names=["Viking Holdings Ltd"],
+                     headlines=[["IBD", "Stock Market Week Ahead: Walmart, Target Lead Retail Earnings"]],
+                     expect=dict(status="unknown", evidence_empty=True)),
+                dict(name="roundup_headline_is_unknown_not_kill_when_names_known (named)",  # :1080-1090
+                     ticker="VIK", company_names=["Viking Holdings Ltd"],
+                     headlines=[["Wire", "Viking cuts guidance after weak bookings"]],
+                     expect=dict(status="fail", evidence_empty=False)),
+                dict(name="roundup_headline_is_unknown_not_kill_when_names_known (no names)",  # :1092-1100
+                     ticker="TEST", company_names=[], headlines=[["Wire", "Retail earnings week ahead"]],
+                     expect=dict(status="fail")),
+                dict(name="no headlines passes (default inputs, :900)", ticker="TEST", company_names=[],
+                     headlines=[], expect=dict(status="pass", evidence_empty=True)),
+            ],
+        },
     }
     path = os.path.join(HERE, "reference_fixture.json")
     with open(path, "w") as f:

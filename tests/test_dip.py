@@ -1,0 +1,196 @@
+"""Headline gate (SURVEY.md section 8 row f, rank 3): catalyst_hits / headline_mentions_company /
+company_name_forms / the no_catalyst_headline gate -- src/domain/dip.rs:38-55, :204-272, :612-659.
+
+Golden vectors are the reference's own test data (dip.rs:850-855, :1002-1100), transcribed in
+tests/golden/reference_fixture.json["dip"].  CPU tests pin the oracle (C restatement and the
+pure-Python one) and the host logic; `gpu` tests run the HIP kernel through the C ABI against
+the same vectors and against the oracle on seeded synthetic titles (bit-exact: integer/byte work).
+"""
+import numpy as np
+import pytest
+
+from openintel_amd import dip, synth
+from openintel_amd.analyzer import pack_posts
+
+
+class OracleScanner:
+    """The CPU oracle behind HeadlineScanner's interface (test infrastructure only)."""
+
+    def __init__(self):
+        from oracle import lib
+        self.lib = lib
+        self.keywords = lib.catalyst_keywords()
+
+    def scan(self, titles, ticker, name_forms):
+        blob, offs = pack_posts(titles)
+        return self.lib.headline_scan(blob, offs, ticker, name_forms)
+
+
+def _gate_cases(golden, scanner):
+    for c in golden["dip"]["gate"]:
+        hl = [dip.Headline(title=t, publisher=p) for p, t in c["headlines"]]
+        status, evidence = dip.no_catalyst_headline(scanner, c["ticker"], c["company_names"], hl)
+        e = c["expect"]
+        assert status.status == e["status"], c["name"]
+        if "evidence0_contains" in e:
+            assert e["evidence0_contains"] in evidence[0], c["name"]
+        if "evidence_empty" in e:
+            assert (len(evidence) == 0) == e["evidence_empty"], c["name"]
+    # the exact strings of dip.rs:627-632, :647-656
+    st, ev = dip.no_catalyst_headline(scanner, "VIK", ["Viking Holdings Ltd"],
+                                      [dip.Headline("Viking cuts guidance after weak bookings, earnings miss", "Wire"),
+                                       dip.Headline("Sector roundup: FDA halt fears", "IBD")])
+    assert st == dip.GateStatus("fail", "catalyst term(s) in company headlines: guidance, earnings, miss")
+    assert ev == ['headline [Wire]: "Viking cuts guidance after weak bookings, earnings miss" '
+                  '(terms: guidance, earnings, miss)']
+    st, ev = dip.no_catalyst_headline(scanner, "VIK", ["Viking Holdings Ltd"],
+                                      [dip.Headline("Sector roundup: FDA halt fears", "IBD"),
+                                       dip.Headline("Halt lifted; fda again", "X")])
+    assert st == dip.GateStatus("unknown", "catalyst term(s) only in headlines not clearly about VIK: fda, halt")
+    assert ev == []
+    st, ev = dip.no_catalyst_headline(scanner, "VIK", [], None, unavailable_reason="news feed down")
+    assert st == dip.GateStatus("unknown", "news feed down") and ev == []
+
+
+# ----------------------------------------------------------------------------- CPU
+def test_oracle_matches_reference_vectors(golden):
+    from oracle import lib, pyref
+    g = golden["dip"]
+    assert lib.catalyst_keywords() == g["catalyst_keywords"] == pyref.CATALYST_KEYWORDS
+    for c in g["catalyst_hits"]:
+        assert lib.catalyst_hits(c["texts"]) == c["expect"]
+        assert pyref.catalyst_hits(c["texts"]) == c["expect"]
+    for c in g["headline_mentions_company"]:
+        assert lib.headline_mentions_company(c["title"], c["ticker"], c["forms"]) is c["expect"], c
+        assert pyref.headline_mentions_company(c["title"], c["ticker"], c["forms"]) is c["expect"], c
+
+
+def test_company_name_forms_reference_vectors(golden):
+    for c in golden["dip"]["company_name_forms"]:
+        assert dip.company_name_forms(c["names"]) == c["expect"], c
+    # the rules of dip.rs:216-243 one by one
+    assert dip.company_name_forms(["Apple Inc.", "APPLE INC", "Apple"]) == ["apple"]          # dedupe
+    assert dip.company_name_forms(["Box Inc"]) == []                                          # 1 word < 4 chars
+    assert dip.company_name_forms(["The Trade Desk, Inc."]) == ["trade desk"]                 # `the` dropped, 2 words
+    assert dip.company_name_forms(["Berkshire Hathaway Energy Co"]) == ["berkshire hathaway"]  # first two words
+    assert dip.company_name_forms(["Société Générale SA"]) == ["soci t"]                      # non-ASCII splits
+    assert dip.company_name_forms(["Holdings Group Trust"]) == []                             # all suffixes
+    assert dip.normalize_words("Ultra-Clean  Holdings, Inc.") == ["ultra", "clean", "holdings", "inc"]
+
+
+def test_oracle_c_matches_python_on_synthetic_titles():
+    from oracle import lib, pyref
+    titles = synth.headlines_np(3000, seed=21)
+    forms = ["ultra clean", "uct", "", "Ultra Clean", "clean ", "ultra  clean", "a a b"]
+    for ticker in ("UCTT", "U", "BRK.B", "uctt", ""):
+        blob, offs = pack_posts(titles)
+        mask, order, about = lib.headline_scan(blob, offs, ticker, forms)
+        kw = lib.catalyst_keywords()
+        for i, t in enumerate(titles):
+            assert lib.hits_from_order(mask[i], order[i]) == pyref.catalyst_hits([t]), (i, t)
+            assert bool(about[i]) == pyref.headline_mentions_company(t, ticker, forms), (i, t, ticker)
+        assert all(k in kw for k in pyref.catalyst_hits(titles))
+    assert mask.any() and about.any() and not about.all()
+
+
+def test_gate_logic_with_oracle_scanner(golden):
+    _gate_cases(golden, OracleScanner())
+
+
+# ----------------------------------------------------------------------------- GPU
+pytest_gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scanner():
+    import openintel_amd as oi
+    c = oi.HipContext(0)
+    yield oi.HeadlineScanner(c)
+    c.close()
+
+
+def _check_scan(scanner, titles, ticker, forms):
+    from oracle import lib
+    blob, offs = pack_posts(titles)
+    m, o, a = scanner.scan_packed(blob, offs, ticker, forms)
+    rm, ro, ra = lib.headline_scan(blob, offs, ticker, forms)
+    bad = np.nonzero((m != rm) | (o != ro) | (a != ra))[0]
+    assert bad.size == 0, "first mismatch at title %d %r: gpu=(%x,%x,%d) ref=(%x,%x,%d)" % (
+        bad[0], titles[bad[0]][:160], m[bad[0]], o[bad[0]], a[bad[0]], rm[bad[0]], ro[bad[0]], ra[bad[0]])
+    return m, o, a
+
+
+@pytest_gpu
+def test_reference_vectors_gpu(golden, scanner):
+    g = golden["dip"]
+    assert scanner.keywords == g["catalyst_keywords"]
+    for c in g["catalyst_hits"]:
+        assert scanner.catalyst_hits(c["texts"]) == c["expect"]
+    for c in g["headline_mentions_company"]:
+        assert scanner.headline_mentions_company(c["title"], c["ticker"], c["forms"]) is c["expect"], c
+    _gate_cases(golden, scanner)
+
+
+@pytest_gpu
+def test_synthetic_titles_match_oracle_gpu(scanner):
+    titles = synth.headlines_np(200_000, seed=22)
+    forms = dip.company_name_forms([synth.HEADLINE_COMPANY])
+    assert forms == ["ultra clean"]
+    m, o, a = _check_scan(scanner, titles, synth.HEADLINE_TICKER, forms)
+    assert 0.05 < (m != 0).mean() < 0.9 and 0.001 < a.mean() < 0.5
+    # every keyword is exercised, and some title holds several in a non-trivial order
+    assert np.bitwise_or.reduce(m) == 0xFFFF
+    assert any(bin(int(x)).count("1") >= 3 for x in m)
+
+
+@pytest_gpu
+def test_pattern_edge_cases_gpu(scanner):
+    titles = synth.headlines_np(20_000, seed=23) + [
+        "", " ", "—", "a a a b", "a a b", "x a a b y", "aab", "a  a - b", "A.A.B", "uctt", "UCTT.", "xuctt", "uctt2",
+        "ultra clean", "ultra", "clean ultra", "ULTRA\tCLEAN!", "ultra cleaner", "nultra clean", "ultra é clean",
+        "brk b", "BRK.B up", "u", "U U", "é", "investigation", "investigations", "investigatio", "xinvestigation",
+        "resign" * 3, "fda" + "x" * 40, "q" * 5000 + " earnings", "cut " * 2000]
+    for ticker, forms in [("UCTT", ["ultra clean"]), ("U", ["a a b"]), ("BRK.B", ["brk b", "", "BRK B"]),
+                          ("", []), ("brk", ["ultra  clean", " ultra", "clean ", "Ultra Clean", "ultra-clean"]),
+                          ("Ab", ["a", "b", "investigation resign", "x" * 600]), ("é", ["é"]), ("uc tt", [" "])]:
+        _check_scan(scanner, titles, ticker, forms)
+
+
+@pytest_gpu
+def test_touching_titles_and_large_tiles_gpu(scanner):
+    # adjacent titles share no separator in the blob: a word must end at the title's end
+    titles = ["earn", "ings", "mi", "ss", "ultra", " clean", "ultra ", "clean", "uc", "tt", "cut", "cut", "fda"] * 50
+    m, o, a = _check_scan(scanner, titles, "UCTT", ["ultra clean"])
+    assert [int(x) for x in m[:13]] == [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 8, 1 << 11]
+    assert a.sum() == 0
+    # a tile of 256 titles larger than the LDS window takes the direct-from-HBM path; mix both kinds
+    long_titles = [(" ".join(synth.headlines_np(6, seed=100 + i, ragged=False))) for i in range(300)]
+    assert sum(len(t) for t in long_titles[:256]) > 48 * 1024
+    _check_scan(scanner, long_titles + synth.headlines_np(1000, seed=24) + long_titles[:10], "UCTT", ["ultra clean"])
+
+
+@pytest_gpu
+def test_device_buffers_and_limits_gpu(scanner):
+    import torch
+    from oracle import lib
+    from openintel_amd import _lib
+    titles = synth.headlines_np(50_000, seed=25)
+    blob, offs = pack_posts(titles)
+    d_blob = torch.from_numpy(blob.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    n = len(titles)
+    d_m = torch.zeros(n, dtype=torch.int16, device="cuda")
+    d_o = torch.zeros(n, dtype=torch.int64, device="cuda")
+    d_a = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    scanner.scan_device(d_blob, d_offs, "UCTT", ["ultra clean"], d_m, d_o, d_a)
+    scanner.ctx.synchronize()
+    rm, ro, ra = lib.headline_scan(blob, offs, "UCTT", ["ultra clean"])
+    assert np.array_equal(d_m.cpu().numpy().view(np.uint16), rm)
+    assert np.array_equal(d_o.cpu().numpy().view(np.uint64), ro)
+    assert np.array_equal(d_a.cpu().numpy(), ra)
+    # empty batch is a no-op; too many pattern bytes is an argument error, not a truncation
+    assert scanner.scan([], "UCTT", ["x"])[0].size == 0
+    with pytest.raises(_lib.OiError):
+        scanner.scan(["a"], "UCTT", ["x" * 600, "y" * 600])
+    with pytest.raises(_lib.OiError):
+        scanner.scan(["a"], "UCTT", ["w%d" % i for i in range(40)])
