@@ -40,6 +40,12 @@ struct __attribute__((aligned(16))) HlParams {
     uint16_t pat_off[HL_MAX_PATTERNS + 2];
     uint8_t pat[HL_MAX_PAT_BYTES];
     uint8_t pad1[12];
+    // Token filter of the byte-parallel kernel, indexed by first char (a-z -> 0..25, 0-9 -> 26..35):
+    // bits 0..15 = lengths L for which a keyword starts with that char; bits 16..31 = length classes
+    // min(L, HL_LONG) of the first words of the company patterns starting with it.
+    uint32_t first_char[40];
+    uint32_t len_any; // OR of all first_char entries
+    uint32_t pad2[3];
 };
 static_assert(sizeof(HlParams) % 16 == 0, "HlParams is copied as uint4");
 
@@ -188,6 +194,230 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
     about_out[t] = (uint8_t)about;
 }
 
+// ---------------------------------------------------------------- byte-parallel kernel
+// The tile's text is staged once; while it passes through registers every lane turns its 16 bytes
+// into 16 alnum bits, so the token pass works on bitmaps: token starts, token lengths and the cut
+// at title boundaries are a handful of bit operations per 16-byte chunk.  A token becomes a
+// candidate only if (first char, length) can begin a keyword or a company pattern; candidates go
+// to a per-wave LDS queue and are verified in a dense pass (packed compare against the perfect
+// hash for keywords, hl_match_at for patterns).  Hits are rare, so their cost -- a binary search
+// for the title, an LDS atomicOr on its mask and an atomicMin on the first position of that
+// keyword -- stays off the streaming path.
+#define HL_LONG 14u              // length class "14 or more"
+#define HL_QCAP 192
+#define HL_WAVES (HL_THREADS / 64)
+#define HL2_TEXT_BYTES (32 * 1024)
+#define HL2_CHUNKS (HL2_TEXT_BYTES / 16)
+
+struct Hl2Shared {
+    HlParams prm;
+    uint32_t text[HL2_TEXT_BYTES / 4 + 8]; // slack: 16-byte token reads may run past the window
+    uint16_t am[HL2_CHUNKS + 8];           // am[1 + c] = alnum bits of chunk c; am[0] = 0
+    uint16_t ts[HL2_CHUNKS + 8];           // ts[1 + c] = title-start bits of chunk c
+    uint32_t off[HL_TILE + 1];             // title offsets relative to the window
+    uint32_t res[HL_TILE];                 // bits 0..15 keyword mask, bit 16 about-company
+    alignas(16) uint32_t first[HL_TILE][HL_N_KW]; // window position of each keyword's first occurrence
+    uint32_t q_cnt[HL_WAVES];
+    uint32_t queue[HL_WAVES][HL_QCAP];     // pos | lenclass << 16 | is_kw << 24 | is_pat << 25
+};
+
+__device__ static inline uint32_t hl_alnum4(uint32_t w) { // one bit per byte
+    const uint32_t hi = w & 0x80808080u;
+    const uint32_t w7 = w & 0x7F7F7F7Fu;
+    const uint32_t ge_a = (w7 | 0x20202020u) + (0x80u - 'a') * 0x01010101u;
+    const uint32_t gt_z = (w7 | 0x20202020u) + (0x7Fu - 'z') * 0x01010101u;
+    const uint32_t ge_0 = w7 + (0x80u - '0') * 0x01010101u;
+    const uint32_t gt_9 = w7 + (0x7Fu - '9') * 0x01010101u;
+    const uint32_t f = ((ge_a & ~gt_z) | (ge_0 & ~gt_9)) & ~hi & 0x80808080u;
+    return (((f >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu;
+}
+
+__device__ static inline uint32_t hl_title_of(const Hl2Shared &s, uint32_t nt, uint32_t pos) {
+    // largest j < nt with off[j] <= pos (empty titles share an offset; the last of them owns the byte)
+    uint32_t lo = 0, hi = nt; // invariant: off[lo] <= pos < off[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s.off[mid] <= pos) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ static void hl2_verify(Hl2Shared &s, uint32_t nt, uint32_t e) {
+    const uint32_t pos = e & 0xFFFFu, lc = (e >> 16) & 0xFFu;
+    const uint32_t j = hl_title_of(s, nt, pos);
+    if (e & (1u << 24)) { // keyword: lc is the exact length, 3..13
+        const uint32_t wi = pos >> 2, sh = pos & 3u;
+        const uint32_t x0 = s.text[wi], x1 = s.text[wi + 1], x2 = s.text[wi + 2], x3 = s.text[wi + 3], x4 = s.text[wi + 4];
+        // every byte inside the token is ASCII alphanumeric: |0x20 lowercases letters, keeps digits
+        const uint64_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh) | 0x20202020u;
+        const uint64_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh) | 0x20202020u;
+        const uint64_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh) | 0x20202020u;
+        const uint64_t t3 = __builtin_amdgcn_alignbyte(x4, x3, sh) | 0x20202020u;
+        uint64_t lo = t0 | (t1 << 32), hi = t2 | (t3 << 32);
+        if (lc < 8) { lo &= (1ull << (8u * lc)) - 1ull; hi = 0; }
+        else if (lc == 8) hi = 0;
+        else hi &= (1ull << (8u * (lc - 8u))) - 1ull;
+        const uint32_t sl = hl_kw_slot(lo, s.prm.kw_mult);
+        if (s.prm.kw_lo[sl] == lo && s.prm.kw_hi[sl] == hi) {
+            const uint32_t k = s.prm.kw_id[sl];
+            atomicOr(&s.res[j], 1u << k);
+            atomicMin(&s.first[j][k], pos);
+        }
+    }
+    if ((e & (1u << 25)) && !((s.res[j] >> 16) & 1u)) {
+        HlLdsReader rd{s.text};
+        const uint32_t end = s.off[j + 1];
+        const uint32_t l = hl_lower(rd(pos));
+        const uint32_t np = s.prm.n_patterns;
+        for (uint32_t p = 0; p < np; ++p) {
+            const uint32_t o = s.prm.pat_off[p];
+            if (s.prm.pat[o] == l && hl_match_at(rd, pos, end, s.prm.pat + o, s.prm.pat_off[p + 1] - o)) {
+                atomicOr(&s.res[j], 1u << 16);
+                break;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel2(const uint8_t *__restrict__ blob,
+                                                                   const uint64_t *__restrict__ offsets, uint64_t n,
+                                                                   uint64_t blob_bytes,
+                                                                   const HlParams *__restrict__ params,
+                                                                   uint16_t *__restrict__ mask_out,
+                                                                   uint64_t *__restrict__ order_out,
+                                                                   uint8_t *__restrict__ about_out) {
+    __shared__ __attribute__((aligned(16))) Hl2Shared s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint64_t t0 = (uint64_t)blockIdx.x * HL_TILE;
+    const uint32_t nt = (uint32_t)((t0 + HL_TILE < n) ? HL_TILE : n - t0);
+    const uint64_t b0 = offsets[t0], b1 = offsets[t0 + nt];
+    const uint64_t a0 = b0 & ~(uint64_t)15;
+
+    for (uint32_t i = tid; i < sizeof(HlParams) / 16; i += HL_THREADS)
+        reinterpret_cast<uint4 *>(&s.prm)[i] = reinterpret_cast<const uint4 *>(params)[i];
+
+    if ((b1 - a0) > HL2_TEXT_BYTES) { // oversized tile: one lane per title, straight from HBM
+        __syncthreads();
+        if (tid < nt) {
+            const uint64_t tb = offsets[t0 + tid], te = offsets[t0 + tid + 1];
+            HlMemReader rd{blob + tb};
+            uint32_t mask, about;
+            uint64_t order;
+            hl_scan_title(rd, 0u, (uint32_t)(te - tb), s.prm, mask, order, about);
+            mask_out[t0 + tid] = (uint16_t)mask;
+            order_out[t0 + tid] = order;
+            about_out[t0 + tid] = (uint8_t)about;
+        }
+        return;
+    }
+
+    // ---- stage: text -> LDS, alnum bits on the way; clear the per-title state
+    const uint32_t lo_rel = (uint32_t)(b0 - a0), hi_rel = (uint32_t)(b1 - a0);
+    const uint32_t n16 = (hi_rel + 15u) >> 4;
+    for (uint32_t i = tid; i < n16; i += HL_THREADS) {
+        const uint64_t src = a0 + 16ull * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src + 16 <= blob_bytes) v = *reinterpret_cast<const uint4 *>(blob + src);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; src + k < blob_bytes; ++k) w[k >> 2] |= (uint32_t)blob[src + k] << (8u * (k & 3u));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        reinterpret_cast<uint4 *>(s.text)[i] = v;
+        s.am[1 + i] = (uint16_t)(hl_alnum4(v.x) | (hl_alnum4(v.y) << 4) | (hl_alnum4(v.z) << 8) | (hl_alnum4(v.w) << 12));
+    }
+    if (tid < 8) {
+        s.am[1 + n16 + tid] = 0; // lookahead of the last chunks
+        if (tid == 0) s.am[0] = 0;
+        if (tid < HL_WAVES) s.q_cnt[tid] = 0;
+    }
+    for (uint32_t i = tid; i < (HL2_CHUNKS + 8) / 2; i += HL_THREADS) reinterpret_cast<uint32_t *>(s.ts)[i] = 0;
+    for (uint32_t i = tid; i < HL_TILE * HL_N_KW / 4; i += HL_THREADS)
+        reinterpret_cast<uint4 *>(&s.first[0][0])[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    s.res[tid] = 0;
+    {
+        const uint32_t i = tid < nt ? tid : nt;
+        s.off[tid] = (uint32_t)(offsets[t0 + i] - a0);
+        if (tid == 0) s.off[HL_TILE] = hi_rel;
+    }
+    __syncthreads();
+    if (tid < nt) { // title starts; ts[1 + o/16] bit o%16, addressed as dwords for the atomic
+        const uint32_t o = s.off[tid];
+        atomicOr(reinterpret_cast<uint32_t *>(s.ts) + ((16u + o) >> 5), 1u << ((16u + o) & 31u));
+    }
+    if (tid == 0) // the end of the last title cuts tokens too: the next tile's bytes follow in the window
+        atomicOr(reinterpret_cast<uint32_t *>(s.ts) + ((16u + hi_rel) >> 5), 1u << ((16u + hi_rel) & 31u));
+    __syncthreads();
+
+    // ---- token pass over 16-byte chunks
+    const uint32_t len_any = s.prm.len_any;
+    for (uint32_t c = tid; c < n16; c += HL_THREADS) {
+        const uint32_t c0 = c << 4;
+        const uint32_t A = (uint32_t)s.am[1 + c] | ((uint32_t)s.am[2 + c] << 16);
+        const uint32_t prev = (s.am[c] >> 15) & 1u;
+        const uint32_t T = (uint32_t)s.ts[1 + c] | ((uint32_t)s.ts[2 + c] << 16);
+        uint32_t starts = A & (~((A << 1) | prev) | T) & 0xFFFFu;
+        if (c0 < lo_rel) starts &= ~((1u << (lo_rel - c0)) - 1u); // bytes of the previous tile
+        if (hi_rel - c0 < 16u) starts &= (1u << (hi_rel - c0)) - 1u;
+        while (starts) {
+            const uint32_t b = __builtin_ctz(starts);
+            starts &= starts - 1;
+            uint32_t len = __builtin_ctz(~(A >> b) | 0x80000000u >> b); // run of alnum bits from b (<= 32 - b)
+            const uint32_t cut = T >> (b + 1u);
+            if (cut) { const uint32_t room = __builtin_ctz(cut) + 1u; len = len < room ? len : room; }
+            const uint32_t lc = len < HL_LONG ? len : HL_LONG;
+            if (!(((len_any | (len_any >> 16)) >> lc) & 1u)) continue;
+            const uint32_t pos = c0 + b;
+            const uint32_t ch = (s.text[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
+            const uint32_t ci = (ch - '0' < 10u) ? 26u + (ch - '0') : ((ch | 0x20u) - 'a');
+            const uint32_t fc = s.prm.first_char[ci];
+            const uint32_t kw = (fc >> lc) & 1u, pt = (fc >> (16u + lc)) & 1u;
+            if (!(kw | pt)) continue;
+            const uint32_t e = pos | (lc << 16) | (kw << 24) | (pt << 25);
+            const uint32_t qp = atomicAdd(&s.q_cnt[wv], 1u);
+            if (qp < HL_QCAP) s.queue[wv][qp] = e;
+            else hl2_verify(s, nt, e); // queue full: verify in place
+        }
+    }
+    // ---- dense pass over this wave's queue (a wave's LDS operations complete in order)
+    {
+        uint32_t nq = s.q_cnt[wv];
+        if (nq > HL_QCAP) nq = HL_QCAP;
+        for (uint32_t q = lane; q < nq; q += 64) hl2_verify(s, nt, s.queue[wv][q]);
+    }
+    __syncthreads();
+
+    // ---- one result per title
+    if (tid < nt) {
+        const uint32_t r = s.res[tid];
+        const uint32_t mask = r & 0xFFFFu;
+        uint32_t about = (r >> 16) & 1u;
+        uint64_t order = 0;
+        uint32_t rem = mask, nh = 0;
+        while (rem) { // first-occurrence order (dip.rs:266): repeatedly take the earliest position
+            uint32_t best = ~0u, bk = 0;
+            for (uint32_t m = rem; m; m &= m - 1) {
+                const uint32_t k = __builtin_ctz(m);
+                const uint32_t v = s.first[tid][k];
+                if (v < best) { best = v; bk = k; }
+            }
+            order |= (uint64_t)bk << (4u * nh);
+            ++nh;
+            rem &= ~(1u << bk);
+        }
+        if (s.prm.empty_form && !about) { // the empty form matches exactly the titles without words
+            const uint32_t tb = s.off[tid], te = s.off[tid + 1];
+            uint32_t any = 0;
+            for (uint32_t p = tb; p < te && !any; ++p) any = (s.am[1 + (p >> 4)] >> (p & 15u)) & 1u;
+            if (!any) about = 1;
+        }
+        mask_out[t0 + tid] = (uint16_t)mask;
+        order_out[t0 + tid] = order;
+        about_out[t0 + tid] = (uint8_t)about;
+    }
+}
+
 // ---------------------------------------------------------------- host
 static bool hl_word_char(uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z'); }
 
@@ -263,6 +493,18 @@ static int hl_build_params(HlParams &prm, const uint8_t *ticker, uint64_t ticker
         OI_CHECK(add(tmp.data(), l));
     }
     prm.n_patterns = np;
+    // (first char, length) filter of the byte-parallel kernel
+    auto char_index = [](uint8_t c) -> uint32_t { return (c >= '0' && c <= '9') ? 26u + (c - '0') : (uint32_t)(c - 'a'); };
+    for (int k = 0; k < HL_N_KW; ++k)
+        prm.first_char[char_index((uint8_t)kCatalyst[k][0])] |= 1u << strlen(kCatalyst[k]);
+    for (uint32_t p = 0; p < np; ++p) {
+        const uint8_t *pt = prm.pat + prm.pat_off[p];
+        const uint32_t pl = prm.pat_off[p + 1] - prm.pat_off[p];
+        uint32_t w = 0;
+        while (w < pl && pt[w] != ' ') ++w;
+        prm.first_char[char_index(pt[0])] |= 1u << (16u + (w < HL_LONG ? w : HL_LONG));
+    }
+    for (int i = 0; i < 36; ++i) prm.len_any |= prm.first_char[i];
     return OI_OK;
 }
 
@@ -278,9 +520,14 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     OI_CHECK(dp.ensure(sizeof(HlParams)));
     OI_HIP_CHECK(hipMemcpyAsync(dp.p, &prm, sizeof(HlParams), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t grid = (uint32_t)((n + HL_TILE - 1) / HL_TILE);
+    static const bool v1 = getenv("OI_HEADLINE_V1") != nullptr; // one lane per title (kept for A/B runs)
     ctx->prof_begin("headline");
-    hipLaunchKernelGGL(headline_scan_kernel, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                       blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about);
+    if (v1)
+        hipLaunchKernelGGL(headline_scan_kernel, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                           blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about);
+    else
+        hipLaunchKernelGGL(headline_scan_kernel2, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                           blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about);
     ctx->prof_end("headline");
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
