@@ -28,6 +28,7 @@
 #define HL_MAX_PATTERNS 32
 #define HL_KW_SLOTS 32
 #define HL_N_KW 16
+#define HL_LONG 14u // token length class "14 or more" of the byte-parallel kernel
 
 struct __attribute__((aligned(16))) HlParams {
     uint32_t n_patterns;
@@ -44,8 +45,11 @@ struct __attribute__((aligned(16))) HlParams {
     // bits 0..15 = lengths L for which a keyword starts with that char; bits 16..31 = length classes
     // min(L, HL_LONG) of the first words of the company patterns starting with it.
     uint32_t first_char[40];
-    uint32_t len_any; // OR of all first_char entries
-    uint32_t pad2[3];
+    // first word of each pattern, packed like a keyword (bytes 0..7 / 8..15); words of HL_LONG or more
+    // bytes are not packed (pw_len = 0) and always go to the byte walker
+    uint64_t pw_lo[HL_MAX_PATTERNS], pw_hi[HL_MAX_PATTERNS];
+    uint8_t pw_len[HL_MAX_PATTERNS];  // length of the first word, 0 if >= HL_LONG
+    uint8_t pw_only[HL_MAX_PATTERNS]; // 1: the pattern is that single word
 };
 static_assert(sizeof(HlParams) % 16 == 0, "HlParams is copied as uint4");
 
@@ -198,16 +202,18 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
 // The tile's text is staged once; while it passes through registers every lane turns its 16 bytes
 // into 16 alnum bits, so the token pass works on bitmaps: token starts, token lengths and the cut
 // at title boundaries are a handful of bit operations per 16-byte chunk.  A token becomes a
-// candidate only if (first char, length) can begin a keyword or a company pattern; candidates go
-// to a per-wave LDS queue and are verified in a dense pass (packed compare against the perfect
-// hash for keywords, hl_match_at for patterns).  Hits are rare, so their cost -- a binary search
-// for the title, an LDS atomicOr on its mask and an atomicMin on the first position of that
-// keyword -- stays off the streaming path.
-#define HL_LONG 14u              // length class "14 or more"
+// candidate only if (first char, length) can begin a keyword or a company pattern -- a 256-bit
+// Bloom filter held in registers, probed with the first char taken from the lane's own staged
+// registers, so the streaming loop reads no LDS per token.  Candidates go to a per-wave LDS queue
+// and are verified in a dense pass (packed compare against the perfect hash for keywords,
+// hl_match_at for patterns).  Hits are rare: each becomes a node in a per-title list (one CAS on
+// the title's result word), which the title's lane folds into mask and first-occurrence order.
 #define HL_QCAP 192
 #define HL_WAVES (HL_THREADS / 64)
 #define HL2_TEXT_BYTES (32 * 1024)
 #define HL2_CHUNKS (HL2_TEXT_BYTES / 16)
+#define HL2_PER_LANE (HL2_CHUNKS / HL_THREADS) // 16-byte chunks a lane stages and scans
+#define HL2_NODES 512u                         // keyword hits per tile before the tile is redone lane-per-title
 
 struct Hl2Shared {
     HlParams prm;
@@ -215,11 +221,15 @@ struct Hl2Shared {
     uint16_t am[HL2_CHUNKS + 8];           // am[1 + c] = alnum bits of chunk c; am[0] = 0
     uint16_t ts[HL2_CHUNKS + 8];           // ts[1 + c] = title-start bits of chunk c
     uint32_t off[HL_TILE + 1];             // title offsets relative to the window
-    uint32_t res[HL_TILE];                 // bits 0..15 keyword mask, bit 16 about-company
-    alignas(16) uint32_t first[HL_TILE][HL_N_KW]; // window position of each keyword's first occurrence
+    uint32_t res[HL_TILE];                 // bits 0..15 keyword mask, bit 16 about-company, bits 17.. head node + 1
+    uint32_t node[HL2_NODES];              // keyword (4 bits) | pos << 4 | (next node + 1) << 19
+    uint8_t tchunk[HL2_CHUNKS];            // title owning the first byte of each chunk (0 before the first title)
+    uint32_t ctab[256];                    // by first byte of a token: prm.first_char of its class, 0 if not alnum
+    uint32_t n_nodes;
     uint32_t q_cnt[HL_WAVES];
-    uint32_t queue[HL_WAVES][HL_QCAP];     // pos | lenclass << 16 | is_kw << 24 | is_pat << 25
+    uint32_t queue[HL_WAVES][HL_QCAP];     // pos | lenclass << 16
 };
+static_assert(sizeof(Hl2Shared) <= 53 * 1024, "three workgroups per CU");
 
 __device__ static inline uint32_t hl_alnum4(uint32_t w) { // one bit per byte
     const uint32_t hi = w & 0x80808080u;
@@ -232,47 +242,70 @@ __device__ static inline uint32_t hl_alnum4(uint32_t w) { // one bit per byte
     return (((f >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu;
 }
 
+__host__ __device__ static inline uint32_t hl_char_index(uint32_t c) { // a-z (either case) -> 0..25, 0-9 -> 26..35
+    return (c - '0' < 10u) ? 26u + (c - '0') : ((c | 0x20u) - 'a');
+}
+
 __device__ static inline uint32_t hl_title_of(const Hl2Shared &s, uint32_t nt, uint32_t pos) {
-    // largest j < nt with off[j] <= pos (empty titles share an offset; the last of them owns the byte)
-    uint32_t lo = 0, hi = nt; // invariant: off[lo] <= pos < off[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s.off[mid] <= pos) lo = mid;
-        else hi = mid;
-    }
-    return lo;
+    // largest j < nt with off[j] <= pos (empty titles share an offset; the last of them owns the byte):
+    // start from the title owning the chunk's first byte, step over the titles that begin before pos
+    uint32_t j = s.tchunk[pos >> 4];
+    while (j + 1u < nt && s.off[j + 1u] <= pos) ++j;
+    return j;
 }
 
 __device__ static void hl2_verify(Hl2Shared &s, uint32_t nt, uint32_t e) {
-    const uint32_t pos = e & 0xFFFFu, lc = (e >> 16) & 0xFFu;
-    const uint32_t j = hl_title_of(s, nt, pos);
-    if (e & (1u << 24)) { // keyword: lc is the exact length, 3..13
-        const uint32_t wi = pos >> 2, sh = pos & 3u;
-        const uint32_t x0 = s.text[wi], x1 = s.text[wi + 1], x2 = s.text[wi + 2], x3 = s.text[wi + 3], x4 = s.text[wi + 4];
-        // every byte inside the token is ASCII alphanumeric: |0x20 lowercases letters, keeps digits
-        const uint64_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh) | 0x20202020u;
-        const uint64_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh) | 0x20202020u;
-        const uint64_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh) | 0x20202020u;
-        const uint64_t t3 = __builtin_amdgcn_alignbyte(x4, x3, sh) | 0x20202020u;
-        uint64_t lo = t0 | (t1 << 32), hi = t2 | (t3 << 32);
-        if (lc < 8) { lo &= (1ull << (8u * lc)) - 1ull; hi = 0; }
-        else if (lc == 8) hi = 0;
-        else hi &= (1ull << (8u * (lc - 8u))) - 1ull;
+    const uint32_t pos = e & 0xFFFFu, lc = e >> 16;
+    const uint32_t wi = pos >> 2, sh = pos & 3u;
+    const uint32_t x0 = s.text[wi], x1 = s.text[wi + 1], x2 = s.text[wi + 2], x3 = s.text[wi + 3], x4 = s.text[wi + 4];
+    const uint32_t fc = s.ctab[__builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFu];
+    // the token, lowercased and packed: every byte inside it is ASCII alphanumeric, so |0x20 lowercases
+    // letters and keeps digits.  Exact for lc < HL_LONG; longer tokens are never compared packed.
+    const uint64_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh) | 0x20202020u;
+    const uint64_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh) | 0x20202020u;
+    const uint64_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh) | 0x20202020u;
+    const uint64_t t3 = __builtin_amdgcn_alignbyte(x4, x3, sh) | 0x20202020u;
+    uint64_t lo = t0 | (t1 << 32), hi = t2 | (t3 << 32);
+    if (lc < 8) { lo &= (1ull << (8u * lc)) - 1ull; hi = 0; }
+    else if (lc == 8) hi = 0;
+    else hi &= (1ull << (8u * (lc - 8u))) - 1ull;
+    uint32_t j = ~0u;
+    if ((fc >> lc) & 1u) { // keyword: lc is the exact length, 3..13
         const uint32_t sl = hl_kw_slot(lo, s.prm.kw_mult);
         if (s.prm.kw_lo[sl] == lo && s.prm.kw_hi[sl] == hi) {
             const uint32_t k = s.prm.kw_id[sl];
-            atomicOr(&s.res[j], 1u << k);
-            atomicMin(&s.first[j][k], pos);
+            j = hl_title_of(s, nt, pos);
+            const uint32_t idx = atomicAdd(&s.n_nodes, 1u);
+            if (idx < HL2_NODES) { // push onto title j's list; past the cap the tile is redone (n_nodes tells)
+                uint32_t old = s.res[j], assumed;
+                do {
+                    assumed = old;
+                    s.node[idx] = k | (pos << 4) | ((assumed >> 17) << 19);
+                    old = atomicCAS(&s.res[j], assumed, (assumed & 0x1FFFFu) | (1u << k) | ((idx + 1u) << 17));
+                } while (old != assumed);
+            }
         }
     }
-    if ((e & (1u << 25)) && !((s.res[j] >> 16) & 1u)) {
-        HlLdsReader rd{s.text};
-        const uint32_t end = s.off[j + 1];
-        const uint32_t l = hl_lower(rd(pos));
+    if ((fc >> (16u + lc)) & 1u) { // company pattern: first word by packed compare, the rest by the byte walker
         const uint32_t np = s.prm.n_patterns;
         for (uint32_t p = 0; p < np; ++p) {
-            const uint32_t o = s.prm.pat_off[p];
-            if (s.prm.pat[o] == l && hl_match_at(rd, pos, end, s.prm.pat + o, s.prm.pat_off[p + 1] - o)) {
+            const uint32_t wl = s.prm.pw_len[p];
+            bool hit;
+            if (wl) {
+                if (wl != lc || s.prm.pw_lo[p] != lo || s.prm.pw_hi[p] != hi) continue;
+                hit = s.prm.pw_only[p] != 0;
+            } else {
+                if (lc != HL_LONG) continue;
+                hit = false;
+            }
+            if (j == ~0u) j = hl_title_of(s, nt, pos);
+            if ((s.res[j] >> 16) & 1u) break;
+            if (!hit) {
+                HlLdsReader rd{s.text};
+                const uint32_t o = s.prm.pat_off[p];
+                hit = hl_match_at(rd, pos, s.off[j + 1], s.prm.pat + o, s.prm.pat_off[p + 1] - o);
+            }
+            if (hit) {
                 atomicOr(&s.res[j], 1u << 16);
                 break;
             }
@@ -286,12 +319,16 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel2(const uint8_
                                                                    const HlParams *__restrict__ params,
                                                                    uint16_t *__restrict__ mask_out,
                                                                    uint64_t *__restrict__ order_out,
-                                                                   uint8_t *__restrict__ about_out) {
+                                                                   uint8_t *__restrict__ about_out, int dbg,
+                                                                   unsigned long long *timing) {
     __shared__ __attribute__((aligned(16))) Hl2Shared s;
+    unsigned long long tk[6];
+    tk[0] = clock64();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t t0 = (uint64_t)blockIdx.x * HL_TILE;
     const uint32_t nt = (uint32_t)((t0 + HL_TILE < n) ? HL_TILE : n - t0);
     const uint64_t b0 = offsets[t0], b1 = offsets[t0 + nt];
+    const uint64_t my_off = offsets[t0 + (tid < nt ? tid : nt)];
     const uint64_t a0 = b0 & ~(uint64_t)15;
 
     for (uint32_t i = tid; i < sizeof(HlParams) / 16; i += HL_THREADS)
@@ -300,11 +337,11 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel2(const uint8_
     if ((b1 - a0) > HL2_TEXT_BYTES) { // oversized tile: one lane per title, straight from HBM
         __syncthreads();
         if (tid < nt) {
-            const uint64_t tb = offsets[t0 + tid], te = offsets[t0 + tid + 1];
-            HlMemReader rd{blob + tb};
+            const uint64_t te = offsets[t0 + tid + 1];
+            HlMemReader rd{blob + my_off};
             uint32_t mask, about;
             uint64_t order;
-            hl_scan_title(rd, 0u, (uint32_t)(te - tb), s.prm, mask, order, about);
+            hl_scan_title(rd, 0u, (uint32_t)(te - my_off), s.prm, mask, order, about);
             mask_out[t0 + tid] = (uint16_t)mask;
             order_out[t0 + tid] = order;
             about_out[t0 + tid] = (uint8_t)about;
@@ -312,109 +349,149 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel2(const uint8_
         return;
     }
 
-    // ---- stage: text -> LDS, alnum bits on the way; clear the per-title state
+    // ---- stage: all of the lane's loads in flight at once; text -> LDS, alnum bits on the way
     const uint32_t lo_rel = (uint32_t)(b0 - a0), hi_rel = (uint32_t)(b1 - a0);
     const uint32_t n16 = (hi_rel + 15u) >> 4;
-    for (uint32_t i = tid; i < n16; i += HL_THREADS) {
-        const uint64_t src = a0 + 16ull * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (src + 16 <= blob_bytes) v = *reinterpret_cast<const uint4 *>(blob + src);
-        else {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (uint32_t k = 0; src + k < blob_bytes; ++k) w[k >> 2] |= (uint32_t)blob[src + k] << (8u * (k & 3u));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+    uint4 v[HL2_PER_LANE];
+    if (a0 + 16ull * n16 <= blob_bytes) { // every 16-byte piece of the window lies inside the blob
+#pragma unroll
+        for (uint32_t k = 0; k < HL2_PER_LANE; ++k) {
+            const uint32_t i = tid + k * HL_THREADS;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (i < n16) v[k] = *reinterpret_cast<const uint4 *>(blob + a0 + 16ull * i);
         }
-        reinterpret_cast<uint4 *>(s.text)[i] = v;
-        s.am[1 + i] = (uint16_t)(hl_alnum4(v.x) | (hl_alnum4(v.y) << 4) | (hl_alnum4(v.z) << 8) | (hl_alnum4(v.w) << 12));
+    } else { // the blob ends inside the last piece: byte loads there
+        for (uint32_t k = 0; k < HL2_PER_LANE; ++k) {
+            const uint32_t i = tid + k * HL_THREADS;
+            const uint64_t src = a0 + 16ull * i;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (i < n16)
+                for (uint32_t q = 0; q < 16 && src + q < blob_bytes; ++q) w[q >> 2] |= (uint32_t)blob[src + q] << (8u * (q & 3u));
+            v[k] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
+    // per-title state while the loads fly
+    for (uint32_t i = tid; i < (HL2_CHUNKS + 8) / 2; i += HL_THREADS) reinterpret_cast<uint32_t *>(s.ts)[i] = 0;
+    s.res[tid] = 0;
+    s.off[tid] = (uint32_t)(my_off - a0);
     if (tid < 8) {
         s.am[1 + n16 + tid] = 0; // lookahead of the last chunks
-        if (tid == 0) s.am[0] = 0;
+        if (tid == 0) { s.am[0] = 0; s.off[HL_TILE] = hi_rel; s.n_nodes = 0; s.tchunk[0] = 0; }
         if (tid < HL_WAVES) s.q_cnt[tid] = 0;
     }
-    for (uint32_t i = tid; i < (HL2_CHUNKS + 8) / 2; i += HL_THREADS) reinterpret_cast<uint32_t *>(s.ts)[i] = 0;
-    for (uint32_t i = tid; i < HL_TILE * HL_N_KW / 4; i += HL_THREADS)
-        reinterpret_cast<uint4 *>(&s.first[0][0])[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    s.res[tid] = 0;
-    {
-        const uint32_t i = tid < nt ? tid : nt;
-        s.off[tid] = (uint32_t)(offsets[t0 + i] - a0);
-        if (tid == 0) s.off[HL_TILE] = hi_rel;
+    s.ctab[tid] = hl_alnum(tid) ? params->first_char[hl_char_index(tid)] : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < HL2_PER_LANE; ++k) {
+        const uint32_t i = tid + k * HL_THREADS;
+        if (i < n16) {
+            reinterpret_cast<uint4 *>(s.text)[i] = v[k];
+            s.am[1 + i] = (uint16_t)(hl_alnum4(v[k].x) | (hl_alnum4(v[k].y) << 4) | (hl_alnum4(v[k].z) << 8) |
+                                     (hl_alnum4(v[k].w) << 12));
+        }
     }
     __syncthreads();
+    tk[1] = clock64();
     if (tid < nt) { // title starts; ts[1 + o/16] bit o%16, addressed as dwords for the atomic
-        const uint32_t o = s.off[tid];
+        const uint32_t o = (uint32_t)(my_off - a0);
         atomicOr(reinterpret_cast<uint32_t *>(s.ts) + ((16u + o) >> 5), 1u << ((16u + o) & 31u));
     }
     if (tid == 0) // the end of the last title cuts tokens too: the next tile's bytes follow in the window
         atomicOr(reinterpret_cast<uint32_t *>(s.ts) + ((16u + hi_rel) >> 5), 1u << ((16u + hi_rel) & 31u));
+    if (tid < nt) { // chunks whose first byte lies in this title
+        const uint32_t tb = s.off[tid], te = s.off[tid + 1];
+        if (te > tb)
+            for (uint32_t c = (tb + 15u) >> 4; c <= ((te - 1u) >> 4); ++c) s.tchunk[c] = (uint8_t)tid;
+    }
     __syncthreads();
 
-    // ---- token pass over 16-byte chunks
-    const uint32_t len_any = s.prm.len_any;
-    for (uint32_t c = tid; c < n16; c += HL_THREADS) {
-        const uint32_t c0 = c << 4;
-        const uint32_t A = (uint32_t)s.am[1 + c] | ((uint32_t)s.am[2 + c] << 16);
-        const uint32_t prev = (s.am[c] >> 15) & 1u;
-        const uint32_t T = (uint32_t)s.ts[1 + c] | ((uint32_t)s.ts[2 + c] << 16);
-        uint32_t starts = A & (~((A << 1) | prev) | T) & 0xFFFFu;
-        if (c0 < lo_rel) starts &= ~((1u << (lo_rel - c0)) - 1u); // bytes of the previous tile
-        if (hi_rel - c0 < 16u) starts &= (1u << (hi_rel - c0)) - 1u;
-        while (starts) {
-            const uint32_t b = __builtin_ctz(starts);
-            starts &= starts - 1;
-            uint32_t len = __builtin_ctz(~(A >> b) | 0x80000000u >> b); // run of alnum bits from b (<= 32 - b)
-            const uint32_t cut = T >> (b + 1u);
-            if (cut) { const uint32_t room = __builtin_ctz(cut) + 1u; len = len < room ? len : room; }
-            const uint32_t lc = len < HL_LONG ? len : HL_LONG;
-            if (!(((len_any | (len_any >> 16)) >> lc) & 1u)) continue;
-            const uint32_t pos = c0 + b;
-            const uint32_t ch = (s.text[pos >> 2] >> (8u * (pos & 3u))) & 0xFFu;
-            const uint32_t ci = (ch - '0' < 10u) ? 26u + (ch - '0') : ((ch | 0x20u) - 'a');
-            const uint32_t fc = s.prm.first_char[ci];
-            const uint32_t kw = (fc >> lc) & 1u, pt = (fc >> (16u + lc)) & 1u;
-            if (!(kw | pt)) continue;
-            const uint32_t e = pos | (lc << 16) | (kw << 24) | (pt << 25);
-            const uint32_t qp = atomicAdd(&s.q_cnt[wv], 1u);
-            if (qp < HL_QCAP) s.queue[wv][qp] = e;
-            else hl2_verify(s, nt, e); // queue full: verify in place
+    // ---- token pass over the lane's own chunks
+    tk[2] = clock64();
+    if (dbg == 1) goto finalize;
+#pragma unroll 1
+    for (uint32_t k = 0; k < HL2_PER_LANE; ++k) {
+        const uint32_t c = tid + k * HL_THREADS;
+        if (c < n16) {
+            const uint32_t c0 = c << 4;
+            const uint32_t A = (uint32_t)s.am[1 + c] | ((uint32_t)s.am[2 + c] << 16);
+            const uint32_t prev = (s.am[c] >> 15) & 1u;
+            const uint32_t T = (uint32_t)s.ts[1 + c] | ((uint32_t)s.ts[2 + c] << 16);
+            uint32_t starts = A & (~((A << 1) | prev) | T) & 0xFFFFu;
+            if (c0 < lo_rel) starts &= ~((1u << (lo_rel - c0)) - 1u); // bytes of the previous tile
+            if (hi_rel - c0 < 16u) starts &= (1u << (hi_rel - c0)) - 1u;
+            // a token cannot continue into a non-alnum byte or across a title start; bit 31 bounds the search
+            const uint32_t Z = ~A | T | 0x80000000u;
+            const uint8_t *tbase = reinterpret_cast<const uint8_t *>(s.text) + c0;
+            while (starts) {
+                const uint32_t b = __builtin_ctz(starts);
+                starts &= starts - 1;
+                const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // exact below HL_LONG (b + 14 <= 31)
+                const uint32_t lc = len < HL_LONG ? len : HL_LONG;
+                const uint32_t fc = s.ctab[tbase[b]];
+                if (!((fc >> lc) & 0x10001u)) continue; // (first char, length) begins no keyword and no pattern
+                const uint32_t e = (c0 + b) | (lc << 16);
+                const uint32_t qp = atomicAdd(&s.q_cnt[wv], 1u);
+                if (qp < HL_QCAP) s.queue[wv][qp] = e;
+                else hl2_verify(s, nt, e); // queue full: verify in place
+            }
         }
     }
     // ---- dense pass over this wave's queue (a wave's LDS operations complete in order)
-    {
+    tk[3] = clock64();
+    if (dbg != 2) {
         uint32_t nq = s.q_cnt[wv];
         if (nq > HL_QCAP) nq = HL_QCAP;
         for (uint32_t q = lane; q < nq; q += 64) hl2_verify(s, nt, s.queue[wv][q]);
     }
+    tk[4] = clock64();
+finalize:
     __syncthreads();
+    tk[5] = clock64();
 
     // ---- one result per title
     if (tid < nt) {
-        const uint32_t r = s.res[tid];
-        const uint32_t mask = r & 0xFFFFu;
-        uint32_t about = (r >> 16) & 1u;
+        uint32_t mask, about;
         uint64_t order = 0;
-        uint32_t rem = mask, nh = 0;
-        while (rem) { // first-occurrence order (dip.rs:266): repeatedly take the earliest position
-            uint32_t best = ~0u, bk = 0;
-            for (uint32_t m = rem; m; m &= m - 1) {
-                const uint32_t k = __builtin_ctz(m);
-                const uint32_t v = s.first[tid][k];
-                if (v < best) { best = v; bk = k; }
+        if (s.n_nodes > HL2_NODES) { // more hits than nodes (a title repeating a keyword hundreds of times)
+            HlLdsReader rd{s.text};
+            hl_scan_title(rd, s.off[tid], s.off[tid + 1], s.prm, mask, order, about);
+        } else {
+            const uint32_t r = s.res[tid];
+            mask = r & 0xFFFFu;
+            about = (r >> 16) & 1u;
+            uint32_t rem = mask, nh = 0;
+            while (rem && nh < HL_N_KW) { // first-occurrence order (dip.rs:266): take the earliest remaining hit
+                uint32_t best = ~0u;
+                for (uint32_t nd = r >> 17, steps = 0; nd && steps < HL2_NODES; ++steps) {
+                    const uint32_t x = s.node[nd - 1u];
+                    if (((rem >> (x & 15u)) & 1u) && (x & 0x7FFFFu) < best) best = x & 0x7FFFFu; // pos in the high bits decides
+                    nd = x >> 19;
+                }
+                const uint32_t bk = best & 15u;
+                order |= (uint64_t)bk << (4u * nh);
+                ++nh;
+                rem &= ~(1u << bk);
             }
-            order |= (uint64_t)bk << (4u * nh);
-            ++nh;
-            rem &= ~(1u << bk);
-        }
-        if (s.prm.empty_form && !about) { // the empty form matches exactly the titles without words
-            const uint32_t tb = s.off[tid], te = s.off[tid + 1];
-            uint32_t any = 0;
-            for (uint32_t p = tb; p < te && !any; ++p) any = (s.am[1 + (p >> 4)] >> (p & 15u)) & 1u;
-            if (!any) about = 1;
+            if (s.prm.empty_form && !about) { // the empty form matches exactly the titles without words
+                const uint32_t tb = s.off[tid], te = s.off[tid + 1];
+                uint32_t any = 0;
+                for (uint32_t p = tb; p < te && !any; ++p) any = (s.am[1 + (p >> 4)] >> (p & 15u)) & 1u;
+                if (!any) about = 1;
+            }
         }
         mask_out[t0 + tid] = (uint16_t)mask;
         order_out[t0 + tid] = order;
         about_out[t0 + tid] = (uint8_t)about;
+    }
+    if (timing && lane == 0 && (blockIdx.x & 63u) == 0) { // development aid, one workgroup in 64: cycles per phase, summed over waves (OI_HEADLINE_TIMING)
+        const unsigned long long t6 = clock64();
+        atomicAdd(&timing[0], tk[1] - tk[0]); // stage
+        atomicAdd(&timing[1], tk[2] - tk[1]); // title-start bits
+        atomicAdd(&timing[2], tk[3] - tk[2]); // token pass
+        atomicAdd(&timing[3], tk[4] - tk[3]); // verify pass
+        atomicAdd(&timing[4], tk[5] - tk[4]); // wait at the barrier
+        atomicAdd(&timing[5], t6 - tk[5]);    // results
+        atomicAdd(&timing[6], 1ull);
+        atomicAdd(&timing[7], (unsigned long long)s.q_cnt[wv]);
     }
 }
 
@@ -494,17 +571,26 @@ static int hl_build_params(HlParams &prm, const uint8_t *ticker, uint64_t ticker
     }
     prm.n_patterns = np;
     // (first char, length) filter of the byte-parallel kernel
-    auto char_index = [](uint8_t c) -> uint32_t { return (c >= '0' && c <= '9') ? 26u + (c - '0') : (uint32_t)(c - 'a'); };
-    for (int k = 0; k < HL_N_KW; ++k)
-        prm.first_char[char_index((uint8_t)kCatalyst[k][0])] |= 1u << strlen(kCatalyst[k]);
+    auto mark = [&](uint8_t c, uint32_t lc, uint32_t shift) {
+        const uint32_t ci = hl_char_index(c);
+        prm.first_char[ci] |= 1u << (shift + lc);
+    };
+    for (int k = 0; k < HL_N_KW; ++k) mark((uint8_t)kCatalyst[k][0], (uint32_t)strlen(kCatalyst[k]), 0);
     for (uint32_t p = 0; p < np; ++p) {
         const uint8_t *pt = prm.pat + prm.pat_off[p];
         const uint32_t pl = prm.pat_off[p + 1] - prm.pat_off[p];
         uint32_t w = 0;
         while (w < pl && pt[w] != ' ') ++w;
-        prm.first_char[char_index(pt[0])] |= 1u << (16u + (w < HL_LONG ? w : HL_LONG));
+        mark(pt[0], w < HL_LONG ? w : HL_LONG, 16);
+        if (w < HL_LONG) {
+            prm.pw_len[p] = (uint8_t)w;
+            prm.pw_only[p] = (uint8_t)(w == pl);
+            for (uint32_t i = 0; i < w; ++i) {
+                if (i < 8) prm.pw_lo[p] |= (uint64_t)pt[i] << (8 * i);
+                else prm.pw_hi[p] |= (uint64_t)pt[i] << (8 * (i - 8));
+            }
+        }
     }
-    for (int i = 0; i < 36; ++i) prm.len_any |= prm.first_char[i];
     return OI_OK;
 }
 
@@ -520,6 +606,14 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     OI_CHECK(dp.ensure(sizeof(HlParams)));
     OI_HIP_CHECK(hipMemcpyAsync(dp.p, &prm, sizeof(HlParams), hipMemcpyHostToDevice, ctx->stream));
     const uint32_t grid = (uint32_t)((n + HL_TILE - 1) / HL_TILE);
+    static const int dbg = getenv("OI_HEADLINE_DBG") ? atoi(getenv("OI_HEADLINE_DBG")) : 0; // ablations (wrong results)
+    unsigned long long *d_timing = nullptr;
+    if (getenv("OI_HEADLINE_TIMING")) {
+        DevBuf &tb = ctx->buf("hl_timing");
+        OI_CHECK(tb.ensure(8 * sizeof(unsigned long long)));
+        OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        d_timing = tb.as<unsigned long long>();
+    }
     static const bool v1 = getenv("OI_HEADLINE_V1") != nullptr; // one lane per title (kept for A/B runs)
     ctx->prof_begin("headline");
     if (v1)
@@ -527,8 +621,16 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
                            blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about);
     else
         hipLaunchKernelGGL(headline_scan_kernel2, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                           blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about);
+                           blob_bytes, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
     ctx->prof_end("headline");
+    if (d_timing) {
+        unsigned long long h[8];
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        OI_HIP_CHECK(hipMemcpy(h, d_timing, sizeof(h), hipMemcpyDeviceToHost));
+        const double w = h[6] ? (double)h[6] : 1.0;
+        fprintf(stderr, "[headline timing] cycles/wave: stage %.0f tsbits %.0f token %.0f verify %.0f barrier %.0f results %.0f | "
+                        "waves %llu queue/wave %.1f\n", h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6], h[7] / w);
+    }
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

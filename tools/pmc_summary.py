@@ -10,7 +10,8 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KEEP = ("cosine", "bm25_block", "select_topk", "rrf_kernel", "lexicon_kernel", "lists_to_pool")
+KEEP = ("cosine", "bm25_block", "select_topk", "rrf_kernel", "lexicon_kernel", "lists_to_pool", "headline_scan",
+        "social_summary")
 agg = defaultdict(lambda: defaultdict(float))
 for f in sorted(glob.glob(out + "/pass*/*/*counter_collection.csv")):
     seen = set()
