@@ -53,7 +53,7 @@ struct __attribute__((aligned(16))) HlHot {
     uint32_t n_patterns;
     uint32_t empty_form;
     uint32_t kw_mult;
-    uint32_t pad0;
+    uint32_t min_len; // shortest keyword / pattern first word: shorter tokens are dropped before the token loop
     uint64_t kw_lo[HL_KW_SLOTS]; // keyword bytes 0..7 packed little-endian, 0 = empty slot
     uint64_t kw_hi[HL_KW_SLOTS]; // bytes 8..15
     uint64_t wd_lo[HL_MAX_WORDS], wd_hi[HL_MAX_WORDS]; // pattern words, packed the same way
@@ -319,7 +319,39 @@ __device__ static void hl_verify(HlShared &s, const HlParams *prm, uint32_t nt, 
     }
 }
 
-__global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t *__restrict__ blob,
+// The piece the blob ends in, zero-filled past the end.
+__device__ __noinline__ uint4 hl_load_tail(const uint8_t *blob, uint64_t src, uint64_t blob_bytes) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t q = 0; q < 16 && src + q < blob_bytes; ++q) w[q >> 2] |= (uint32_t)blob[src + q] << (8u * (q & 3u));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// A lane's share of a tile's window: 16-byte pieces tid, tid + 256, ... of [a0, a0 + 16 * n16).
+__device__ __forceinline__ void hl_load_text(const uint8_t *__restrict__ blob, uint64_t blob_bytes, uint64_t a0,
+                                             uint32_t n16, uint32_t tid, uint4 (&v)[HL_PER_LANE]) {
+    if (n16 == 0) return;
+    const uint64_t whole = (blob_bytes - a0) >> 4; // pieces wholly inside the blob (a0 < blob_bytes here)
+    const uint32_t full = whole < n16 ? (uint32_t)whole : n16;
+    if (full) {
+        // No branch around the loads (a lane past the end re-reads the last piece and ignores it), so
+        // all of them are in flight together instead of each waiting at its own join.
+#pragma unroll
+        for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
+            const uint32_t i = tid + k * HL_THREADS;
+            v[k] = *reinterpret_cast<const uint4 *>(blob + a0 + 16ull * (i < full ? i : full - 1u));
+        }
+    }
+    if (full < n16) { // the blob ends inside piece `full` (the last one): its owner loads it by bytes
+#pragma unroll
+        for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
+            if (tid + k * HL_THREADS == full) v[k] = hl_load_tail(blob, a0 + 16ull * full, blob_bytes);
+        }
+    }
+}
+
+template <bool TM> // TM: per-phase cycle counters (development aid)
+// (4 waves per SIMD: the LDS budget allows four workgroups per CU, the registers must too.)
+__global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint8_t *__restrict__ blob,
                                                                   const uint64_t *__restrict__ offsets, uint64_t n,
                                                                   uint64_t blob_bytes, uint32_t tile,
                                                                   const HlParams *__restrict__ params,
@@ -328,8 +360,8 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
                                                                   uint8_t *__restrict__ about_out, int dbg,
                                                                   unsigned long long *timing) {
     __shared__ __attribute__((aligned(16))) HlShared s;
-    unsigned long long tk[6];
-    tk[0] = clock64();
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    if (TM) tk[0] = clock64();
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t t0 = (uint64_t)blockIdx.x * tile;
     const uint32_t nt = (uint32_t)((t0 + tile < n) ? tile : n - t0);
@@ -359,24 +391,7 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
     const uint32_t lo_rel = (uint32_t)(b0 - a0), hi_rel = (uint32_t)(b1 - a0);
     const uint32_t n16 = (hi_rel + 15u) >> 4;
     uint4 v[HL_PER_LANE];
-    if (a0 + 16ull * n16 <= blob_bytes) { // every 16-byte piece of the window lies inside the blob
-#pragma unroll
-        for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
-            const uint32_t i = tid + k * HL_THREADS;
-            v[k] = make_uint4(0, 0, 0, 0);
-            if (i < n16) v[k] = *reinterpret_cast<const uint4 *>(blob + a0 + 16ull * i);
-        }
-    } else { // the blob ends inside the last piece: byte loads there
-#pragma unroll
-        for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
-            const uint32_t i = tid + k * HL_THREADS;
-            const uint64_t src = a0 + 16ull * i;
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (i < n16)
-                for (uint32_t q = 0; q < 16 && src + q < blob_bytes; ++q) w[q >> 2] |= (uint32_t)blob[src + q] << (8u * (q & 3u));
-            v[k] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
+    hl_load_text(blob, blob_bytes, a0, n16, tid, v);
     // per-title state while the loads fly
     for (uint32_t i = tid; i < (HL_CHUNKS + 8) / 2; i += HL_THREADS) reinterpret_cast<uint32_t *>(s.ts)[i] = 0;
     s.res[tid] = 0;
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
         }
     }
     __syncthreads();
-    tk[1] = clock64();
+    if (TM) tk[1] = clock64();
     if (tid < nt) {
         const uint32_t tb = s.off[tid], te = s.off[tid + 1];
         // title starts: ts[1 + o/16] bit o%16, addressed as dwords for the atomic
@@ -407,60 +422,56 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
     if (tid == 0) // the end of the last title cuts tokens too: the next tile's bytes follow in the window
         atomicOr(reinterpret_cast<uint32_t *>(s.ts) + ((16u + hi_rel) >> 5), 1u << ((16u + hi_rel) & 31u));
     __syncthreads();
-    tk[2] = clock64();
+    if (TM) tk[2] = clock64();
 
     // ---- token pass over the lane's chunks.  The loop is wave-uniform: candidates are compacted with
     // ballots into this wave's ring (no atomics), and whenever 64 are waiting a full wave verifies them.
     uint32_t head = 0, tail = 0; // wave-uniform ring cursors
+    const uint32_t min_len = s.hot.min_len;
     if (dbg != 1) {
         for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
             if (wv * 64u + k * HL_THREADS >= n16) break; // uniform: the wave has no chunk left
             const uint32_t c = tid + k * HL_THREADS, c0 = c << 4;
             uint32_t starts = 0, Z = 0;
-            uint4 tx = make_uint4(0, 0, 0, 0);
             if (c < n16) {
                 const uint32_t A = hl_am32(s, c);
                 const uint32_t prev = (s.am[c] >> 15) & 1u;
                 const uint32_t T = (uint32_t)s.ts[1 + c] | ((uint32_t)s.ts[2 + c] << 16);
-                tx = reinterpret_cast<const uint4 *>(s.text)[c];
                 starts = A & (~((A << 1) | prev) | T) & 0xFFFFu;
                 if (c0 < lo_rel) starts &= ~((1u << (lo_rel - c0)) - 1u); // bytes of the previous tile
                 if (hi_rel - c0 < 16u) starts &= (1u << (hi_rel - c0)) - 1u;
                 // a token cannot continue into a non-alnum byte or across a title start; bit 31 bounds the search
                 Z = ~A | T | 0x80000000u;
+                // tokens shorter than every keyword and every pattern's first word never enter the loop
+                if (min_len >= 2u) starts &= ~(Z >> 1);
+                if (min_len >= 3u) starts &= ~(Z >> 2);
             }
-            while (__ballot(starts != 0)) { // two tokens per lane per trip: their table reads overlap
-                bool cand[2] = {false, false};
-                uint32_t e[2] = {0, 0};
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (starts) {
-                        const uint32_t b = __builtin_ctz(starts);
-                        starts &= starts - 1;
-                        const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // exact below HL_LONG (b + 14 <= 31)
-                        const uint32_t lc = len < HL_LONG ? len : HL_LONG;
-                        const uint32_t w = (b & 8u) ? ((b & 4u) ? tx.w : tx.z) : ((b & 4u) ? tx.y : tx.x);
-                        const uint32_t fc = s.ctab[(w >> (8u * (b & 3u))) & 0xFFu];
-                        cand[u] = ((fc >> lc) & 0x10001u) != 0; // (first char, length) begins a keyword or a pattern
-                        e[u] = (c0 + b) | (lc << 16);
-                    }
+            const uint8_t *tbytes = reinterpret_cast<const uint8_t *>(s.text) + c0;
+            while (__ballot(starts != 0)) {
+                bool cand = false;
+                uint32_t e = 0;
+                if (starts) {
+                    const uint32_t b = __builtin_ctz(starts);
+                    starts &= starts - 1;
+                    const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // exact below HL_LONG (b + 14 <= 31)
+                    const uint32_t lc = len < HL_LONG ? len : HL_LONG;
+                    const uint32_t fc = s.ctab[tbytes[b]];
+                    cand = ((fc >> lc) & 0x10001u) != 0; // (first char, length) begins a keyword or a pattern
+                    e = (c0 + b) | (lc << 16);
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const uint64_t m = __ballot(cand[u]);
-                    if (cand[u]) {
-                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        s.ring[wv][(tail + below) & (HL_RING - 1u)] = e[u];
-                    }
-                    tail += (uint32_t)__popcll(m);
-                    if (tail - head >= 64u && dbg != 2) { // a wave's LDS operations complete in order
-                        hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)]);
-                        head += 64u;
-                    }
+                const uint64_t m = __ballot(cand);
+                if (cand) {
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s.ring[wv][(tail + below) & (HL_RING - 1u)] = e;
+                }
+                tail += (uint32_t)__popcll(m);
+                if (tail - head >= 64u && dbg != 2) { // a wave's LDS operations complete in order
+                    hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)]);
+                    head += 64u;
                 }
             }
         }
-        tk[3] = clock64();
+        if (TM) tk[3] = clock64();
         if (dbg != 2) {
             while (head < tail) {
                 if (head + lane < tail) hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)]);
@@ -468,11 +479,11 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
             }
         }
     } else {
-        tk[3] = clock64();
+        if (TM) tk[3] = clock64();
     }
-    tk[4] = clock64();
+    if (TM) tk[4] = clock64();
     __syncthreads();
-    tk[5] = clock64();
+    if (TM) tk[5] = clock64();
 
     // ---- one result per title
     if (tid < nt) {
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(HL_THREADS) void headline_scan_kernel(const uint8_t
         order_out[t0 + tid] = order;
         about_out[t0 + tid] = (uint8_t)about;
     }
-    if (timing && lane == 0 && (blockIdx.x & 63u) == 0) { // development aid, one workgroup in 64 (OI_HEADLINE_TIMING)
+    if (TM && timing && lane == 0 && (blockIdx.x & 63u) == 0) { // development aid, one workgroup in 64 (OI_HEADLINE_TIMING)
         const unsigned long long t6 = clock64();
         atomicAdd(&timing[0], tk[1] - tk[0]); // stage
         atomicAdd(&timing[1], tk[2] - tk[1]); // title-start bits, chunk owners
@@ -636,6 +647,9 @@ static int hl_build_params(HlParams &prm, const uint8_t *ticker, uint64_t ticker
         }
     }
     hot.pat_w0[np] = (uint8_t)nw;
+    hot.min_len = 3; // the shortest keywords ("cut", "fda")
+    for (uint32_t p = 0; p < np; ++p)
+        if (hot.pat_first_len[p] < hot.min_len) hot.min_len = hot.pat_first_len[p];
     return OI_OK;
 }
 
@@ -673,9 +687,12 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     if (v1)
         hipLaunchKernelGGL(headline_scan_kernel_v1, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
                            dp.as<HlParams>(), d_mask, d_order, d_about);
+    else if (d_timing)
+        hipLaunchKernelGGL(headline_scan_kernel<true>, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets,
+                           n, blob_bytes, tile, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
     else
-        hipLaunchKernelGGL(headline_scan_kernel, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                           blob_bytes, tile, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
+        hipLaunchKernelGGL(headline_scan_kernel<false>, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets,
+                           n, blob_bytes, tile, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
     ctx->prof_end("headline");
     OI_HIP_CHECK(hipGetLastError());
     if (d_timing) {
