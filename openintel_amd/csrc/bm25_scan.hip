@@ -11,15 +11,16 @@
 // Algorithmic bytes per batch: 4*T + 8*N (tokens + doc offsets); HBM-bound by construction.
 //
 //   phase 1  token-parallel: every lane loads 8 consecutive tokens (two 16-byte loads, fully
-//            coalesced) and tests each against a 4 KiB Bloom filter of the batch's terms in LDS (one
-//            LDS read per token); the ~5 % that pass are compacted per wave into the tile's hit array.
-//   link     one lane per hit: exact term -> slot lookup in the LDS hash table (2048 slots; Bloom false
-//            positives die here), the doc by binary search in the tile's LDS-staged offsets, and a push
+//            coalesced; the next step's loads are issued before this step is processed) and tests each
+//            against a 4 KiB Bloom filter of the batch's terms in LDS (one LDS read per token).  The ~5 %
+//            that pass are resolved to their term slot (LDS hash table; Bloom false positives die
+//            here) and compacted per wave into the tile's hit array as (slot, token index).
+//   link     one lane per hit: the doc by binary search in the tile's LDS-staged offsets, and a push
 //            on that doc's LDS linked list (atomicExch on the list head).
-//   phase 2  lane-per-hit: walk the hit's doc list; every query that uses a matched term is scored
-//            exactly once (f32 sum over its terms IN QUERY ORDER, tf counted
-//            from the list, impact from the doc length); survivors of the per-query threshold go to
-//            the workgroup's private pool segment (LDS fill counters, no global atomics).
+//   phase 2  one lane per DOC: the doc's list is folded once into (slot, tf) pairs in registers; every
+//            query using one of those terms is scored exactly once (f32 sum over its terms IN QUERY
+//            ORDER, impact from tf and the doc length); survivors of the per-query threshold go to the
+//            workgroup's private pool segment (LDS fill counters, no global atomics).
 #include <cstdlib>
 
 #include "oi_device.h"
@@ -28,13 +29,18 @@
 #define BS_THREADS 512
 #define BS_DPT 512          // docs per workgroup tile (one per lane in phase 2)
 #define BS_TPT 8            // tokens per thread and step in phase 1
+#define BS_PRE 4            // steps of a tile loaded before the first is scanned (a typical tile has 3)
 #define BS_HASH 2048        // term hash table slots (power of two)
 #define BS_MAX_TERMS 1024   // distinct batch terms (load factor <= 50 %)
 #define BS_MAX_Q 256        // queries per pass
 #define BS_MAX_QT 2048      // total (query, term) pairs per pass
-#define BS_HITCAP 4096      // hit entries per tile (typ. ~650); beyond: exact per-doc fallback
+#define BS_WAVE_HITS 384    // hit entries per wave and tile (typ. ~70); beyond: exact per-doc fallback
+#define BS_HITCAP (BS_WAVE_HITS * BS_THREADS / 64)
 #define BS_BLOOM_WORDS 1024  // 4 KiB: <= 1024 keys in 32768 bits -> < 3 % false positives
 #define BS_NIL 0xFFFFu
+#define BS_LONGQ 0xFFFEu
+#define BS_TF_SLOTS 4096    // (doc, term) -> tf table of a tile (typ. ~600 pairs; 2000 at 256 queries)
+#define BS_TF_EMPTY 0xFFFFFFFFu
 #define BS_K1 1.2f
 #define BS_B 0.75f
 
@@ -46,6 +52,10 @@ struct BsBatch { // built once per batch by bm25_scan_setup (global memory, ~40 
     uint32_t q_off[BS_MAX_Q + 1];   // CSR over queries: their terms' slots in query order
     uint32_t q_slot[BS_MAX_QT];     // slot or 0xFFFF (term outside the vocabulary: contributes nothing)
     uint32_t bloom[BS_BLOOM_WORDS]; // 32768-bit filter over the batch's term ids (1 hash)
+    // queries of at most 4 terms, ready for registers: their slots (0xFFFF: no term) and idfs in query
+    // order; qp_slots[q][0] = BS_LONGQ marks a longer query (scored from q_slot / idf instead)
+    uint16_t qp_slots[BS_MAX_Q][4];
+    float qp_idf[BS_MAX_Q][4];
     uint32_t n_queries, n_pairs, error, pad;
 };
 __device__ __forceinline__ uint32_t bs_bloom_bit(uint32_t t) { return (t * 0x85EBCA77u) >> 17; } // 15 bits
@@ -127,26 +137,33 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
             const uint32_t slot = out->q_slot[p];
             if (slot != BS_NIL) out->users[atomicAdd(&cnt[slot], 1u)] = (q << 16) | (p - lo);
         }
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t slot = lo + j < hi ? out->q_slot[lo + j] : BS_NIL;
+            out->qp_slots[q][j] = (uint16_t)slot;
+            out->qp_idf[q][j] = slot != BS_NIL ? out->idf[slot] : 0.f;
+        }
+        if (hi - lo > 4) out->qp_slots[q][0] = (uint16_t)BS_LONGQ;
     }
 }
 
 // ------------------------------------------------------------------ the scan
 struct BsShared {
     uint32_t key[BS_HASH];
-    float idf[BS_HASH];
-    uint32_t users_off[BS_HASH + 1];
     uint32_t users[BS_MAX_QT];
     uint32_t q_off[BS_MAX_Q + 1];
-    uint32_t q_slot[BS_MAX_QT];
     uint32_t tau[BS_MAX_Q];
     uint32_t seg_fill[BS_MAX_Q];
     uint32_t off[BS_DPT + 1];      // token offsets of the tile's docs, relative to the tile's first token
-    uint32_t head[BS_DPT];         // per-doc list head (entry index) or BS_NIL
     uint32_t bloom[BS_BLOOM_WORDS];
-    uint32_t hit[BS_HITCAP];       // slot (low 16) | next entry (high 16)
-    uint16_t hit_doc[BS_HITCAP];   // doc (index in the tile) of each hit
-    uint32_t hit_cnt, overflow_tile;
+    uint32_t hit[BS_HITCAP];       // slot | token index << 11 (phase 1), then slot | doc << 11 | representative << 20
+    uint32_t tf[BS_TF_SLOTS];      // doc << 11 | slot in the low 20 bits, tf above; BS_TF_EMPTY when free
+    alignas(16) float qp_idf[BS_MAX_Q][4];
+    alignas(8) uint16_t qp_slots[BS_MAX_Q][4];
+    uint16_t users_off[BS_HASH + 2];
+    uint16_t q_slot[BS_MAX_QT];
+    uint32_t wave_cnt[BS_THREADS / 64], overflow_tile;
 };
+static_assert(sizeof(BsShared) <= 80 * 1024, "two 512-thread workgroups per CU");
 
 __device__ __forceinline__ uint32_t bs_wave_slot(bool pred, uint32_t *counter) {
     const unsigned long long m = __ballot(pred);
@@ -159,25 +176,43 @@ __device__ __forceinline__ uint32_t bs_wave_slot(bool pred, uint32_t *counter) {
     return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
 }
 
+__device__ __forceinline__ uint32_t bs_tf_hash(uint32_t key20) { return (key20 * 0x9E3779B1u) >> 20; } // 12 bits
+
+// tf of (doc, slot) in the tile's table, 0 if the doc does not hold the term
+__device__ __forceinline__ uint32_t bs_tf_lookup(const BsShared &s, uint32_t key20) {
+    for (uint32_t h = bs_tf_hash(key20);; h = (h + 1) & (BS_TF_SLOTS - 1)) {
+        const uint32_t v = s.tf[h];
+        if (v == BS_TF_EMPTY) return 0;
+        if ((v & 0xFFFFFu) == key20) return v >> 20;
+    }
+}
+
 __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
     const uint32_t *__restrict__ terms, const uint64_t *__restrict__ doc_offsets, uint64_t doc_begin,
     uint64_t doc_end, float avgdl, const BsBatch *__restrict__ batch, const uint32_t *tau_keys, uint32_t q_begin,
     uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride, uint64_t pool_stride,
-    uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     BsShared &s = *reinterpret_cast<BsShared *>(smem_raw);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (batch->error) { // a query broke the pass limits (see oi_index_set_max_query_terms): fail loudly
         if (tid == 0) *overflow = 1u;
         return;
     }
     const uint32_t nq = batch->n_queries;
     // ---- batch tables -> LDS (once per workgroup)
-    for (uint32_t i = tid; i < BS_HASH; i += BS_THREADS) { s.key[i] = batch->key[i]; s.idf[i] = batch->idf[i]; s.users_off[i] = batch->users_off[i]; }
-    if (tid == 0) s.users_off[BS_HASH] = batch->users_off[BS_HASH];
+    for (uint32_t i = tid; i < BS_HASH; i += BS_THREADS) {
+        s.key[i] = batch->key[i];
+        s.users_off[i] = (uint16_t)batch->users_off[i];
+    }
+    if (tid == 0) s.users_off[BS_HASH] = (uint16_t)batch->users_off[BS_HASH];
     for (uint32_t i = tid; i < BS_BLOOM_WORDS; i += BS_THREADS) s.bloom[i] = batch->bloom[i];
-    for (uint32_t i = tid; i < batch->n_pairs; i += BS_THREADS) { s.users[i] = batch->users[i]; s.q_slot[i] = batch->q_slot[i]; }
+    for (uint32_t i = tid; i < batch->n_pairs; i += BS_THREADS) { s.users[i] = batch->users[i]; s.q_slot[i] = (uint16_t)batch->q_slot[i]; }
     for (uint32_t i = tid; i <= nq; i += BS_THREADS) s.q_off[i] = batch->q_off[i];
+    for (uint32_t i = tid; i < nq * 4; i += BS_THREADS) {
+        s.qp_slots[i >> 2][i & 3] = batch->qp_slots[i >> 2][i & 3];
+        s.qp_idf[i >> 2][i & 3] = batch->qp_idf[i >> 2][i & 3];
+    }
     for (uint32_t i = tid; i < nq; i += BS_THREADS) { s.tau[i] = tau_keys ? tau_keys[q_begin + i] : 0u; s.seg_fill[i] = 0; }
     __syncthreads();
 
@@ -189,34 +224,36 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
         const uint64_t t0 = doc_offsets[d0];
         __syncthreads(); // previous tile done
         if (tid < nd) s.off[tid] = (uint32_t)(doc_offsets[d0 + tid] - t0);
-        if (tid < BS_DPT) s.head[tid] = BS_NIL;
+        for (uint32_t i = tid; i < BS_TF_SLOTS; i += BS_THREADS) s.tf[i] = BS_TF_EMPTY;
         if (tid == 0) { // (nd may equal the block size: the end offset needs its own writer)
             s.off[nd] = (uint32_t)(doc_offsets[d0 + nd] - t0);
-            s.hit_cnt = 0;
             s.overflow_tile = 0;
         }
         __syncthreads();
         const uint32_t n_tok = s.off[nd];
         if (n_tok >= (1u << 21) && tid == 0) s.overflow_tile = 1; // token index would not fit a hit entry
+        if (tid < nd && s.off[tid + 1] - s.off[tid] >= 4096u) s.overflow_tile = 1; // tf would not fit its 12 bits
 
-        // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.
+        // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.  The first
+        // BS_PRE steps of the tile are loaded up front (enough bytes in flight to cover the HBM latency);
+        // loads are never predicated -- a group past the tile's end re-reads the tile's last group and
+        // its tokens fail the range test below.
+        uint32_t wave_hits = 0; // wave-uniform: hits this wave has appended to its region
         const uint32_t headpad = (uint32_t)(t0 & 3u); // tokens before t0 in the first aligned group
-        for (uint32_t sb = 0; sb < n_tok + headpad; sb += BS_THREADS * BS_TPT) {
-            const int64_t rel0 = (int64_t)sb - headpad + (int64_t)tid * BS_TPT; // tile-relative index of my first token
-            uint32_t tk[BS_TPT];
-            {
-                const uint64_t g = t0 - headpad + sb + (uint64_t)tid * BS_TPT; // absolute token index, multiple of 4
+        const uint32_t span = n_tok + headpad;        // tokens from the first aligned group to the tile's end
+        const uint32_t last_g = span ? ((span - 1u) & ~3u) : 0u;
+        const uint32_t *tbase = terms + (t0 - headpad);
+        auto load_step = [&](uint32_t sb, uint32_t (&tk)[BS_TPT]) {
 #pragma unroll
-                for (int v = 0; v < BS_TPT / 4; ++v) {
-                    uint4 x = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                    const int64_t r = rel0 + 4 * v;
-                    if (r + 4 > 0 && r < (int64_t)n_tok) x = *reinterpret_cast<const uint4 *>(terms + g + 4 * v);
-                    tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
-                }
+            for (int v = 0; v < BS_TPT / 4; ++v) {
+                const uint32_t g = sb + tid * BS_TPT + 4u * v;
+                const uint4 x = *reinterpret_cast<const uint4 *>(tbase + (g < last_g ? g : last_g));
+                tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
             }
-            // phase 1 proper: ONE LDS read per token (Bloom bit of its term id); ~4.5 % pass.  The
-            // passing tokens' indices are compacted per wave (popcount + wave prefix, one LDS atomic per
-            // wave and step); everything else about a hit is resolved in the link pass below.
+        };
+        auto scan_step = [&](uint32_t sb, const uint32_t (&tk)[BS_TPT]) {
+            const int64_t rel0 = (int64_t)sb - headpad + (int64_t)tid * BS_TPT; // tile-relative index of my first token
+            // ONE LDS read per token (Bloom bit of its term id); ~4.5 % pass
             uint32_t hmask = 0;
 #pragma unroll
             for (int i = 0; i < BS_TPT; ++i) {
@@ -225,131 +262,206 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 const uint32_t wbits = s.bloom[bb >> 5];
                 if (r >= 0 && r < (int64_t)n_tok && ((wbits >> (bb & 31u)) & 1u)) hmask |= 1u << i;
             }
-            if (__ballot(hmask != 0)) {
-                const uint32_t cnt = __builtin_popcount(hmask);
-                uint32_t incl = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(incl, o, OI_WAVE);
-                    if ((int)lane >= o) incl += v;
-                }
-                const uint32_t total = __shfl(incl, 63, OI_WAVE);
-                uint32_t base = 0;
-                if (lane == 63) base = atomicAdd(&s.hit_cnt, total);
-                base = __shfl(base, 63, OI_WAVE) + incl - cnt;
-                while (hmask) {
+            // every trip, each lane with a hit left resolves one (term -> slot in the LDS hash table; Bloom
+            // false positives die here) and the wave appends the survivors to its own region of the hit
+            // array: ballot + lane prefix, no atomics, no shuffles
+            while (__ballot(hmask != 0)) {
+                uint32_t ent = 0xFFFFFFFFu;
+                if (hmask) {
                     const uint32_t i = __builtin_ctz(hmask);
                     hmask &= hmask - 1;
-                    if (base < BS_HITCAP) s.hit[base] = (uint32_t)(rel0 + i); // pending: the token's index
-                    else s.overflow_tile = 1;
-                    ++base;
+                    // the token's term: a select chain over the registers (i is not a constant)
+                    uint32_t t = tk[0];
+#pragma unroll
+                    for (int j = 1; j < BS_TPT; ++j) t = (i == (uint32_t)j) ? tk[j] : t;
+                    for (uint32_t h = bs_hash(t);; h = (h + 1) & (BS_HASH - 1)) {
+                        const uint32_t k = s.key[h];
+                        if (k == t) { ent = h | ((uint32_t)(rel0 + i) << 11); break; }
+                        if (k == 0xFFFFFFFFu) break;
+                    }
+                }
+                const uint64_t m = __ballot(ent != 0xFFFFFFFFu);
+                if (ent != 0xFFFFFFFFu) {
+                    const uint32_t at = wave_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (at < BS_WAVE_HITS) s.hit[wv * BS_WAVE_HITS + at] = ent;
+                }
+                wave_hits += (uint32_t)__popcll(m);
+            }
+        };
+        constexpr uint32_t STEP = BS_THREADS * BS_TPT;
+        if (span) {
+            uint32_t tka[BS_PRE][BS_TPT];
+#pragma unroll
+            for (int st = 0; st < BS_PRE; ++st) load_step(st * STEP, tka[st]);
+#pragma unroll
+            for (int st = 0; st < BS_PRE; ++st)
+                if (st * STEP < span) scan_step(st * STEP, tka[st]);
+            if (span > BS_PRE * STEP) { // a tile of long docs: the rest one step ahead
+                uint32_t tk[BS_TPT], tkn[BS_TPT];
+                load_step(BS_PRE * STEP, tk);
+                for (uint32_t sb = BS_PRE * STEP; sb < span; sb += STEP) {
+                    const bool more = sb + STEP < span;
+                    if (more) load_step(sb + STEP, tkn);
+                    scan_step(sb, tk);
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < BS_TPT; ++i) tk[i] = tkn[i];
+                    }
                 }
             }
         }
-        __syncthreads();
-        // ---- link pass: every hit finds its doc (binary search in the tile's offsets) and pushes itself
-        // on that doc's list; one hit per lane, no divergence between hit and miss lanes
+        if (lane == 0) {
+            s.wave_cnt[wv] = wave_hits < BS_WAVE_HITS ? wave_hits : BS_WAVE_HITS;
+            if (wave_hits > BS_WAVE_HITS) s.overflow_tile = 1;
+        }
+        if (dbg == 1) continue; // ablation: phase 1 only
+        // (no barrier: a wave links the hits it found itself)
+        // ---- link pass: every hit finds its doc (binary search in the tile's offsets); one hit per lane, no
+        // divergence between hit and miss lanes
         {
-            const uint32_t nh = s.hit_cnt < BS_HITCAP ? s.hit_cnt : BS_HITCAP;
-            for (uint32_t e = tid; e < nh; e += BS_THREADS) {
-                const uint32_t r = s.hit[e];
-                const uint32_t t = terms[t0 + r]; // just streamed: an L2 hit
-                uint32_t slot = BS_NIL;
-                for (uint32_t h = bs_hash(t);; h = (h + 1) & (BS_HASH - 1)) {
-                    const uint32_t k = s.key[h];
-                    if (k == t) { slot = h; break; }
-                    if (k == 0xFFFFFFFFu) break;
-                }
-                if (slot == BS_NIL) { // Bloom false positive: a dead entry, never linked
-                    s.hit[e] = BS_NIL | (BS_NIL << 16);
-                    s.hit_doc[e] = (uint16_t)BS_NIL;
-                    continue;
-                }
-                const uint32_t ent = slot;
+            const uint32_t nh = wave_hits < BS_WAVE_HITS ? wave_hits : BS_WAVE_HITS; // each wave links its own hits
+            for (uint32_t e = wv * BS_WAVE_HITS + lane; e < wv * BS_WAVE_HITS + nh; e += 64) {
+                const uint32_t x = s.hit[e];
+                const uint32_t r = x >> 11;
                 uint32_t lo = 0, hi = nd; // largest d with off[d] <= r
                 while (hi - lo > 1) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if (s.off[mid] <= r) lo = mid; else hi = mid;
                 }
-                const uint32_t prev = atomicExch(&s.head[lo], e);
-                s.hit[e] = (ent & 0x7FFu) | (prev << 16);
-                s.hit_doc[e] = (uint16_t)lo;
+                // count the hit in the tile's (doc, term) -> tf table; the hit that creates the entry is the
+                // pair's representative and does the scoring
+                const uint32_t key20 = (lo << 11) | (x & 0x7FFu);
+                uint32_t rep = 0, probes = 0;
+                for (uint32_t h = bs_tf_hash(key20);; h = (h + 1) & (BS_TF_SLOTS - 1)) {
+                    uint32_t v = s.tf[h];
+                    if (v == BS_TF_EMPTY) {
+                        v = atomicCAS(&s.tf[h], BS_TF_EMPTY, key20 | (1u << 20));
+                        if (v == BS_TF_EMPTY) { rep = 1; break; }
+                    }
+                    if ((v & 0xFFFFFu) == key20) { atomicAdd(&s.tf[h], 1u << 20); break; }
+                    if (++probes == BS_TF_SLOTS) { s.overflow_tile = 1; break; } // table full
+                }
+                s.hit[e] = key20 | (rep << 20);
             }
         }
         __syncthreads();
 
-        // ---- phase 2: one lane per HIT (balanced: a long doc's hits spread over many lanes).  A doc's
-        // hits form a short LDS linked list; for every query using the hit's term, the hit that comes
-        // first in the list among all hits carrying one of that query's terms scores the (doc, query)
-        // pair -- exactly once -- as the f32 sum over the query's terms IN QUERY ORDER, tf counted by
-        // walking the list, impact from the doc length.
-        if (s.overflow_tile == 0) {
-            const uint32_t nh = s.hit_cnt;
-            for (uint32_t e = tid; e < nh; e += BS_THREADS) {
-                const uint32_t sl = s.hit[e] & 0xFFFFu;
-                const uint32_t d = s.hit_doc[e];
-                if (d == BS_NIL) continue; // Bloom false positive
-                const uint32_t list_head = s.head[d];
-                const uint32_t ub = s.users_off[sl], ue = s.users_off[sl + 1];
-                float kd = 0.f;
-                bool have_kd = false;
-                for (uint32_t u = ub; u < ue; ++u) {
-                    const uint32_t q = s.users[u] >> 16, pos_in_q = s.users[u] & 0xFFFFu;
+        // ---- phase 2: one lane per HIT (balanced: a long doc's hits spread over many lanes); only the
+        // representative of a (doc, term) pair goes on.  For every query q using the term it looks up the
+        // tf of q's terms in the tile's table, and scores the (doc, q) pair iff its term is the first of
+        // q's terms (in query order) that the doc holds -- so each pair is scored exactly once, as the
+        // f32 sum over q's terms IN QUERY ORDER.
+        if (dbg == 2) continue; // ablation: no scoring
+        uint32_t wstart[BS_THREADS / 64 + 1]; // the waves' regions, flattened: hit f lives in the region w with wstart[w] <= f
+        wstart[0] = 0;
+#pragma unroll
+        for (int w = 0; w < BS_THREADS / 64; ++w) wstart[w + 1] = wstart[w] + s.wave_cnt[w];
+        const uint32_t nh_all = wstart[BS_THREADS / 64];
+        for (uint32_t f = tid; f < nh_all && s.overflow_tile == 0 && dbg != 4; f += BS_THREADS) {
+            uint32_t he = f; // region base + index within the region
+#pragma unroll
+            for (int w = 1; w < BS_THREADS / 64; ++w) he = f >= wstart[w] ? (uint32_t)w * BS_WAVE_HITS + (f - wstart[w]) : he;
+            const uint32_t x = s.hit[he];
+            if (!((x >> 20) & 1u)) continue; // not the representative of its (doc, term) pair
+            const uint32_t sl = x & 0x7FFu, d = (x >> 11) & 0x1FFu, dkey = x & 0xFF800u;
+            const uint32_t dlen = s.off[d + 1] - s.off[d];
+            const float ratio = __fdiv_rn((float)dlen, avgdl);
+            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
+            const uint32_t ub = s.users_off[sl], ue = s.users_off[sl + 1];
+            for (uint32_t u = ub; u < ue; ++u) {
+                const uint32_t q = s.users[u] >> 16, pos_in_q = s.users[u] & 0xFFFFu;
+                const uint2 qs = *reinterpret_cast<const uint2 *>(&s.qp_slots[q][0]);
+                float score = 0.0f;
+                if ((qs.x & 0xFFFFu) != BS_LONGQ) {
+                    const uint32_t t[4] = {qs.x & 0xFFFFu, qs.x >> 16, qs.y & 0xFFFFu, qs.y >> 16};
+                    uint32_t tf[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) tf[p] = t[p] == BS_NIL ? 0u : bs_tf_lookup(s, dkey | t[p]);
+                    bool mine = true; // no earlier term of q occurs in the doc
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) mine = mine && !((uint32_t)p < pos_in_q && tf[p] != 0);
+                    if (!mine) continue;
+                    const float4 qi = *reinterpret_cast<const float4 *>(&s.qp_idf[q][0]);
+                    const float idfs[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { // q's terms in query order
+                        if (tf[p] == 0) continue;
+                        const float ftf = (float)tf[p];
+                        const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                        score = __fadd_rn(score, __fmul_rn(idfs[p], im));
+                    }
+                } else { // a query of more than four terms: the same, out of the LDS tables
                     const uint32_t qb = s.q_off[q], qe = s.q_off[q + 1];
                     bool mine = true;
-                    for (uint32_t p = qb; p < qb + pos_in_q; ++p) mine = mine && s.q_slot[p] != sl;
-                    for (uint32_t h2 = list_head; mine && h2 != e; h2 = s.hit[h2] >> 16) {
-                        const uint32_t sl2 = s.hit[h2] & 0xFFFFu;
-                        for (uint32_t p = qb; p < qe; ++p) mine = mine && s.q_slot[p] != sl2;
+                    for (uint32_t p = qb; p < qb + pos_in_q; ++p) {
+                        const uint32_t slp = s.q_slot[p];
+                        mine = mine && (slp == BS_NIL || bs_tf_lookup(s, dkey | slp) == 0);
                     }
                     if (!mine) continue;
-                    if (!have_kd) {
-                        const uint32_t dlen = s.off[d + 1] - s.off[d];
-                        const float ratio = __fdiv_rn((float)dlen, avgdl);
-                        kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
-                        have_kd = true;
-                    }
-                    float score = 0.0f;
-                    for (uint32_t p = qb; p < qe; ++p) { // q's terms in query order
+                    for (uint32_t p = qb; p < qe; ++p) {
                         const uint32_t slp = s.q_slot[p];
-                        if (slp == BS_NIL) continue;
-                        uint32_t tf = 0;
-                        for (uint32_t h = list_head; h != BS_NIL; h = s.hit[h] >> 16) tf += (s.hit[h] & 0xFFFFu) == slp;
+                        const uint32_t tf = slp == BS_NIL ? 0u : bs_tf_lookup(s, dkey | slp);
                         if (tf == 0) continue;
                         const float ftf = (float)tf;
                         const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
-                        score = __fadd_rn(score, __fmul_rn(s.idf[slp], im));
+                        score = __fadd_rn(score, __fmul_rn(batch->idf[slp], im));
                     }
-                    if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
-                        const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
-                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + d));
-                        else *overflow = 1u;
-                    }
-                }
-            }
-        } else if (tid < nd) {
-            // the tile produced more than BS_HITCAP hits (a batch whose terms cover a large share of the
-            // text) or is too long: exact per-query evaluation straight from each doc's tokens
-            const uint32_t dlen = s.off[tid + 1] - s.off[tid];
-            const float ratio = __fdiv_rn((float)dlen, avgdl);
-            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
-            const uint32_t *dt = terms + t0 + s.off[tid];
-            for (uint32_t q = 0; q < nq; ++q) {
-                float score = 0.0f;
-                for (uint32_t p = s.q_off[q]; p < s.q_off[q + 1]; ++p) {
-                    const uint32_t sl = s.q_slot[p];
-                    if (sl == BS_NIL) continue;
-                    const uint32_t t = s.key[sl];
-                    uint32_t tf = 0;
-                    for (uint32_t i = 0; i < dlen; ++i) tf += dt[i] == t;
-                    if (tf == 0) continue;
-                    const float ftf = (float)tf;
-                    const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
-                    score = __fadd_rn(score, __fmul_rn(s.idf[sl], im));
                 }
                 if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
                     const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
-                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + tid));
+                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + d));
+                    else *overflow = 1u;
+                }
+            }
+        }
+        const bool slow_doc = tid < nd && s.overflow_tile != 0;
+        // ---- every doc of a tile whose hits overflowed the hit array or the tf table (or with a 4096-token doc):
+        // the wave takes them one at a time, ONE LANE PER QUERY, counting tf straight from the doc's
+        // tokens (every lane reads the same token: a broadcast load that hits in cache, just streamed)
+        for (uint64_t sm = dbg == 3 ? 0ull : __ballot(slow_doc); sm; sm &= sm - 1) {
+            const uint32_t d = (tid & ~63u) + (uint32_t)__builtin_ctzll(sm);
+            const uint32_t dlen = s.off[d + 1] - s.off[d];
+            const float ratio = __fdiv_rn((float)dlen, avgdl);
+            const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
+            const uint32_t *dt = terms + t0 + s.off[d];
+            for (uint32_t q = lane; q < nq; q += 64) {
+                const uint2 qs = *reinterpret_cast<const uint2 *>(&s.qp_slots[q][0]);
+                float score = 0.0f;
+                if ((qs.x & 0xFFFFu) != BS_LONGQ) {
+                    const uint32_t t[4] = {qs.x & 0xFFFFu, qs.x >> 16, qs.y & 0xFFFFu, qs.y >> 16};
+                    uint32_t key[4], tf[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) key[p] = t[p] == BS_NIL ? 0xFFFFFFFFu : s.key[t[p]]; // no token has that id
+                    for (uint32_t i = 0; i < dlen; ++i) {
+                        const uint32_t tok = dt[i];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) tf[p] += tok == key[p];
+                    }
+                    const float4 qi = *reinterpret_cast<const float4 *>(&s.qp_idf[q][0]);
+                    const float idfs[4] = {qi.x, qi.y, qi.z, qi.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) { // q's terms in query order
+                        if (tf[p] == 0) continue;
+                        const float ftf = (float)tf[p];
+                        const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                        score = __fadd_rn(score, __fmul_rn(idfs[p], im));
+                    }
+                } else { // a query of more than four terms: term by term
+                    for (uint32_t p = s.q_off[q]; p < s.q_off[q + 1]; ++p) {
+                        const uint32_t sl = s.q_slot[p];
+                        if (sl == BS_NIL) continue;
+                        const uint32_t t = s.key[sl];
+                        uint32_t tf = 0;
+                        for (uint32_t i = 0; i < dlen; ++i) tf += dt[i] == t;
+                        if (tf == 0) continue;
+                        const float ftf = (float)tf;
+                        const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
+                        score = __fadd_rn(score, __fmul_rn(batch->idf[sl], im));
+                    }
+                }
+                if (score > 0.0f && oi_f32_key(score) >= s.tau[q]) {
+                    const uint32_t pos = atomicAdd(&s.seg_fill[q], 1u);
+                    if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(score, doc_id_base + (uint32_t)(d0 + d));
                     else *overflow = 1u;
                 }
             }
@@ -402,11 +514,12 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
                            idx->vocab, idx->max_query_terms, idx->idf.as<float>(), bb.as<BsBatch>());
         OI_HIP_CHECK(hipGetLastError());
     }
+    static const int dbg = getenv("OI_BM25_SCAN_DBG") ? atoi(getenv("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
     ProfScope ps(ctx, "bm25");
     hipLaunchKernelGGL(bm25_scan_kernel, dim3(pool.n_segs), dim3(BS_THREADS), sizeof(BsShared), ctx->stream,
                        idx->fwd_terms.as<uint32_t>(), idx->fwd_offsets.as<uint64_t>(), doc_begin, doc_end, avgdl,
                        bb.as<BsBatch>(), pool.tau_keys, q_begin, idx->doc_id_base, pool.keys, pool.seg_cnt,
-                       pool.seg_cnt_stride, pool.stride, pool.carry_cap, pool.seg_cap, pool.overflow);
+                       pool.seg_cnt_stride, pool.stride, pool.carry_cap, pool.seg_cap, pool.overflow, dbg);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""BM25 kernels alone at the bench shape: 10M-doc synthetic forward index, 64 queries x 4 terms, depth 1000.
+Runs the term-at-a-time kernel and the batch scan, checks that their ranked lists are identical, and
+prints one JSON line with the per-batch kernel times (HIP events inside the library).
+    python tools/bm25_bench.py [n_docs] [reps]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import openintel_amd as oi
+from openintel_amd import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+B, DIM, DEPTH = 64, 32, 1000   # a narrow embedding keeps the cosine leg out of the way
+dev = torch.device("cuda:0")
+ctx = oi.HipContext(0)
+ctx.use_torch_current_stream()
+rows = synth.embeddings_torch(n, DIM, dev)
+terms, offs = synth.forward_index_torch(n, dev)
+n_tokens = int(offs[-1].item())
+idx = oi.HybridIndex(ctx, n, DIM, synth.VOCAB)
+idx.set_embeddings(rows, normalize=False)
+idx.set_forward(terms, offs)
+idx.set_max_query_terms(4)
+idx.finalize()
+qv, qt, qo = synth.query_batch_torch(B, DIM, dev)
+res = {}
+lists = {}
+for name, mode in (("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN)):
+    idx.set_bm25_mode(mode)
+    for _ in range(2):
+        r = idx.search_lists(qv, qt, qo, depth=DEPTH)
+    torch.cuda.synchronize()
+    ctx.profile_reset(True)
+    for _ in range(reps):
+        r = idx.search_lists(qv, qt, qo, depth=DEPTH)
+    torch.cuda.synchronize()
+    ms, launches = ctx.profile_read("bm25")
+    ctx.profile_reset(False)
+    res[name] = {"ms_per_batch": ms / reps, "launches_per_batch": launches / reps}
+    lists[name] = (r.bm25_docs.clone(), r.bm25_scores.clone(), r.bm25_counts.clone())
+same = all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["scan"]))
+scan_bytes = 4 * n_tokens + 8 * (n + 1)
+res["scan"]["algorithmic_GBs"] = scan_bytes / (res["scan"]["ms_per_batch"] / 1e3) / 1e9
+res["scan"]["frac_of_8TBs"] = res["scan"]["algorithmic_GBs"] / 8000.0
+print(json.dumps({"docs": n, "tokens": n_tokens, "batch": B, "depth": DEPTH, "lists_identical": same, **res}))
