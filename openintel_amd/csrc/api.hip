@@ -500,7 +500,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             // chunk (1/8 of the docs) fixing the thresholds.  Same worst-case rule as the cosine pools:
             // a chunk can append at most one entry per doc and query.
             const uint32_t segs = 2u * (uint32_t)ctx->num_cus;
-            const uint64_t sslack = 512ull * (segs + 1);
+            const uint64_t sslack = 1024ull * (segs + 1); // oi_bm25_scan_geometry: a workgroup's docs, rounded up by two tiles
             uint64_t sstride = carry_cap + std::min<uint64_t>(n, 1ull << 23) + sslack;
             const uint64_t sbudget = (4ull << 30) / 8 / B;
             if (sstride > sbudget) sstride = std::max<uint64_t>(sbudget, carry_cap + 4 * sslack);

@@ -27,7 +27,7 @@
 #include "oi_internal.h"
 
 #define BS_THREADS 512
-#define BS_DPT 512          // docs per workgroup tile (one per lane in phase 2)
+#define BS_DPT 512          // docs per workgroup tile, at most (the setup kernel picks the tile size per batch)
 #define BS_TPT 8            // tokens per thread and step in phase 1
 #define BS_PRE 4            // steps of a tile loaded before the first is scanned (a typical tile has 3)
 #define BS_HASH 2048        // term hash table slots (power of two)
@@ -56,7 +56,8 @@ struct BsBatch { // built once per batch by bm25_scan_setup (global memory, ~40 
     // order; qp_slots[q][0] = BS_LONGQ marks a longer query (scored from q_slot / idf instead)
     uint16_t qp_slots[BS_MAX_Q][4];
     float qp_idf[BS_MAX_Q][4];
-    uint32_t n_queries, n_pairs, error, pad;
+    uint32_t n_queries, n_pairs, error;
+    uint32_t docs_per_tile; // chosen from the batch's expected hits per doc, see bm25_scan_setup
 };
 __device__ __forceinline__ uint32_t bs_bloom_bit(uint32_t t) { return (t * 0x85EBCA77u) >> 17; } // 15 bits
 
@@ -66,16 +67,18 @@ __device__ __forceinline__ uint32_t bs_hash(uint32_t t) { return (t * 0x9E3779B1
 __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms, const uint32_t *q_offsets,
                                                          uint32_t q_begin, uint32_t n_queries, uint32_t vocab,
                                                          uint32_t max_terms_per_query, const float *idf,
+                                                         const uint32_t *df, uint64_t n_docs, float avgdl,
                                                          BsBatch *out) {
     __shared__ uint32_t cnt[BS_HASH];
     __shared__ uint32_t scan_tmp[1024];
     __shared__ uint32_t n_distinct;
+    __shared__ unsigned long long sum_df; // docs holding each distinct batch term, summed: ~ hits of the batch
     const uint32_t tid = threadIdx.x;
     const uint32_t base = q_offsets[q_begin];
     const uint32_t n_pairs = q_offsets[q_begin + n_queries] - base;
     for (uint32_t i = tid; i < BS_HASH; i += 1024) { out->key[i] = 0xFFFFFFFFu; out->idf[i] = 0.f; cnt[i] = 0; }
     for (uint32_t i = tid; i < BS_BLOOM_WORDS; i += 1024) out->bloom[i] = 0;
-    if (tid == 0) { n_distinct = 0; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
+    if (tid == 0) { n_distinct = 0; sum_df = 0; out->docs_per_tile = BS_DPT; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
     for (uint32_t q = tid; q <= n_queries; q += 1024) out->q_off[q] = q_offsets[q_begin + q] - base;
     __syncthreads();
     __shared__ uint32_t too_long;
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
                 const uint32_t prev = atomicCAS(&out->key[h], 0xFFFFFFFFu, t);
                 if (prev == 0xFFFFFFFFu) {
                     atomicAdd(&n_distinct, 1u);
+                    atomicAdd(&sum_df, (unsigned long long)df[t]);
                     out->idf[h] = idf[t];
                     const uint32_t bb = bs_bloom_bit(t);
                     atomicOr(&out->bloom[bb >> 5], 1u << (bb & 31u));
@@ -112,6 +116,22 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
     }
     __syncthreads();
     if (n_distinct > BS_MAX_TERMS) { if (tid == 0) out->error = 2; return; }
+    if (tid == 0) {
+        // Tile size.  Phase 1 works in steps of BS_THREADS * BS_TPT tokens and the hit passes in rounds of
+        // BS_THREADS hits, both rounded up per tile, so the tile that wastes least depends on the batch:
+        // pick the docs per tile minimising (steps + 2.1 * hit rounds) / docs (the measured cost ratio of
+        // a hit round to a token step).
+        const float hpd = n_docs ? 1.05f * (float)sum_df / (float)n_docs : 0.f; // expected hits per doc
+        float best = 3.4e38f;
+        uint32_t best_d = BS_DPT;
+        for (uint32_t d = 64; d <= BS_DPT; d += 32) {
+            const float steps = ceilf((float)d * avgdl / (float)(BS_THREADS * BS_TPT));
+            const float rounds = ceilf(fmaxf((float)d * hpd * 1.04f, 1.f) / (float)BS_THREADS);
+            const float cost = (steps + 2.1f * rounds) / (float)d;
+            if (cost <= best) { best = cost; best_d = d; }
+        }
+        out->docs_per_tile = best_d;
+    }
     // exclusive scan of cnt[2048] (two entries per thread)
     const uint32_t a = cnt[2 * tid], b = cnt[2 * tid + 1];
     scan_tmp[tid] = a + b;
@@ -176,6 +196,8 @@ __device__ __forceinline__ uint32_t bs_wave_slot(bool pred, uint32_t *counter) {
     return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
 }
 
+__device__ unsigned long long bs_timing[8]; // development aid (OI_BM25_SCAN_DBG=9): cycles per phase, summed over sampled waves
+
 __device__ __forceinline__ uint32_t bs_tf_hash(uint32_t key20) { return (key20 * 0x9E3779B1u) >> 20; } // 12 bits
 
 // tf of (doc, slot) in the tile's table, 0 if the doc does not hold the term
@@ -217,51 +239,88 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
     __syncthreads();
 
     uint64_t *my_seg = pools + (uint64_t)q_begin * pool_stride + carry_cap + (uint64_t)blockIdx.x * seg_cap;
-    const uint64_t n_tiles = (doc_end - doc_begin + BS_DPT - 1) / BS_DPT;
+    const uint32_t D = batch->docs_per_tile; // docs per tile for this batch (<= BS_DPT)
+    const uint64_t n_tiles = (doc_end - doc_begin + D - 1) / D;
+    // Software pipeline over the workgroup's tiles: while a tile is linked and scored out of LDS, the
+    // next tile's tokens are already on their way into registers, and the offsets of the tile after that
+    // are being fetched -- the dependent HBM round trips (offsets, then tokens) are off a tile's path.
+    struct TileMeta {
+        uint64_t t0, mine; // first token of the tile; this lane's doc offset (the tile's end past the last doc)
+        uint32_t n_tok, nd;
+    };
+    auto fetch_meta = [&](uint64_t tile) {
+        TileMeta m{0, 0, 0, 0};
+        if (tile < n_tiles) {
+            const uint64_t d0 = doc_begin + tile * D;
+            m.nd = (uint32_t)((doc_end - d0) < D ? (doc_end - d0) : D);
+            // vector loads on purpose (a per-lane zero the compiler cannot see through): scalar loads would
+            // share lgkmcnt with LDS and make the next LDS wait sit out an HBM round trip
+            uint32_t z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            m.t0 = doc_offsets[d0 + z];
+            m.n_tok = (uint32_t)(doc_offsets[d0 + m.nd + z] - m.t0);
+            m.mine = doc_offsets[d0 + (tid < m.nd ? tid : m.nd)];
+        }
+        return m;
+    };
+    // a tile's token window: loads are never predicated -- a group past the tile's end re-reads the
+    // tile's last group and its tokens fail the range test in scan_step
+    auto load_step = [&](const TileMeta &m, uint32_t sb, uint32_t (&tk)[BS_TPT]) {
+        const uint32_t headpad = (uint32_t)(m.t0 & 3u);
+        const uint32_t span = m.n_tok + headpad;
+        const uint32_t last_g = span ? ((span - 1u) & ~3u) : 0u;
+        const uint32_t *tbase = terms + (m.t0 - headpad);
+#pragma unroll
+        for (int v = 0; v < BS_TPT / 4; ++v) {
+            const uint32_t g = sb + tid * BS_TPT + 4u * v;
+            const uint4 x = *reinterpret_cast<const uint4 *>(tbase + (g < last_g ? g : last_g));
+            tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
+        }
+    };
+    constexpr uint32_t STEP = BS_THREADS * BS_TPT;
+    uint32_t tka[BS_PRE][BS_TPT]; // the first BS_PRE steps of a tile (a typical tile has 3)
+    TileMeta cur = fetch_meta(blockIdx.x);
+    if (cur.n_tok) {
+#pragma unroll
+        for (int st = 0; st < BS_PRE; ++st) load_step(cur, st * STEP, tka[st]);
+    }
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t d0 = doc_begin + tile * BS_DPT;
-        const uint32_t nd = (uint32_t)((doc_end - d0) < BS_DPT ? (doc_end - d0) : BS_DPT);
-        const uint64_t t0 = doc_offsets[d0];
+        const uint64_t d0 = doc_begin + tile * D;
+        const uint32_t nd = cur.nd;
+        const uint64_t t0 = cur.t0;
+        const uint32_t n_tok = cur.n_tok;
+        const unsigned long long c0 = clock64();
         __syncthreads(); // previous tile done
-        if (tid < nd) s.off[tid] = (uint32_t)(doc_offsets[d0 + tid] - t0);
+        s.off[tid] = (uint32_t)(cur.mine - t0); // (docs past nd hold the tile's end)
         for (uint32_t i = tid; i < BS_TF_SLOTS; i += BS_THREADS) s.tf[i] = BS_TF_EMPTY;
         if (tid == 0) { // (nd may equal the block size: the end offset needs its own writer)
-            s.off[nd] = (uint32_t)(doc_offsets[d0 + nd] - t0);
+            s.off[nd] = n_tok;
             s.overflow_tile = 0;
         }
+        const TileMeta nxt = fetch_meta(tile + gridDim.x); // arrives while this tile is scanned
         __syncthreads();
-        const uint32_t n_tok = s.off[nd];
         if (n_tok >= (1u << 21) && tid == 0) s.overflow_tile = 1; // token index would not fit a hit entry
         if (tid < nd && s.off[tid + 1] - s.off[tid] >= 4096u) s.overflow_tile = 1; // tf would not fit its 12 bits
 
-        // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.  The first
-        // BS_PRE steps of the tile are loaded up front (enough bytes in flight to cover the HBM latency);
-        // loads are never predicated -- a group past the tile's end re-reads the tile's last group and
-        // its tokens fail the range test below.
+        const unsigned long long c1 = clock64();
+        // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.
         uint32_t wave_hits = 0; // wave-uniform: hits this wave has appended to its region
         const uint32_t headpad = (uint32_t)(t0 & 3u); // tokens before t0 in the first aligned group
         const uint32_t span = n_tok + headpad;        // tokens from the first aligned group to the tile's end
-        const uint32_t last_g = span ? ((span - 1u) & ~3u) : 0u;
-        const uint32_t *tbase = terms + (t0 - headpad);
-        auto load_step = [&](uint32_t sb, uint32_t (&tk)[BS_TPT]) {
-#pragma unroll
-            for (int v = 0; v < BS_TPT / 4; ++v) {
-                const uint32_t g = sb + tid * BS_TPT + 4u * v;
-                const uint4 x = *reinterpret_cast<const uint4 *>(tbase + (g < last_g ? g : last_g));
-                tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
-            }
-        };
         auto scan_step = [&](uint32_t sb, const uint32_t (&tk)[BS_TPT]) {
-            const int64_t rel0 = (int64_t)sb - headpad + (int64_t)tid * BS_TPT; // tile-relative index of my first token
+            // tile-relative index of my first token (32-bit: a tile has fewer than 2^21 tokens) and which of my
+            // BS_TPT tokens lie inside the tile
+            const int32_t rel0 = (int32_t)(sb + tid * BS_TPT) - (int32_t)headpad;
+            const int32_t lo = rel0 < 0 ? -rel0 : 0, hi = (int32_t)n_tok - rel0;
+            const uint32_t inside = hi <= lo ? 0u : (((hi >= BS_TPT ? 1u << BS_TPT : 1u << hi) - 1u) & ~((1u << lo) - 1u));
             // ONE LDS read per token (Bloom bit of its term id); ~4.5 % pass
             uint32_t hmask = 0;
 #pragma unroll
             for (int i = 0; i < BS_TPT; ++i) {
-                const int64_t r = rel0 + i;
                 const uint32_t bb = bs_bloom_bit(tk[i]);
-                const uint32_t wbits = s.bloom[bb >> 5];
-                if (r >= 0 && r < (int64_t)n_tok && ((wbits >> (bb & 31u)) & 1u)) hmask |= 1u << i;
+                hmask |= ((s.bloom[bb >> 5] >> (bb & 31u)) & 1u) << i;
             }
+            hmask &= inside;
             // every trip, each lane with a hit left resolves one (term -> slot in the LDS hash table; Bloom
             // false positives die here) and the wave appends the survivors to its own region of the hit
             // array: ballot + lane prefix, no atomics, no shuffles
@@ -276,7 +335,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                     for (int j = 1; j < BS_TPT; ++j) t = (i == (uint32_t)j) ? tk[j] : t;
                     for (uint32_t h = bs_hash(t);; h = (h + 1) & (BS_HASH - 1)) {
                         const uint32_t k = s.key[h];
-                        if (k == t) { ent = h | ((uint32_t)(rel0 + i) << 11); break; }
+                        if (k == t) { ent = h | ((uint32_t)(rel0 + (int32_t)i) << 11); break; }
                         if (k == 0xFFFFFFFFu) break;
                     }
                 }
@@ -288,20 +347,16 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 wave_hits += (uint32_t)__popcll(m);
             }
         };
-        constexpr uint32_t STEP = BS_THREADS * BS_TPT;
         if (span) {
-            uint32_t tka[BS_PRE][BS_TPT];
-#pragma unroll
-            for (int st = 0; st < BS_PRE; ++st) load_step(st * STEP, tka[st]);
 #pragma unroll
             for (int st = 0; st < BS_PRE; ++st)
                 if (st * STEP < span) scan_step(st * STEP, tka[st]);
             if (span > BS_PRE * STEP) { // a tile of long docs: the rest one step ahead
                 uint32_t tk[BS_TPT], tkn[BS_TPT];
-                load_step(BS_PRE * STEP, tk);
+                load_step(cur, BS_PRE * STEP, tk);
                 for (uint32_t sb = BS_PRE * STEP; sb < span; sb += STEP) {
                     const bool more = sb + STEP < span;
-                    if (more) load_step(sb + STEP, tkn);
+                    if (more) load_step(cur, sb + STEP, tkn);
                     scan_step(sb, tk);
                     if (more) {
 #pragma unroll
@@ -310,11 +365,16 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
+        const unsigned long long c2 = clock64();
+        if (nxt.n_tok) { // the next tile's tokens fly while this one is linked and scored
+#pragma unroll
+            for (int st = 0; st < BS_PRE; ++st) load_step(nxt, st * STEP, tka[st]);
+        }
         if (lane == 0) {
             s.wave_cnt[wv] = wave_hits < BS_WAVE_HITS ? wave_hits : BS_WAVE_HITS;
             if (wave_hits > BS_WAVE_HITS) s.overflow_tile = 1;
         }
-        if (dbg == 1) continue; // ablation: phase 1 only
+        if (dbg == 1) { cur = nxt; continue; } // ablation: phase 1 only
         // (no barrier: a wave links the hits it found itself)
         // ---- link pass: every hit finds its doc (binary search in the tile's offsets); one hit per lane, no
         // divergence between hit and miss lanes
@@ -346,12 +406,13 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
         }
         __syncthreads();
 
+        const unsigned long long c3 = clock64();
         // ---- phase 2: one lane per HIT (balanced: a long doc's hits spread over many lanes); only the
         // representative of a (doc, term) pair goes on.  For every query q using the term it looks up the
         // tf of q's terms in the tile's table, and scores the (doc, q) pair iff its term is the first of
         // q's terms (in query order) that the doc holds -- so each pair is scored exactly once, as the
         // f32 sum over q's terms IN QUERY ORDER.
-        if (dbg == 2) continue; // ablation: no scoring
+        if (dbg == 2) { cur = nxt; continue; } // ablation: no scoring
         uint32_t wstart[BS_THREADS / 64 + 1]; // the waves' regions, flattened: hit f lives in the region w with wstart[w] <= f
         wstart[0] = 0;
 #pragma unroll
@@ -414,6 +475,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
+        const unsigned long long c4 = clock64();
         const bool slow_doc = tid < nd && s.overflow_tile != 0;
         // ---- every doc of a tile whose hits overflowed the hit array or the tf table (or with a 4096-token doc):
         // the wave takes them one at a time, ONE LANE PER QUERY, counting tf straight from the doc's
@@ -466,6 +528,16 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
+        if (dbg == 9 && lane == 0 && (blockIdx.x & 15u) == 0) {
+            atomicAdd(&bs_timing[0], c1 - c0); // tile setup (barriers, offsets to LDS, tf table reset)
+            atomicAdd(&bs_timing[1], c2 - c1); // phase 1
+            atomicAdd(&bs_timing[2], c3 - c2); // next tile's loads issued, link, barrier
+            atomicAdd(&bs_timing[3], c4 - c3); // phase 2
+            atomicAdd(&bs_timing[4], clock64() - c4);
+            atomicAdd(&bs_timing[5], 1ull);
+            atomicAdd(&bs_timing[6], (unsigned long long)wave_hits);
+        }
+        cur = nxt;
     }
     __syncthreads();
     for (uint32_t q = tid; q < nq; q += BS_THREADS) {
@@ -481,7 +553,9 @@ void oi_bm25_scan_geometry(const oi_ctx *ctx, uint64_t n_docs, uint32_t *n_segs,
     if (grid > n_tiles) grid = n_tiles;
     if (grid == 0) grid = 1;
     *n_segs = (uint32_t)grid;
-    *seg_cap = (uint32_t)(((n_tiles + grid - 1) / grid) * BS_DPT);
+    // docs one workgroup can meet, whatever tile size (<= BS_DPT) the batch picks: n_docs / grid rounded up
+    // to whole tiles plus one tile
+    *seg_cap = (uint32_t)(((n_tiles + grid - 1) / grid + 1) * BS_DPT);
 }
 
 uint32_t oi_bm25_scan_max_queries() { return BS_MAX_Q; }
@@ -511,7 +585,8 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     }
     if (run_setup) {
         hipLaunchKernelGGL(bm25_scan_setup, dim3(1), dim3(1024), 0, ctx->stream, d_q_terms, d_q_offsets, q_begin, nq,
-                           idx->vocab, idx->max_query_terms, idx->idf.as<float>(), bb.as<BsBatch>());
+                           idx->vocab, idx->max_query_terms, idx->idf.as<float>(), idx->df_local.as<uint32_t>(),
+                           (uint64_t)idx->n_docs, avgdl, bb.as<BsBatch>());
         OI_HIP_CHECK(hipGetLastError());
     }
     static const int dbg = getenv("OI_BM25_SCAN_DBG") ? atoi(getenv("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
@@ -521,5 +596,15 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
                        bb.as<BsBatch>(), pool.tau_keys, q_begin, idx->doc_id_base, pool.keys, pool.seg_cnt,
                        pool.seg_cnt_stride, pool.stride, pool.carry_cap, pool.seg_cap, pool.overflow, dbg);
     OI_HIP_CHECK(hipGetLastError());
+    if (dbg == 9) {
+        unsigned long long h[8] = {0};
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        OI_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(bs_timing), sizeof(h)));
+        const double w = h[5] ? (double)h[5] : 1.0;
+        fprintf(stderr, "[bm25 scan timing] cycles/wave/tile: setup %.0f phase1 %.0f link %.0f phase2 %.0f tail %.0f | samples %llu hits/wave %.1f\n",
+                h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5], h[6] / w);
+        unsigned long long z[8] = {0};
+        OI_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bs_timing), z, sizeof(z)));
+    }
     return OI_OK;
 }
