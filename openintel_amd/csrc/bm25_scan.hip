@@ -27,19 +27,20 @@
 #include "oi_internal.h"
 
 #define BS_THREADS 512
-#define BS_DPT 512          // docs per workgroup tile, at most (the setup kernel picks the tile size per batch)
-#define BS_TPT 8            // tokens per thread and step in phase 1
-#define BS_PRE 4            // steps of a tile loaded before the first is scanned (a typical tile has 3)
+#define BS_WAVES (BS_THREADS / 64)
+#define BS_WD 64            // docs per wave tile, at most (the setup kernel picks the tile size per batch)
+#define BS_TPT 4            // tokens per lane and step in phase 1: one 16-byte load
+#define BS_STEP (64 * BS_TPT)
+#define BS_PRE 6            // steps of a tile loaded before the first is scanned (a typical tile has 5)
 #define BS_HASH 2048        // term hash table slots (power of two)
 #define BS_MAX_TERMS 1024   // distinct batch terms (load factor <= 50 %)
 #define BS_MAX_Q 256        // queries per pass
 #define BS_MAX_QT 2048      // total (query, term) pairs per pass
-#define BS_WAVE_HITS 384    // hit entries per wave and tile (typ. ~70); beyond: exact per-doc fallback
-#define BS_HITCAP (BS_WAVE_HITS * BS_THREADS / 64)
+#define BS_WAVE_HITS 192    // hit entries per wave tile (typ. ~55; ~200 at 256 queries); beyond: exact per-doc fallback
 #define BS_BLOOM_WORDS 1024  // 4 KiB: <= 1024 keys in 32768 bits -> < 3 % false positives
 #define BS_NIL 0xFFFFu
 #define BS_LONGQ 0xFFFEu
-#define BS_TF_SLOTS 4096    // (doc, term) -> tf table of a tile (typ. ~600 pairs; 2000 at 256 queries)
+#define BS_TF_SLOTS 512     // (doc, term) -> tf table of a wave tile (more slots than BS_WAVE_HITS)
 #define BS_TF_EMPTY 0xFFFFFFFFu
 #define BS_K1 1.2f
 #define BS_B 0.75f
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
     const uint32_t n_pairs = q_offsets[q_begin + n_queries] - base;
     for (uint32_t i = tid; i < BS_HASH; i += 1024) { out->key[i] = 0xFFFFFFFFu; out->idf[i] = 0.f; cnt[i] = 0; }
     for (uint32_t i = tid; i < BS_BLOOM_WORDS; i += 1024) out->bloom[i] = 0;
-    if (tid == 0) { n_distinct = 0; sum_df = 0; out->docs_per_tile = BS_DPT; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
+    if (tid == 0) { n_distinct = 0; sum_df = 0; out->docs_per_tile = BS_WD; out->n_queries = n_queries; out->n_pairs = n_pairs; out->error = 0; }
     for (uint32_t q = tid; q <= n_queries; q += 1024) out->q_off[q] = q_offsets[q_begin + q] - base;
     __syncthreads();
     __shared__ uint32_t too_long;
@@ -117,17 +118,18 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
     __syncthreads();
     if (n_distinct > BS_MAX_TERMS) { if (tid == 0) out->error = 2; return; }
     if (tid == 0) {
-        // Tile size.  Phase 1 works in steps of BS_THREADS * BS_TPT tokens and the hit passes in rounds of
-        // BS_THREADS hits, both rounded up per tile, so the tile that wastes least depends on the batch:
-        // pick the docs per tile minimising (steps + 2.1 * hit rounds) / docs (the measured cost ratio of
-        // a hit round to a token step).
+        // Tile size (docs per WAVE tile).  Phase 1 works in steps of BS_STEP tokens and the hit passes in
+        // rounds of 64 hits, both rounded up per tile, so the tile that wastes least depends on the batch:
+        // pick the docs per tile minimising (steps + 4 * hit rounds) / docs (roughly the cost ratio of a
+        // hit round -- link + score -- to a token step).
         const float hpd = n_docs ? 1.05f * (float)sum_df / (float)n_docs : 0.f; // expected hits per doc
         float best = 3.4e38f;
-        uint32_t best_d = BS_DPT;
-        for (uint32_t d = 64; d <= BS_DPT; d += 32) {
-            const float steps = ceilf((float)d * avgdl / (float)(BS_THREADS * BS_TPT));
-            const float rounds = ceilf(fmaxf((float)d * hpd * 1.04f, 1.f) / (float)BS_THREADS);
-            const float cost = (steps + 2.1f * rounds) / (float)d;
+        uint32_t best_d = 8;
+        for (uint32_t d = 8; d <= BS_WD; d += 4) {
+            const float steps = ceilf((float)d * avgdl / (float)BS_STEP);
+            const float rounds = ceilf(fmaxf((float)d * hpd * 1.1f, 1.f) / 64.f);
+            const float cost = (steps + 4.f * rounds) / (float)d;
+            if (d > 8 && (float)d * hpd * 1.5f > (float)BS_WAVE_HITS) break; // the tile's hits must fit its hit array
             if (cost <= best) { best = cost; best_d = d; }
         }
         out->docs_per_tile = best_d;
@@ -167,48 +169,55 @@ __global__ __launch_bounds__(1024) void bm25_scan_setup(const uint32_t *q_terms,
 }
 
 // ------------------------------------------------------------------ the scan
+// Every WAVE is autonomous: it owns tiles of up to 64 consecutive docs (one contiguous token range),
+// scans, links and scores them out of its own slice of LDS, and never meets a workgroup barrier after
+// the batch tables are staged.  A workgroup is only eight such waves sharing those read-only tables and
+// one pool segment.
+struct BsWave {
+    uint32_t off[BS_WD + 1];       // token offsets of the tile's docs, relative to the tile's first token
+    uint32_t tf[BS_TF_SLOTS];      // doc << 11 | slot in the low 20 bits, tf above; BS_TF_EMPTY when free
+    uint32_t hit[BS_WAVE_HITS];    // slot | token index << 11 (phase 1), then slot | doc << 11 | representative << 20
+    uint32_t overflow_tile, pad[2];
+};
 struct BsShared {
     uint32_t key[BS_HASH];
     uint32_t users[BS_MAX_QT];
     uint32_t q_off[BS_MAX_Q + 1];
     uint32_t tau[BS_MAX_Q];
     uint32_t seg_fill[BS_MAX_Q];
-    uint32_t off[BS_DPT + 1];      // token offsets of the tile's docs, relative to the tile's first token
     uint32_t bloom[BS_BLOOM_WORDS];
-    uint32_t hit[BS_HITCAP];       // slot | token index << 11 (phase 1), then slot | doc << 11 | representative << 20
-    uint32_t tf[BS_TF_SLOTS];      // doc << 11 | slot in the low 20 bits, tf above; BS_TF_EMPTY when free
     alignas(16) float qp_idf[BS_MAX_Q][4];
     alignas(8) uint16_t qp_slots[BS_MAX_Q][4];
     uint16_t users_off[BS_HASH + 2];
     uint16_t q_slot[BS_MAX_QT];
-    uint32_t wave_cnt[BS_THREADS / 64], overflow_tile;
+    BsWave wave[BS_WAVES];
 };
 static_assert(sizeof(BsShared) <= 80 * 1024, "two 512-thread workgroups per CU");
 
-__device__ __forceinline__ uint32_t bs_wave_slot(bool pred, uint32_t *counter) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0) return 0;
-    const uint32_t lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
-    base = __shfl(base, leader, OI_WAVE);
-    return base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-}
-
 __device__ unsigned long long bs_timing[8]; // development aid (OI_BM25_SCAN_DBG=9): cycles per phase, summed over sampled waves
 
-__device__ __forceinline__ uint32_t bs_tf_hash(uint32_t key20) { return (key20 * 0x9E3779B1u) >> 20; } // 12 bits
+__device__ __forceinline__ uint32_t bs_tf_hash(uint32_t key20) { return (key20 * 0x9E3779B1u) >> 23; } // 9 bits
 
-// tf of (doc, slot) in the tile's table, 0 if the doc does not hold the term
-__device__ __forceinline__ uint32_t bs_tf_lookup(const BsShared &s, uint32_t key20) {
+// tf of (doc, slot) in the wave tile's table, 0 if the doc does not hold the term
+__device__ __forceinline__ uint32_t bs_tf_lookup(const BsWave &w, uint32_t key20) {
     for (uint32_t h = bs_tf_hash(key20);; h = (h + 1) & (BS_TF_SLOTS - 1)) {
-        const uint32_t v = s.tf[h];
+        const uint32_t v = w.tf[h];
         if (v == BS_TF_EMPTY) return 0;
         if ((v & 0xFFFFFu) == key20) return v >> 20;
     }
 }
 
+// Between a wave's phases.  The hardware keeps one wave's LDS operations in order, so what the wave
+// wrote is what it reads next; this only stops the compiler from moving or caching LDS accesses across
+// the phase boundary.  (Deliberately not a fence: a fence would also wait for the global loads in
+// flight -- the next tile's tokens -- and undo the software pipeline.)
+__device__ __forceinline__ void bs_wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool TM> // TM: per-phase cycle counters (development aid, OI_BM25_SCAN_DBG=9)
 __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
     const uint32_t *__restrict__ terms, const uint64_t *__restrict__ doc_offsets, uint64_t doc_begin,
     uint64_t doc_end, float avgdl, const BsBatch *__restrict__ batch, const uint32_t *tau_keys, uint32_t q_begin,
@@ -238,79 +247,79 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
     for (uint32_t i = tid; i < nq; i += BS_THREADS) { s.tau[i] = tau_keys ? tau_keys[q_begin + i] : 0u; s.seg_fill[i] = 0; }
     __syncthreads();
 
+    BsWave &w = s.wave[wv];
     uint64_t *my_seg = pools + (uint64_t)q_begin * pool_stride + carry_cap + (uint64_t)blockIdx.x * seg_cap;
-    const uint32_t D = batch->docs_per_tile; // docs per tile for this batch (<= BS_DPT)
+    const uint32_t D = batch->docs_per_tile; // docs per wave tile for this batch (<= BS_WD)
     const uint64_t n_tiles = (doc_end - doc_begin + D - 1) / D;
-    // Software pipeline over the workgroup's tiles: while a tile is linked and scored out of LDS, the
-    // next tile's tokens are already on their way into registers, and the offsets of the tile after that
-    // are being fetched -- the dependent HBM round trips (offsets, then tokens) are off a tile's path.
+    const uint64_t tile_stride = (uint64_t)gridDim.x * BS_WAVES;
+
+    // Software pipeline over the wave's tiles: while a tile is linked and scored out of LDS, the next
+    // tile's tokens are already on their way into registers, and the offsets of the tile after that are
+    // being fetched -- the dependent HBM round trips (offsets, then tokens) are off a tile's path.
     struct TileMeta {
-        uint64_t t0, mine; // first token of the tile; this lane's doc offset (the tile's end past the last doc)
-        uint32_t n_tok, nd;
+        uint64_t t0, tend, mine; // first token of the tile, one past its last; this lane's doc offset (tend past the last doc)
+        uint32_t nd;             // docs in the tile; 0 past the last tile
     };
+    // No branch around the loads (past the last tile the last tile is re-read and nd = 0 marks it void),
+    // and nothing is computed from the loaded values here: a wait would otherwise be placed at the end of
+    // the branch, i.e. a whole HBM round trip inside the tile's setup.
     auto fetch_meta = [&](uint64_t tile) {
-        TileMeta m{0, 0, 0, 0};
-        if (tile < n_tiles) {
-            const uint64_t d0 = doc_begin + tile * D;
-            m.nd = (uint32_t)((doc_end - d0) < D ? (doc_end - d0) : D);
-            // vector loads on purpose (a per-lane zero the compiler cannot see through): scalar loads would
-            // share lgkmcnt with LDS and make the next LDS wait sit out an HBM round trip
-            uint32_t z;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-            m.t0 = doc_offsets[d0 + z];
-            m.n_tok = (uint32_t)(doc_offsets[d0 + m.nd + z] - m.t0);
-            m.mine = doc_offsets[d0 + (tid < m.nd ? tid : m.nd)];
-        }
+        TileMeta m;
+        const uint64_t tl = tile < n_tiles ? tile : n_tiles - 1;
+        const uint64_t d0 = doc_begin + tl * D;
+        const uint32_t nd = (uint32_t)((doc_end - d0) < D ? (doc_end - d0) : D);
+        // vector loads on purpose (a per-lane zero the compiler cannot see through): scalar loads would
+        // share lgkmcnt with LDS and make the next LDS wait sit out an HBM round trip
+        uint32_t z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        m.t0 = doc_offsets[d0 + z];
+        m.tend = doc_offsets[d0 + nd + z];
+        m.mine = doc_offsets[d0 + (lane < nd ? lane : nd)];
+        m.nd = tile < n_tiles ? nd : 0u;
         return m;
     };
+    auto meta_ntok = [](const TileMeta &m) { return m.nd ? (uint32_t)(m.tend - m.t0) : 0u; };
     // a tile's token window: loads are never predicated -- a group past the tile's end re-reads the
     // tile's last group and its tokens fail the range test in scan_step
     auto load_step = [&](const TileMeta &m, uint32_t sb, uint32_t (&tk)[BS_TPT]) {
         const uint32_t headpad = (uint32_t)(m.t0 & 3u);
-        const uint32_t span = m.n_tok + headpad;
+        const uint32_t span = meta_ntok(m) + headpad;
         const uint32_t last_g = span ? ((span - 1u) & ~3u) : 0u;
-        const uint32_t *tbase = terms + (m.t0 - headpad);
-#pragma unroll
-        for (int v = 0; v < BS_TPT / 4; ++v) {
-            const uint32_t g = sb + tid * BS_TPT + 4u * v;
-            const uint4 x = *reinterpret_cast<const uint4 *>(tbase + (g < last_g ? g : last_g));
-            tk[4 * v] = x.x; tk[4 * v + 1] = x.y; tk[4 * v + 2] = x.z; tk[4 * v + 3] = x.w;
-        }
+        const uint32_t g = sb + lane * BS_TPT;
+        const uint4 x = *reinterpret_cast<const uint4 *>(terms + (m.t0 - headpad) + (g < last_g ? g : last_g));
+        tk[0] = x.x; tk[1] = x.y; tk[2] = x.z; tk[3] = x.w;
     };
-    constexpr uint32_t STEP = BS_THREADS * BS_TPT;
-    uint32_t tka[BS_PRE][BS_TPT]; // the first BS_PRE steps of a tile (a typical tile has 3)
-    TileMeta cur = fetch_meta(blockIdx.x);
-    if (cur.n_tok) {
+    uint32_t tka[BS_PRE][BS_TPT]; // the first BS_PRE steps of a tile
+    TileMeta cur = fetch_meta((uint64_t)blockIdx.x * BS_WAVES + wv);
+    if (meta_ntok(cur)) {
 #pragma unroll
-        for (int st = 0; st < BS_PRE; ++st) load_step(cur, st * STEP, tka[st]);
+        for (int st = 0; st < BS_PRE; ++st) load_step(cur, st * BS_STEP, tka[st]);
     }
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (uint64_t tile = (uint64_t)blockIdx.x * BS_WAVES + wv; tile < n_tiles; tile += tile_stride) {
+        const unsigned long long c0 = TM ? clock64() : 0ull;
         const uint64_t d0 = doc_begin + tile * D;
         const uint32_t nd = cur.nd;
         const uint64_t t0 = cur.t0;
-        const uint32_t n_tok = cur.n_tok;
-        const unsigned long long c0 = clock64();
-        __syncthreads(); // previous tile done
-        s.off[tid] = (uint32_t)(cur.mine - t0); // (docs past nd hold the tile's end)
-        for (uint32_t i = tid; i < BS_TF_SLOTS; i += BS_THREADS) s.tf[i] = BS_TF_EMPTY;
-        if (tid == 0) { // (nd may equal the block size: the end offset needs its own writer)
-            s.off[nd] = n_tok;
-            s.overflow_tile = 0;
+        const uint32_t n_tok = meta_ntok(cur);
+        w.off[lane] = (uint32_t)(cur.mine - t0); // (docs past nd hold the tile's end)
+        for (uint32_t i = lane; i < BS_TF_SLOTS; i += 64) w.tf[i] = BS_TF_EMPTY;
+        if (lane == 0) { // (nd may be 64: the end offset needs its own writer)
+            w.off[nd] = n_tok;
+            w.overflow_tile = n_tok >= (1u << 21); // a token index would not fit a hit entry
         }
-        const TileMeta nxt = fetch_meta(tile + gridDim.x); // arrives while this tile is scanned
-        __syncthreads();
-        if (n_tok >= (1u << 21) && tid == 0) s.overflow_tile = 1; // token index would not fit a hit entry
-        if (tid < nd && s.off[tid + 1] - s.off[tid] >= 4096u) s.overflow_tile = 1; // tf would not fit its 12 bits
+        TileMeta nxt = fetch_meta(tile + tile_stride); // arrives while this tile is scanned
+        bs_wave_sync();
+        if (lane < nd && w.off[lane + 1] - w.off[lane] >= 4096u) w.overflow_tile = 1; // tf would not fit its 12 bits
 
-        const unsigned long long c1 = clock64();
         // ---- phase 1: token-parallel scan.  Steps start 16-byte aligned in the token array.
-        uint32_t wave_hits = 0; // wave-uniform: hits this wave has appended to its region
+        const unsigned long long c1 = TM ? clock64() : 0ull;
+        uint32_t wave_hits = 0; // wave-uniform: hits appended to the tile's hit array
         const uint32_t headpad = (uint32_t)(t0 & 3u); // tokens before t0 in the first aligned group
         const uint32_t span = n_tok + headpad;        // tokens from the first aligned group to the tile's end
         auto scan_step = [&](uint32_t sb, const uint32_t (&tk)[BS_TPT]) {
             // tile-relative index of my first token (32-bit: a tile has fewer than 2^21 tokens) and which of my
             // BS_TPT tokens lie inside the tile
-            const int32_t rel0 = (int32_t)(sb + tid * BS_TPT) - (int32_t)headpad;
+            const int32_t rel0 = (int32_t)(sb + lane * BS_TPT) - (int32_t)headpad;
             const int32_t lo = rel0 < 0 ? -rel0 : 0, hi = (int32_t)n_tok - rel0;
             const uint32_t inside = hi <= lo ? 0u : (((hi >= BS_TPT ? 1u << BS_TPT : 1u << hi) - 1u) & ~((1u << lo) - 1u));
             // ONE LDS read per token (Bloom bit of its term id); ~4.5 % pass
@@ -322,8 +331,8 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
             }
             hmask &= inside;
             // every trip, each lane with a hit left resolves one (term -> slot in the LDS hash table; Bloom
-            // false positives die here) and the wave appends the survivors to its own region of the hit
-            // array: ballot + lane prefix, no atomics, no shuffles
+            // false positives die here) and the wave appends the survivors to the tile's hit array:
+            // ballot + lane prefix, no atomics, no shuffles
             while (__ballot(hmask != 0)) {
                 uint32_t ent = 0xFFFFFFFFu;
                 if (hmask) {
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 const uint64_t m = __ballot(ent != 0xFFFFFFFFu);
                 if (ent != 0xFFFFFFFFu) {
                     const uint32_t at = wave_hits + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (at < BS_WAVE_HITS) s.hit[wv * BS_WAVE_HITS + at] = ent;
+                    if (at < BS_WAVE_HITS) w.hit[at] = ent;
                 }
                 wave_hits += (uint32_t)__popcll(m);
             }
@@ -350,13 +359,13 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
         if (span) {
 #pragma unroll
             for (int st = 0; st < BS_PRE; ++st)
-                if (st * STEP < span) scan_step(st * STEP, tka[st]);
-            if (span > BS_PRE * STEP) { // a tile of long docs: the rest one step ahead
+                if (st * BS_STEP < span) scan_step(st * BS_STEP, tka[st]);
+            if (span > BS_PRE * BS_STEP) { // a tile of long docs: the rest one step ahead
                 uint32_t tk[BS_TPT], tkn[BS_TPT];
-                load_step(cur, BS_PRE * STEP, tk);
-                for (uint32_t sb = BS_PRE * STEP; sb < span; sb += STEP) {
-                    const bool more = sb + STEP < span;
-                    if (more) load_step(cur, sb + STEP, tkn);
+                load_step(cur, BS_PRE * BS_STEP, tk);
+                for (uint32_t sb = BS_PRE * BS_STEP; sb < span; sb += BS_STEP) {
+                    const bool more = sb + BS_STEP < span;
+                    if (more) load_step(cur, sb + BS_STEP, tkn);
                     scan_step(sb, tk);
                     if (more) {
 #pragma unroll
@@ -365,67 +374,57 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
-        const unsigned long long c2 = clock64();
-        if (nxt.n_tok) { // the next tile's tokens fly while this one is linked and scored
+        const unsigned long long c2 = TM ? clock64() : 0ull;
+        // (pins the first use of the prefetched offsets here: the compiler would otherwise compute with them
+        // -- and wait for them -- right after issuing the loads)
+        asm volatile("" : "+v"(nxt.t0), "+v"(nxt.tend), "+v"(nxt.mine));
+        if (meta_ntok(nxt)) { // the next tile's tokens fly while this one is linked and scored
 #pragma unroll
-            for (int st = 0; st < BS_PRE; ++st) load_step(nxt, st * STEP, tka[st]);
+            for (int st = 0; st < BS_PRE; ++st) load_step(nxt, st * BS_STEP, tka[st]);
         }
-        if (lane == 0) {
-            s.wave_cnt[wv] = wave_hits < BS_WAVE_HITS ? wave_hits : BS_WAVE_HITS;
-            if (wave_hits > BS_WAVE_HITS) s.overflow_tile = 1;
+        if (wave_hits > BS_WAVE_HITS) { // (uniform)
+            if (lane == 0) w.overflow_tile = 1;
+            wave_hits = BS_WAVE_HITS;
         }
         if (dbg == 1) { cur = nxt; continue; } // ablation: phase 1 only
-        // (no barrier: a wave links the hits it found itself)
-        // ---- link pass: every hit finds its doc (binary search in the tile's offsets); one hit per lane, no
-        // divergence between hit and miss lanes
-        {
-            const uint32_t nh = wave_hits < BS_WAVE_HITS ? wave_hits : BS_WAVE_HITS; // each wave links its own hits
-            for (uint32_t e = wv * BS_WAVE_HITS + lane; e < wv * BS_WAVE_HITS + nh; e += 64) {
-                const uint32_t x = s.hit[e];
-                const uint32_t r = x >> 11;
-                uint32_t lo = 0, hi = nd; // largest d with off[d] <= r
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (s.off[mid] <= r) lo = mid; else hi = mid;
-                }
-                // count the hit in the tile's (doc, term) -> tf table; the hit that creates the entry is the
-                // pair's representative and does the scoring
-                const uint32_t key20 = (lo << 11) | (x & 0x7FFu);
-                uint32_t rep = 0, probes = 0;
-                for (uint32_t h = bs_tf_hash(key20);; h = (h + 1) & (BS_TF_SLOTS - 1)) {
-                    uint32_t v = s.tf[h];
-                    if (v == BS_TF_EMPTY) {
-                        v = atomicCAS(&s.tf[h], BS_TF_EMPTY, key20 | (1u << 20));
-                        if (v == BS_TF_EMPTY) { rep = 1; break; }
-                    }
-                    if ((v & 0xFFFFFu) == key20) { atomicAdd(&s.tf[h], 1u << 20); break; }
-                    if (++probes == BS_TF_SLOTS) { s.overflow_tile = 1; break; } // table full
-                }
-                s.hit[e] = key20 | (rep << 20);
+        bs_wave_sync();
+        // ---- link pass: every hit finds its doc (binary search in the tile's offsets) and counts itself in
+        // the tile's (doc, term) -> tf table; the hit that creates the entry is the pair's representative
+        for (uint32_t e = lane; e < wave_hits; e += 64) {
+            const uint32_t x = w.hit[e];
+            const uint32_t r = x >> 11;
+            uint32_t lo = 0, hi = nd; // largest d with off[d] <= r
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (w.off[mid] <= r) lo = mid; else hi = mid;
             }
+            const uint32_t key20 = (lo << 11) | (x & 0x7FFu);
+            uint32_t rep = 0, probes = 0;
+            for (uint32_t h = bs_tf_hash(key20);; h = (h + 1) & (BS_TF_SLOTS - 1)) {
+                uint32_t v = w.tf[h];
+                if (v == BS_TF_EMPTY) {
+                    v = atomicCAS(&w.tf[h], BS_TF_EMPTY, key20 | (1u << 20));
+                    if (v == BS_TF_EMPTY) { rep = 1; break; }
+                }
+                if ((v & 0xFFFFFu) == key20) { atomicAdd(&w.tf[h], 1u << 20); break; }
+                if (++probes == BS_TF_SLOTS) { w.overflow_tile = 1; break; } // (cannot happen: more slots than hits)
+            }
+            w.hit[e] = key20 | (rep << 20);
         }
-        __syncthreads();
-
-        const unsigned long long c3 = clock64();
+        bs_wave_sync();
+        const unsigned long long c3 = TM ? clock64() : 0ull;
         // ---- phase 2: one lane per HIT (balanced: a long doc's hits spread over many lanes); only the
         // representative of a (doc, term) pair goes on.  For every query q using the term it looks up the
         // tf of q's terms in the tile's table, and scores the (doc, q) pair iff its term is the first of
         // q's terms (in query order) that the doc holds -- so each pair is scored exactly once, as the
         // f32 sum over q's terms IN QUERY ORDER.
         if (dbg == 2) { cur = nxt; continue; } // ablation: no scoring
-        uint32_t wstart[BS_THREADS / 64 + 1]; // the waves' regions, flattened: hit f lives in the region w with wstart[w] <= f
-        wstart[0] = 0;
-#pragma unroll
-        for (int w = 0; w < BS_THREADS / 64; ++w) wstart[w + 1] = wstart[w] + s.wave_cnt[w];
-        const uint32_t nh_all = wstart[BS_THREADS / 64];
-        for (uint32_t f = tid; f < nh_all && s.overflow_tile == 0 && dbg != 4; f += BS_THREADS) {
-            uint32_t he = f; // region base + index within the region
-#pragma unroll
-            for (int w = 1; w < BS_THREADS / 64; ++w) he = f >= wstart[w] ? (uint32_t)w * BS_WAVE_HITS + (f - wstart[w]) : he;
-            const uint32_t x = s.hit[he];
+        const bool tile_overflow = w.overflow_tile != 0; // (uniform)
+        for (uint32_t he = lane; he < wave_hits && !tile_overflow && dbg != 4; he += 64) {
+            const uint32_t x = w.hit[he];
             if (!((x >> 20) & 1u)) continue; // not the representative of its (doc, term) pair
             const uint32_t sl = x & 0x7FFu, d = (x >> 11) & 0x1FFu, dkey = x & 0xFF800u;
-            const uint32_t dlen = s.off[d + 1] - s.off[d];
+            const uint32_t dlen = w.off[d + 1] - w.off[d];
             const float ratio = __fdiv_rn((float)dlen, avgdl);
             const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
             const uint32_t ub = s.users_off[sl], ue = s.users_off[sl + 1];
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                     const uint32_t t[4] = {qs.x & 0xFFFFu, qs.x >> 16, qs.y & 0xFFFFu, qs.y >> 16};
                     uint32_t tf[4];
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) tf[p] = t[p] == BS_NIL ? 0u : bs_tf_lookup(s, dkey | t[p]);
+                    for (int p = 0; p < 4; ++p) tf[p] = t[p] == BS_NIL ? 0u : bs_tf_lookup(w, dkey | t[p]);
                     bool mine = true; // no earlier term of q occurs in the doc
 #pragma unroll
                     for (int p = 0; p < 3; ++p) mine = mine && !((uint32_t)p < pos_in_q && tf[p] != 0);
@@ -456,12 +455,12 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                     bool mine = true;
                     for (uint32_t p = qb; p < qb + pos_in_q; ++p) {
                         const uint32_t slp = s.q_slot[p];
-                        mine = mine && (slp == BS_NIL || bs_tf_lookup(s, dkey | slp) == 0);
+                        mine = mine && (slp == BS_NIL || bs_tf_lookup(w, dkey | slp) == 0);
                     }
                     if (!mine) continue;
                     for (uint32_t p = qb; p < qe; ++p) {
                         const uint32_t slp = s.q_slot[p];
-                        const uint32_t tf = slp == BS_NIL ? 0u : bs_tf_lookup(s, dkey | slp);
+                        const uint32_t tf = slp == BS_NIL ? 0u : bs_tf_lookup(w, dkey | slp);
                         if (tf == 0) continue;
                         const float ftf = (float)tf;
                         const float im = __fdiv_rn(__fmul_rn(ftf, BS_K1 + 1.0f), __fadd_rn(ftf, kd));
@@ -475,17 +474,15 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
-        const unsigned long long c4 = clock64();
-        const bool slow_doc = tid < nd && s.overflow_tile != 0;
-        // ---- every doc of a tile whose hits overflowed the hit array or the tf table (or with a 4096-token doc):
-        // the wave takes them one at a time, ONE LANE PER QUERY, counting tf straight from the doc's
-        // tokens (every lane reads the same token: a broadcast load that hits in cache, just streamed)
-        for (uint64_t sm = dbg == 3 ? 0ull : __ballot(slow_doc); sm; sm &= sm - 1) {
-            const uint32_t d = (tid & ~63u) + (uint32_t)__builtin_ctzll(sm);
-            const uint32_t dlen = s.off[d + 1] - s.off[d];
+        const unsigned long long c4 = TM ? clock64() : 0ull;
+        // ---- a tile whose hits overflowed the hit array (or with a 4096-token doc): the wave takes its
+        // docs one at a time, ONE LANE PER QUERY, counting tf straight from the doc's tokens (every lane
+        // reads the same token: a broadcast load that hits in cache, just streamed)
+        for (uint32_t d = 0; d < nd && tile_overflow && dbg != 3; ++d) {
+            const uint32_t dlen = w.off[d + 1] - w.off[d];
             const float ratio = __fdiv_rn((float)dlen, avgdl);
             const float kd = __fmul_rn(BS_K1, __fadd_rn(1.0f - BS_B, __fmul_rn(BS_B, ratio)));
-            const uint32_t *dt = terms + t0 + s.off[d];
+            const uint32_t *dt = terms + t0 + w.off[d];
             for (uint32_t q = lane; q < nq; q += 64) {
                 const uint2 qs = *reinterpret_cast<const uint2 *>(&s.qp_slots[q][0]);
                 float score = 0.0f;
@@ -528,10 +525,11 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
                 }
             }
         }
-        if (dbg == 9 && lane == 0 && (blockIdx.x & 15u) == 0) {
-            atomicAdd(&bs_timing[0], c1 - c0); // tile setup (barriers, offsets to LDS, tf table reset)
+        bs_wave_sync(); // the next tile overwrites this wave's slice
+        if (TM && lane == 0 && (blockIdx.x & 15u) == 0) {
+            atomicAdd(&bs_timing[0], c1 - c0); // tile setup (offsets to LDS, tf table reset)
             atomicAdd(&bs_timing[1], c2 - c1); // phase 1
-            atomicAdd(&bs_timing[2], c3 - c2); // next tile's loads issued, link, barrier
+            atomicAdd(&bs_timing[2], c3 - c2); // next tile's loads issued, link
             atomicAdd(&bs_timing[3], c4 - c3); // phase 2
             atomicAdd(&bs_timing[4], clock64() - c4);
             atomicAdd(&bs_timing[5], 1ull);
@@ -548,14 +546,15 @@ __global__ __launch_bounds__(BS_THREADS) void bm25_scan_kernel(
 
 // ------------------------------------------------------------------ host
 void oi_bm25_scan_geometry(const oi_ctx *ctx, uint64_t n_docs, uint32_t *n_segs, uint32_t *seg_cap) {
-    const uint64_t n_tiles = (n_docs + BS_DPT - 1) / BS_DPT;
+    const uint64_t wg_docs = (uint64_t)BS_WAVES * BS_WD; // docs one workgroup takes per round, at most
+    const uint64_t n_rounds = (n_docs + wg_docs - 1) / wg_docs;
     uint64_t grid = 2ull * (uint64_t)ctx->num_cus; // two 512-thread workgroups per CU
-    if (grid > n_tiles) grid = n_tiles;
+    if (grid > n_rounds) grid = n_rounds;
     if (grid == 0) grid = 1;
     *n_segs = (uint32_t)grid;
-    // docs one workgroup can meet, whatever tile size (<= BS_DPT) the batch picks: n_docs / grid rounded up
-    // to whole tiles plus one tile
-    *seg_cap = (uint32_t)(((n_tiles + grid - 1) / grid + 1) * BS_DPT);
+    // docs one workgroup can meet, whatever tile size (<= BS_WD per wave) the batch picks: n_docs / grid
+    // rounded up to whole rounds plus one round
+    *seg_cap = (uint32_t)(((n_rounds + grid - 1) / grid + 1) * wg_docs);
 }
 
 uint32_t oi_bm25_scan_max_queries() { return BS_MAX_Q; }
@@ -577,9 +576,13 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     OI_REQUIRE(nq <= BS_MAX_Q, "bm25 scan: %u queries in one pass (limit %u)", nq, BS_MAX_Q);
     DevBuf &bb = ctx->buf("bm25_scan_batch");
     OI_CHECK(bb.ensure(sizeof(BsBatch)));
+    static const int dbg = getenv("OI_BM25_SCAN_DBG") ? atoi(getenv("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
+    auto kernel = dbg == 9 ? bm25_scan_kernel<true> : bm25_scan_kernel<false>;
     static bool attr = false;
     if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel),
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BsShared)));
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BsShared)));
         attr = true;
     }
@@ -589,9 +592,8 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
                            (uint64_t)idx->n_docs, avgdl, bb.as<BsBatch>());
         OI_HIP_CHECK(hipGetLastError());
     }
-    static const int dbg = getenv("OI_BM25_SCAN_DBG") ? atoi(getenv("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
     ProfScope ps(ctx, "bm25");
-    hipLaunchKernelGGL(bm25_scan_kernel, dim3(pool.n_segs), dim3(BS_THREADS), sizeof(BsShared), ctx->stream,
+    hipLaunchKernelGGL(kernel, dim3(pool.n_segs), dim3(BS_THREADS), sizeof(BsShared), ctx->stream,
                        idx->fwd_terms.as<uint32_t>(), idx->fwd_offsets.as<uint64_t>(), doc_begin, doc_end, avgdl,
                        bb.as<BsBatch>(), pool.tau_keys, q_begin, idx->doc_id_base, pool.keys, pool.seg_cnt,
                        pool.seg_cnt_stride, pool.stride, pool.carry_cap, pool.seg_cap, pool.overflow, dbg);

@@ -2,7 +2,7 @@
 """BM25 kernels alone at the bench shape: 10M-doc synthetic forward index, 64 queries x 4 terms, depth 1000.
 Runs the term-at-a-time kernel and the batch scan, checks that their ranked lists are identical, and
 prints one JSON line with the per-batch kernel times (HIP events inside the library).
-    python tools/bm25_bench.py [n_docs] [reps]"""
+    python tools/bm25_bench.py [n_docs] [reps] [batch]"""
 import json
 import os
 import sys
@@ -16,7 +16,8 @@ from openintel_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-B, DIM, DEPTH = 64, 32, 1000   # a narrow embedding keeps the cosine leg out of the way
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+DIM, DEPTH = 32, 1000   # a narrow embedding keeps the cosine leg out of the way
 dev = torch.device("cuda:0")
 ctx = oi.HipContext(0)
 ctx.use_torch_current_stream()
