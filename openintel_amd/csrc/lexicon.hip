@@ -391,6 +391,13 @@ __device__ __forceinline__ void lex2_lookup(Lex2Shared &s, uint32_t mult, uint32
     lex2_hit(s, mult, k0, k1, c8, len, j);
 }
 
+// The 16-byte piece the blob ends in, zero-filled past the end.
+__device__ __noinline__ uint4 lex_load_tail(const uint8_t *blob, uint64_t src, uint64_t blob_bytes) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < 16 && src + i < blob_bytes; ++i) w[i >> 2] |= (uint32_t)blob[src + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
                                                               uint64_t n, uint64_t blob_bytes,
                                                               const LexEntry *table, const uint32_t *bloom,
@@ -418,18 +425,31 @@ __global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blo
         for (uint32_t sb = 0; sb < n_bytes + head; sb += LX_SUB) {
             // this sub-tile covers tile-relative positions [sb - head, sb - head + LX_SUB)
             const uint64_t g0 = byte_begin - head + sb; // absolute, 16-byte aligned
-            // ---- stage [g0-16, g0+LX_SUB+16) -> LDS, 16 B per lane per step, zeros outside the blob
-            for (uint32_t v = tid; v < LX_SUB / 16 + 2; v += LEX_THREADS) {
+            // ---- stage [g0-16, g0+LX_SUB+16) -> LDS, 16 B per lane per step, zeros outside the blob.
+            // The loads are not predicated (a unit outside the blob reads the blob's first 16 bytes and is
+            // zeroed afterwards), so a lane's five are in flight together instead of each waiting at the
+            // end of its own branch.
+            constexpr uint32_t kUnits = LX_SUB / 16 + 2;
+            constexpr uint32_t kSteps = (kUnits + LEX_THREADS - 1) / LEX_THREADS;
+            uint4 xs[kSteps];
+            if (blob_bytes >= 16) {
+#pragma unroll
+                for (uint32_t k = 0; k < kSteps; ++k) {
+                    const uint64_t a = g0 + (uint64_t)(tid + k * LEX_THREADS) * 16; // absolute address + 16 (slot 0 = g0-16)
+                    const bool whole = a >= 16 && a <= blob_bytes;                  // [a-16, a) inside the blob
+                    xs[k] = *reinterpret_cast<const uint4 *>(blob + (whole ? a - 16 : 0));
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < kSteps; ++k) {
+                const uint32_t v = tid + k * LEX_THREADS;
+                if (v >= kUnits) continue;
+                const uint64_t a = g0 + (uint64_t)v * 16;
                 uint4 x = make_uint4(0, 0, 0, 0);
-                const uint64_t a = g0 + (uint64_t)v * 16; // absolute address + 16 (slot 0 = g0-16)
                 if (a >= 16) {
                     const uint64_t src = a - 16;
-                    if (src + 16 <= blob_bytes) x = *reinterpret_cast<const uint4 *>(blob + src);
-                    else if (src < blob_bytes) {
-                        uint32_t w[4] = {0, 0, 0, 0};
-                        for (uint32_t i = 0; src + i < blob_bytes; ++i) w[i >> 2] |= (uint32_t)blob[src + i] << (8 * (i & 3));
-                        x = make_uint4(w[0], w[1], w[2], w[3]);
-                    }
+                    if (src + 16 <= blob_bytes) x = xs[k];
+                    else if (src < blob_bytes) x = lex_load_tail(blob, src, blob_bytes); // the piece the blob ends in
                 }
                 const uint32_t D = 4u * v; // logical dword of this 16-byte unit
                 const uint32_t P = v == 0 ? 0u : lx_phys(D);
