@@ -136,9 +136,23 @@ class PostText:
     def __init__(self, s: str):
         self._s = s
 
+    # char::is_whitespace (Unicode White_Space), which is what str::trim strips -- not Python's
+    # str.strip(), which also strips U+001C..U+001F
+    _WS = frozenset("\t\n\x0b\x0c\r \x85\xa0\u1680\u2000\u2001\u2002\u2003\u2004\u2005\u2006\u2007\u2008"
+                    "\u2009\u200a\u2028\u2029\u202f\u205f\u3000")
+
+    @staticmethod
+    def rust_trim(s: str) -> str:
+        a, b = 0, len(s)
+        while a < b and s[a] in PostText._WS:
+            a += 1
+        while b > a and s[b - 1] in PostText._WS:
+            b -= 1
+        return s[a:b]
+
     @staticmethod
     def parse(raw: str) -> "PostText":  # social_post.rs:14-23
-        trimmed = raw.strip()
+        trimmed = PostText.rust_trim(raw)
         if not trimmed:
             raise InvalidPostText("empty")
         if len(trimmed) > MAX_POST_LEN:  # chars, not bytes
