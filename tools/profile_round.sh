@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-end profile collection on the GPU box (one gpurun call):
+#   rocprofv3 --kernel-trace --stats over bench.py and the three side benches, then the PMC passes.
+# Usage: tools/profile_round.sh <tag>      (writes under gpurun_out/<tag>/)
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+T=${1:-prof}
+OUT=$R/gpurun_out/$T
+mkdir -p $OUT
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err && echo "bench ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
+python3 $R/tools/headline_bench.py 10000000 10 > $OUT/headline_bench.json 2> $OUT/headline_bench.err && echo "headline ok"
+python3 $R/tools/lexicon_bench.py 10000000 10 > $OUT/lexicon_bench.json 2> $OUT/lexicon_bench.err && echo "lexicon ok"
+python3 $R/tools/bm25_bench.py 10000000 5 > $OUT/bm25_bench.json 2> $OUT/bm25_bench.err && echo "bm25 ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/tools/headline_bench.py 10000000 5 > /dev/null 2> $OUT/stats_headline.err && echo "stats headline ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bm25 -- python3 $R/tools/bm25_bench.py 10000000 3 > /dev/null 2> $OUT/stats_bm25.err && echo "stats bm25 ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lexicon -- python3 $R/tools/lexicon_bench.py 10000000 5 > /dev/null 2> $OUT/stats_lexicon.err && echo "stats lexicon ok"
