@@ -77,6 +77,11 @@ void oi_destroy(oi_ctx *ctx);
 int oi_set_stream(oi_ctx *ctx, void *hip_stream);
 int oi_synchronize(oi_ctx *ctx);
 
+/* A hybrid query has two independent legs until fusion.  By default the BM25 leg is issued on an
+ * internal side stream (forked from and joined back into the ctx stream inside the call) so that it
+ * runs beside the MFMA-bound cosine leg; enable = 0 runs them one after the other. */
+int oi_set_overlap(oi_ctx *ctx, int enable);
+
 /* ------------------------------------------------------------------------- */
 /* PostAnalyzer path (reference-pinned)                                        */
 /* ------------------------------------------------------------------------- */

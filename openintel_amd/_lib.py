@@ -58,6 +58,7 @@ SIGNATURES = {
     "oi_synchronize": (_I, [_P]),
     "oi_lexicon_analyze": (_I, [_P, _P, _P, _U64, _P, _P]),
     "oi_lexicon_analyze_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P]),
+    "oi_set_overlap": (_I, [_P, _I]),
     "oi_catalyst_keyword": (C.c_char_p, [_U32]),
     "oi_headline_scan": (_I, [_P, _P, _P, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
     "oi_headline_scan_device": (_I, [_P, _P, _P, _U64, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),

@@ -31,6 +31,10 @@ class HipContext:
     def synchronize(self) -> None:
         _lib.check(self.lib.oi_synchronize(self.handle))
 
+    def set_overlap(self, enable: bool) -> None:
+        """BM25 leg of a hybrid query beside the cosine leg on a side stream (default) or after it."""
+        _lib.check(self.lib.oi_set_overlap(self.handle, 1 if enable else 0))
+
     # ---- HIP-event kernel timing (bench.py)
     def profile_reset(self, enable: bool = True) -> None:
         _lib.check(self.lib.oi_profile_reset(self.handle, 1 if enable else 0))

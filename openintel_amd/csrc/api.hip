@@ -108,6 +108,11 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->device = device_ordinal;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->stream = nullptr;
+    // best effort: without these the two legs of a query simply run one after the other
+    // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) c->ev_join = nullptr;
     *out = c;
     return OI_OK;
 }
@@ -116,6 +121,9 @@ extern "C" void oi_destroy(oi_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     oi_profile_reset(ctx, 0);
     for (auto &kv : ctx->ws) kv.second.release();
     delete ctx;
@@ -125,6 +133,13 @@ extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return OI_OK;
+}
+
+extern "C" int oi_set_overlap(oi_ctx *ctx, int enable) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->overlap_legs = enable != 0;
     return OI_OK;
 }
 
@@ -444,35 +459,15 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     Pools P;
     OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, idx->n_blocks, depth, &P));
 
-    // ---- cosine list
-    if (cos_s) {
-        OI_REQUIRE(idx->rows, "search: embeddings not set");
-        const uint32_t Bp = oi_cosine_query_padding(B);
-        const float *q = d_qv;
-        if (Bp != B) {
-            DevBuf &qp = ctx->buf("q_padded");
-            OI_CHECK(qp.ensure(sizeof(float) * (size_t)Bp * idx->dim));
-            OI_HIP_CHECK(hipMemsetAsync(qp.p, 0, sizeof(float) * (size_t)Bp * idx->dim, st));
-            OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
-            q = qp.as<float>();
-        }
-        const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
-        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
-        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
-        uint64_t r = 0;
-        while (r < n) {
-            if (chunk > max_chunk) chunk = max_chunk;
-            const uint64_t e = std::min(n, r + chunk);
-            OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
-            const bool last = e == n;
-            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
-                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
-            r = e;
-            chunk *= 8;
-        }
-    }
+    // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
+    // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
+    // leaves, instead of running after it.  OI_NO_OVERLAP=1 serialises them (A/B runs).
+    static const bool no_overlap = getenv("OI_NO_OVERLAP") != nullptr;
+    const bool overlap = cos_s && bm_s && ctx->side_stream && ctx->ev_fork && ctx->ev_join && ctx->overlap_legs && !no_overlap;
     // ---- BM25 list
-    if (bm_s) {
+    auto bm25_leg = [&]() -> int {
+        hipStream_t st = ctx->stream; // (the side stream when the legs overlap)
+        (void)st;
         OI_REQUIRE(idx->finalized, "search: index not finalized");
         // Which BM25 kernel: the term-at-a-time kernel is the default for every batch size (0.6 ms per
         // 64-query batch at 10M docs vs 2.0 ms for the forward scan today); the scan is selected per
@@ -537,7 +532,46 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 }
             }
         }
+        return OI_OK;
+    };
+    if (overlap) {
+        OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // pools are reset, queries staged
+        OI_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        ctx->stream = ctx->side_stream;
+        const int rc = bm25_leg();
+        ctx->stream = st;
+        OI_CHECK(rc);
+        OI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side_stream));
     }
+    // ---- cosine list
+    if (cos_s) {
+        OI_REQUIRE(idx->rows, "search: embeddings not set");
+        const uint32_t Bp = oi_cosine_query_padding(B);
+        const float *q = d_qv;
+        if (Bp != B) {
+            DevBuf &qp = ctx->buf("q_padded");
+            OI_CHECK(qp.ensure(sizeof(float) * (size_t)Bp * idx->dim));
+            OI_HIP_CHECK(hipMemsetAsync(qp.p, 0, sizeof(float) * (size_t)Bp * idx->dim, st));
+            OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
+            q = qp.as<float>();
+        }
+        const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
+        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
+        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+        uint64_t r = 0;
+        while (r < n) {
+            if (chunk > max_chunk) chunk = max_chunk;
+            const uint64_t e = std::min(n, r + chunk);
+            OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
+            const bool last = e == n;
+            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+            r = e;
+            chunk *= 8;
+        }
+    }
+    if (overlap) OI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    else if (bm_s) OI_CHECK(bm25_leg());
     return OI_OK;
 }
 

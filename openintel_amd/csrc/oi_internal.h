@@ -64,6 +64,9 @@ struct oi_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_legs = true;              // oi_set_overlap
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     bool prof_enabled = false;
