@@ -166,6 +166,13 @@ void oi_index_destroy(oi_index *idx);
  * place when OI_DEVICE).  OI_DEVICE borrows the pointer; OI_HOST copies to HBM. */
 int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize);
 
+/* A bf16 corpus instead (BASELINE configs[4]): rows n_docs x dim of bfloat16 bit patterns, row-major,
+ * unit-norm as stored (no normalisation is applied), dim in {384, 768, 1024}.  OI_DEVICE borrows the
+ * pointer (16-byte aligned); OI_HOST copies to HBM.  Queries stay f32 at the API and are rounded to
+ * bf16 (nearest even) inside: a score is sum_k bf16(q_k) * x_k accumulated in f32.  Replaces any f32
+ * matrix set before, and vice versa. */
+int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows, int location);
+
 /* Forward index: doc d owns term_ids[doc_offsets[d] .. doc_offsets[d+1]),
  * every id < vocab.  Stages the postings and computes local statistics. */
 int oi_index_set_forward(oi_index *idx, const uint32_t *term_ids, const uint64_t *doc_offsets,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "oi_index_create": (_I, [_P, _U64, _U32, _U32, _U32, C.POINTER(_P)]),
     "oi_index_destroy": (None, [_P]),
     "oi_index_set_embeddings": (_I, [_P, _P, _I, _I]),
+    "oi_index_set_embeddings_bf16": (_I, [_P, _P, _I]),
     "oi_index_set_forward": (_I, [_P, _P, _P, _I]),
     "oi_index_local_stats": (_I, [_P, C.POINTER(_U64), _P]),
     "oi_index_set_max_query_terms": (_I, [_P, _U32]),

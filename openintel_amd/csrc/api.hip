@@ -308,6 +308,7 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         (void)hipSetDevice(idx->ctx->device);
         (void)hipStreamSynchronize(idx->ctx->stream);
         if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
+        if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
         idx->postings.release(); idx->cell_start.release(); idx->idf.release();
         idx->fwd_terms.release(); idx->fwd_offsets.release();
@@ -321,6 +322,8 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
     if (idx->rows_owned && idx->rows) { (void)hipFree(idx->rows); idx->rows = nullptr; idx->rows_owned = false; }
+    if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
+    idx->rows_bf16 = nullptr; idx->rows_bf16_owned = false;
     const size_t bytes = (size_t)idx->n_docs * idx->dim * sizeof(float);
     if (location == OI_DEVICE) {
         OI_REQUIRE(((uintptr_t)rows & 15u) == 0, "index: embedding matrix must be 16-byte aligned");
@@ -334,6 +337,31 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     }
     if (normalize) OI_CHECK(oi_launch_l2_normalize(ctx, idx->rows, idx->n_docs, idx->dim));
     OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OI_OK;
+}
+
+extern "C" int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows, int location) {
+    if (!idx || !rows) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    OI_REQUIRE(oi_cosine_bf16_supported(idx->dim), "index: a bf16 corpus needs dim 384, 768 or 1024 (got %u)", idx->dim);
+    if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
+    idx->rows = nullptr; idx->rows_owned = false;
+    if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
+    idx->rows_bf16 = nullptr; idx->rows_bf16_owned = false;
+    const size_t bytes = (size_t)idx->n_docs * idx->dim * sizeof(uint16_t);
+    if (location == OI_DEVICE) {
+        OI_REQUIRE(((uintptr_t)rows & 15u) == 0, "index: embedding matrix must be 16-byte aligned");
+        idx->rows_bf16 = const_cast<uint16_t *>(rows);
+    } else {
+        void *p = nullptr;
+        OI_HIP_CHECK(hipMalloc(&p, bytes));
+        idx->rows_bf16 = reinterpret_cast<uint16_t *>(p);
+        idx->rows_bf16_owned = true;
+        OI_HIP_CHECK(hipMemcpyAsync(idx->rows_bf16, rows, bytes, hipMemcpyHostToDevice, ctx->stream));
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     return OI_OK;
 }
 
@@ -448,7 +476,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // query, so a chunk sized from the pool's free room can never overflow it (no overflow path
     // to handle, no data-dependent sizing).  BM25: every doc block contributes <= depth entries.
     const uint32_t carry_cap = OI_MAX_DEPTH;
-    const uint64_t slack = 32ull * ((uint64_t)ctx->num_cus + 1);
+    const uint64_t slack = (idx->rows_bf16 ? 128ull : 32ull) * ((uint64_t)ctx->num_cus + 1);
     // Large pools = few launches: at 10M rows the schedule is 32K, 256K, 2M, rest (4 launches).
     // The room is address space, not traffic: only entries that pass the threshold are written.
     uint64_t cos_stride = 1ull << 24;
@@ -544,7 +572,25 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         OI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side_stream));
     }
     // ---- cosine list
-    if (cos_s) {
+    if (cos_s && idx->rows_bf16) {
+        // bf16 corpus: same chunk schedule; a workgroup's segment is rounded up to four tiles per wave round
+        const uint64_t bslack = 128ull * ((uint64_t)ctx->num_cus + 1);
+        const uint64_t room = cos_stride - carry_cap;
+        const uint64_t max_chunk = room > bslack ? room - bslack : 0;
+        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
+        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+        uint64_t r = 0;
+        while (r < n) {
+            if (chunk > max_chunk) chunk = max_chunk;
+            const uint64_t e = std::min(n, r + chunk);
+            OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->rows_bf16, r, e, idx->dim, d_qv, B, idx->doc_id_base, P.cos));
+            const bool last = e == n;
+            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+            r = e;
+            chunk *= 8;
+        }
+    } else if (cos_s) {
         OI_REQUIRE(idx->rows, "search: embeddings not set");
         const uint32_t Bp = oi_cosine_query_padding(B);
         const float *q = d_qv;

@@ -1,0 +1,303 @@
+// cosine_bf16.hip -- the cosine scorer over a bf16 corpus (BASELINE configs[4]: 100M x 1024-d bf16).
+//
+// Builder-defined like the rest of the retrieval path (the reference has none).  Scores are
+// sum_k bf16(q_k) * x_k accumulated in f32 by v_mfma_f32_32x32x16_bf16 (products of two bf16 values
+// are exact in f32), i.e. the cosine of the rows AS STORED with the queries rounded to bf16 -- the
+// oracle for this kernel does the same rounding and sums in f64.
+//
+// Regime.  At 2 bytes per element the scorer needs 64 flop per corpus byte at B = 64 while the matrix
+// pipes offer ~300: the kernel is HBM-bound (15.4 GB per pass at 10M x 768), so it is built to stream,
+// not to keep the MFMA pipe full:
+//   * one workgroup per CU, 4 waves, one per SIMD, each owning the full 512-register file.  There is
+//     NO K-split here: a wave holds ALL 64 queries over the whole K in registers (64 x 768 bf16 =
+//     96 KB = 384 VGPRs per lane, as B operands of the 32x32x16 MFMA) and owns whole 32-row tiles, so
+//     waves never meet -- no cross-wave sum, no barrier after the prologue;
+//   * each wave streams its tiles through its own LDS ring of 4 KiB slots (32 rows x 128 B = 64 bf16
+//     of K) with buffer_load ... lds, P slots ahead, ordered by counted s_waitcnt vmcnt, the prefetch
+//     running across tile boundaries (same DMA, descriptor and swizzle as cosine_ksplit.hip);
+//   * a lane's A fragment (8 consecutive bf16 of its row) is one conflict-free ds_read_b128 per MFMA
+//     group; the filter + pool append come straight out of the accumulators (the 32x32 D layout maps
+//     a lane to one query column), into this workgroup's private pool segment.
+// d = 1024 with 64 queries would need all 512 registers for the queries alone: it runs 32 queries per
+// pass (NQT = 1); d = 384 and 768 run 64.
+#include <cstdlib>
+#include <type_traits>
+
+#include "oi_device.h"
+#include "oi_internal.h"
+
+typedef float cb_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 cb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t cb_u32x4 __attribute__((ext_vector_type(4)));
+
+#define CB_TILE_ROWS 32
+#define CB_SLOT_K 64                 // bf16 of K per ring slot row (128 B)
+#define CB_SLOT_BYTES (CB_TILE_ROWS * 128)
+
+__device__ __forceinline__ uint32_t cb_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ cb_u32x4 cb_make_srd(const uint16_t *base, uint64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    cb_u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu); // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
+    r[3] = 0x00020000u;
+    return r;
+}
+// One 1-KiB LDS-DMA piece (8 rows x 128 B).  Lanes past the descriptor's end read as zero: the ragged
+// last tile needs no clamping.  hipcc does not see these loads: they are ordered by cb_wait<N>().
+__device__ __forceinline__ void cb_issue_piece(const cb_u32x4 &srd, uint32_t voff, uint32_t soff, uint32_t lds_dst,
+                                               bool skip) {
+    if (skip) return;
+    uint32_t keep;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(so), "s"(d)
+        : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void cb_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cb_static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void cb_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int D, int NQT>
+__global__ __launch_bounds__(256, 1) void cosine_bf16_filter(
+    const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const uint16_t *__restrict__ queries, // bf16 [32*NQT][D], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int NKC = D / CB_SLOT_K;                    // ring slots per tile
+    constexpr int NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
+    constexpr int P = NBUF - 1;                           // slots in flight ahead of the one being consumed
+    constexpr int KSTEPS = D / 16;                        // MFMA groups per tile
+    static_assert(D % CB_SLOT_K == 0 && NKC % NBUF == 0 && P >= 1 && P < NKC, "unsupported D");
+    static_assert(NQT * KSTEPS * 4 <= 400, "the query block must fit the register file");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                       // [4][NBUF][4 KiB]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * CB_SLOT_BYTES); // [32*NQT]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t li = lane & 31, lh = lane >> 5;
+
+    // ---- every query over the whole K, in registers for the whole launch: B[k = 16 s + 8 lh + 0..7][n = li]
+    cb_bf16x8 qreg[NQT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            qreg[t][s] = *reinterpret_cast<const cb_bf16x8 *>(queries + (uint64_t)(32 * t + li) * D + 16 * s + 8 * lh);
+    uint32_t tau[NQT]; // thresholds of the queries this lane filters
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32u * t + li;
+        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+    }
+    if (tid < 32 * NQT) seg_fill[tid] = 0;
+    __syncthreads(); // the only barrier: seg_fill is zero before any wave appends
+
+    // ---- tiles of this WAVE: (blockIdx.x * 4 + w), + 4 * gridDim.x, ...
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
+    const uint64_t first = (uint64_t)blockIdx.x * 4 + w, stride = (uint64_t)gridDim.x * 4;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+
+    if (my_nt) {
+        // per-lane source of the 4 DMA pieces of a slot: piece m covers tile rows 8m..8m+7; lane l -> row
+        // 8m + (l>>3), physical 16-B column l&7 holding LOGICAL column (l&7) ^ ((row>>1)&7)
+        uint32_t voff[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t prow = 8 * m + (lane >> 3);
+            voff[m] = prow * (uint32_t)(D * 2) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+        }
+        const uint32_t ring_w = cb_lds_addr(ring) + w * (NBUF * CB_SLOT_BYTES);
+        const unsigned char *ring_rd = ring + w * (NBUF * CB_SLOT_BYTES);
+        // fragment read address inside a slot: row li, logical 16-B column (2g + lh)
+        uint32_t frag_off[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
+
+        auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)CB_TILE_ROWS; };
+        auto tile_srd = [&](uint64_t ti) {
+            const uint64_t r0 = tile_row0(ti);
+            return cb_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 2));
+        };
+        cb_u32x4 cur = tile_srd(0), nxt = tile_srd(my_nt > 1 ? 1 : 0);
+        // Every load hipcc knows about (queries, thresholds) is retired HERE, with a wait it models:
+        // otherwise it re-waits for them inside the tile loop and drains the DMA ring.
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+#pragma unroll
+        for (int kc = 0; kc < P; ++kc) // prologue: slots 0..P-1 of the first tile
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                cb_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CB_SLOT_BYTES + m * 1024, false);
+
+        for (uint64_t ti = 0; ti < my_nt; ++ti) {
+            const bool has_next_tile = ti + 1 < my_nt;
+            cb_f32x16 acc[NQT];
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+            // Slot s of this tile lives in ring buffer s % NBUF.  Per MFMA group (kc, g): read the next
+            // fragment, NQT MFMAs on the current one, and DMA piece g of slot kc + P into the buffer slot
+            // kc - 1 has vacated; at g == 3 the next fragment is (kc + 1, 0), behind the counted wait that
+            // retires slot kc + 1 (P - 1 younger slots stay in flight).
+            cb_wait<4 * (P - 1)>();
+            cb_bf16x8 a_cur = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + frag_off[0]);
+            cb_static_for<0, NKC * 4>([&](auto gi_) {
+                constexpr int gi = decltype(gi_)::value;
+                constexpr int kc = gi / 4, g = gi % 4;
+                constexpr int sn = kc + P; // slot refilled during this slot's groups
+                cb_bf16x8 a_nxt = a_cur;
+                if constexpr (g < 3)
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + (kc % NBUF) * CB_SLOT_BYTES + frag_off[g + 1]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+                if constexpr (sn < NKC)
+                    cb_issue_piece(cur, voff[g], sn * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024, false);
+                else
+                    cb_issue_piece(nxt, voff[g], (sn - NKC) * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024,
+                                   !has_next_tile);
+                if constexpr (g == 3 && kc + 1 < NKC) {
+                    if (kc + P < NKC || has_next_tile) cb_wait<4 * (P - 1)>();
+                    else cb_wait<4 * (NKC - 2 - kc)>();
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + ((kc + 1) % NBUF) * CB_SLOT_BYTES + frag_off[0]);
+                }
+                a_cur = a_nxt;
+            });
+
+            // ---- filter + append, straight out of the accumulators: register r of query tile t holds
+            // D[row (r&3) + 8 (r>>2) + 4 lh][query 32 t + li]
+            const uint64_t row0 = tile_row0(ti);
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                const uint32_t q = 32u * t + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float s = acc[t][r];
+                    if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+                        const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+                        else *overflow = 1u;
+                    }
+                }
+            }
+            cur = nxt;
+            if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
+        }
+    }
+    __syncthreads(); // every wave's appends are counted
+    if (tid < 32 * NQT && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
+// ------------------------------------------------------------------ query staging: f32 -> bf16 (RNE), zero padded
+__global__ __launch_bounds__(256) void cb_stage_queries(const float *__restrict__ q, uint32_t n_queries, uint32_t n_padded,
+                                                        uint32_t dim, uint16_t *__restrict__ out) {
+    const uint64_t total = (uint64_t)n_padded * dim;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t row = (uint32_t)(i / dim);
+        uint16_t v = 0;
+        if (row < n_queries) {
+            const uint32_t u = __float_as_uint(q[i]);
+            v = (u & 0x7F800000u) == 0x7F800000u ? (uint16_t)(u >> 16)                        // inf / NaN: truncate
+                                                 : (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); // round to nearest even
+        }
+        out[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ host
+bool oi_cosine_bf16_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
+uint32_t oi_cosine_bf16_group(uint32_t dim) { return dim == 1024 ? 32u : 64u; } // queries per pass
+
+void oi_cosine_bf16_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
+    const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
+    const uint64_t quads = (n_tiles + 3) / 4; // a workgroup's four waves take four tiles at a time
+    const uint64_t grid = quads < (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (uint64_t)ctx->num_cus;
+    *n_segs = (uint32_t)grid;
+    *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * CB_TILE_ROWS;
+}
+
+template <int D, int NQT>
+static int launch_bf16(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                       uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    constexpr int NKC = D / CB_SLOT_K, NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
+    constexpr size_t smem = 4 * NBUF * CB_SLOT_BYTES + 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_bf16_filter<D, NQT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((cosine_bf16_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
+                       row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
+                       p.carry_cap, p.seg_cap, p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// All queries of a batch over rows [row_begin, row_end) of a bf16 corpus.  d_queries: f32 [n_queries][dim].
+int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                                const float *d_queries, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool) {
+    OI_REQUIRE(oi_cosine_bf16_supported(dim), "cosine (bf16 corpus): dim %u not instantiated (384, 768, 1024)", dim);
+    oi_cosine_bf16_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
+    OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
+               "cosine (bf16 corpus): chunk does not fit the candidate pool");
+    if (row_end <= row_begin || n_queries == 0) return OI_OK;
+    const uint32_t group = oi_cosine_bf16_group(dim);
+    const uint32_t n_padded = (n_queries + 31u) & ~31u;
+    DevBuf &qb = ctx->buf("q_bf16");
+    OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 32) * dim));
+    {
+        const uint64_t total = (uint64_t)n_padded * dim;
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 1024);
+        hipLaunchKernelGGL(cb_stage_queries, dim3(blocks), dim3(256), 0, ctx->stream, d_queries, n_queries, n_padded, dim,
+                           qb.as<uint16_t>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    ProfScope ps(ctx, "cosine");
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += group) {
+        const uint32_t nq_here = std::min(group, n_queries - q0);
+        const bool two = group == 64 && nq_here > 32;
+        PoolView p = pool;
+        p.keys += (uint64_t)q0 * pool.stride;
+        p.carry_cnt += q0;
+        p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
+        p.tau_keys += q0;
+        const uint16_t *qptr = qb.as<uint16_t>() + (uint64_t)q0 * dim;
+        switch (dim) {
+            case 384: OI_CHECK(two ? (launch_bf16<384, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))
+                                   : (launch_bf16<384, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
+            case 768: OI_CHECK(two ? (launch_bf16<768, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))
+                                   : (launch_bf16<768, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
+            default: OI_CHECK((launch_bf16<1024, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
+        }
+    }
+    return OI_OK;
+}

@@ -98,6 +98,8 @@ struct oi_index {
     // embeddings
     float *rows = nullptr; // device
     bool rows_owned = false;
+    uint16_t *rows_bf16 = nullptr; // device; set instead of `rows` for a bf16 corpus
+    bool rows_bf16_owned = false;
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;
@@ -169,6 +171,10 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
 uint64_t oi_cosine_max_chunk_rows(const oi_ctx *ctx, uint32_t dim, uint32_t n_queries, uint64_t stride,
                                   uint32_t carry_cap);
 int oi_launch_l2_normalize(oi_ctx *ctx, float *rows, uint64_t n, uint32_t dim);
+// cosine_bf16.hip
+bool oi_cosine_bf16_supported(uint32_t dim);
+int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                                const float *d_queries, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
 uint32_t oi_cosine_query_padding(uint32_t n_queries);
 // cosine_ksplit.hip
 bool oi_cosine_ksplit_supported(uint32_t dim);

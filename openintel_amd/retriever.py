@@ -108,6 +108,19 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_embeddings(self.handle, _lib.ptr(rows), loc, 1 if normalize else 0))
 
+    def set_embeddings_bf16(self, rows) -> None:
+        """A bf16 corpus: a torch.bfloat16 CUDA tensor [n_docs, dim] (borrowed, never copied) or a numpy
+        uint16 array of bfloat16 bit patterns (copied to HBM).  Rows must be unit-norm as stored."""
+        if _is_dev(rows):
+            assert rows.is_contiguous() and tuple(rows.shape) == (self.n_docs, self.dim) and rows.element_size() == 2
+            self._keep.append(rows)  # keep the borrowed matrix alive
+            loc = _lib.OI_DEVICE
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.uint16)
+            assert rows.shape == (self.n_docs, self.dim)
+            loc = _lib.OI_HOST
+        _lib.check(self.lib.oi_index_set_embeddings_bf16(self.handle, _lib.ptr(rows), loc))
+
     def set_forward(self, term_ids, doc_offsets) -> None:
         """Forward index: doc d owns term_ids[doc_offsets[d]:doc_offsets[d+1]] (u32 ids, u64 offsets)."""
         if _is_dev(term_ids):

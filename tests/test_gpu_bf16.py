@@ -1,0 +1,129 @@
+"""bf16 corpus (BASELINE configs[4]: bf16 embeddings): the cosine leg through cosine_bf16_filter.
+Builder-defined like the rest of the retrieval path (parity unpinned): the oracle is
+the f64 dot of the rows AS STORED with the queries rounded to bf16 (what the kernel is specified to
+compute, f32-accumulated); tolerance 1e-5 absolute, and bit-exact with small-integer embeddings."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+COS_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import openintel_amd as oi
+    c = oi.HipContext(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import lib
+    return lib
+
+
+def to_bf16_bits(x):
+    """f32 -> bfloat16 bit patterns, round to nearest even."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16_bits(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def _forward(rng, n, vocab=50):
+    lens = rng.integers(1, 9, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    return rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32), offs
+
+
+def _index(ctx, bits, terms, offs, vocab, base=0):
+    import openintel_amd as oi
+    idx = oi.HybridIndex(ctx, bits.shape[0], bits.shape[1], vocab, base)
+    idx.set_embeddings_bf16(bits)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    return idx
+
+
+@pytest.mark.parametrize("B,dim,n", [(1, 768, 5000), (9, 384, 3000), (40, 768, 9000), (64, 768, 40_000),
+                                     (70, 384, 6000), (33, 1024, 5000), (64, 1024, 20_000), (3, 1024, 33)])
+def test_bf16_cosine_within_tolerance(ctx, O, B, dim, n):
+    from openintel_amd import synth
+    bits = to_bf16_bits(synth.embeddings_np(n, dim, seed=5 + B))
+    rows = from_bf16_bits(bits)                       # the corpus as stored
+    q = synth.embeddings_np(B, dim, seed=77 + B)
+    qr = from_bf16_bits(to_bf16_bits(q))              # what the kernel multiplies with
+    rng = np.random.default_rng(B)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, bits, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    for depth in (10, 1000):
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        for b in range(B):
+            ref = O.dot_scores(rows, qr[b])
+            c = int(L.cos_counts[b])
+            assert c == min(depth, n)
+            d, s = L.cos_docs[b][:c], L.cos_scores[b][:c]
+            assert np.unique(d).size == c and np.abs(s - ref[d]).max() <= COS_TOL
+            assert (np.diff(s) <= 0).all()
+            kth = np.sort(ref)[::-1][c - 1]
+            assert np.isin(np.nonzero(ref > kth + 2 * COS_TOL)[0], d).all() and (ref[d] >= kth - 2 * COS_TOL).all()
+    idx.close()
+
+
+@pytest.mark.parametrize("n,dim,B,depth,k", [(70_000, 384, 9, 1000, 100), (40_000, 768, 64, 10, 10),
+                                             (300_000, 384, 3, 100, 50), (5_000, 1024, 40, 1024, 1024)])
+def test_bf16_hybrid_pipeline_bit_exact(ctx, O, n, dim, B, depth, k):
+    # small integers are exact in bf16 and their dot products exact in f32 in any order: the whole
+    # pipeline (several cosine chunks, BM25, RRF) must match the oracle bit for bit
+    rng = np.random.default_rng(n + B)
+    rows = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+    q = rng.integers(-3, 4, size=(B, dim)).astype(np.float32)
+    vocab = 300
+    terms, offs = _forward(rng, n, vocab)
+    qt = rng.integers(0, 12, size=B * 4).astype(np.uint32)
+    qo = (np.arange(B + 1) * 4).astype(np.uint32)
+    idx = _index(ctx, to_bf16_bits(rows), terms, offs, vocab, base=1000)
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    R = idx.search(q, qt, qo, k=k, depth=depth)
+    for b in range(B):
+        cs, cd = O.topk(O.dot_scores(rows, q[b]), depth, False, 1000)
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, qt[qo[b]:qo[b + 1]]), depth, True, 1000)
+        fs, fd = O.rrf_fuse(cd, bd, k)
+        assert int(L.cos_counts[b]) == cd.size
+        assert np.array_equal(L.cos_docs[b][:cd.size], cd) and np.array_equal(L.cos_scores[b][:cd.size], cs)
+        assert np.array_equal(L.bm25_docs[b][:bd.size], bd)
+        assert int(R.counts[b]) == fd.size and np.array_equal(R.docs[b][:fd.size], fd)
+        assert np.array_equal(R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32))
+    idx.close()
+
+
+def test_bf16_device_tensor_and_errors(ctx, O):
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib, synth
+    n, dim, B = 10_000, 768, 5
+    x = torch.from_numpy(synth.embeddings_np(n, dim, seed=9)).cuda().to(torch.bfloat16).contiguous()
+    rows = x.float().cpu().numpy()
+    rng = np.random.default_rng(0)
+    terms, offs = _forward(rng, n)
+    idx = oi.HybridIndex(ctx, n, dim, 50)
+    idx.set_embeddings_bf16(x)                        # borrowed torch.bfloat16 tensor in HBM
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    q = synth.embeddings_np(B, dim, seed=10)
+    qr = from_bf16_bits(to_bf16_bits(q))
+    L = idx.search_lists(q, np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32), depth=100)
+    for b in range(B):
+        ref = O.dot_scores(rows, qr[b])
+        d = L.cos_docs[b][:100]
+        assert np.abs(L.cos_scores[b][:100] - ref[d]).max() <= COS_TOL
+    idx.close()
+    bad = oi.HybridIndex(ctx, 100, 96, 10)            # dim without a bf16 kernel: loud, not a fallback
+    with pytest.raises(_lib.OiError):
+        bad.set_embeddings_bf16(np.zeros((100, 96), np.uint16))
+    bad.close()
