@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--depth", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=131072)
     ap.add_argument("--bm25", choices=["taat", "scan"], default="taat", help="BM25 kernel (default: term-at-a-time)")
+    ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
+                    help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -107,7 +109,11 @@ def main():
     rows = synth.embeddings_torch(n_local, args.dim, dev, seed=synth.SEED_EMB + rank)
     terms, offs = synth.forward_index_torch(n_local, dev, vocab=args.vocab, seed=synth.SEED_TEXT + rank)
     idx = oi.HybridIndex(ctx, n_local, args.dim, args.vocab, doc_id_base=lo)
-    idx.set_embeddings(rows, normalize=False)          # rows are generated unit-norm
+    if args.corpus == "bf16":
+        rows = rows.to(torch.bfloat16)                 # stored as bf16 (unit norm up to the rounding)
+        idx.set_embeddings_bf16(rows)
+    else:
+        idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
     idx.set_forward(terms, offs)
     idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
     idx.set_bm25_mode(idx.BM25_SCAN if args.bm25 == "scan" else idx.BM25_TAAT)
@@ -190,8 +196,11 @@ def main():
         # (SURVEY.md 8d): flops = 2 * n_local * d * B, bytes = n_local * d * 4 (corpus read once per batch)
         flops_step = 2.0 * n_local * args.dim * args.batch
         bytes_step = 4.0 * n_local * args.dim
+        if args.corpus == "bf16":  # 2 B per element, one corpus pass per 64 queries (32 at d = 1024)
+            group = 32 if args.dim == 1024 else 64
+            bytes_step = 2.0 * n_local * args.dim * ((args.batch + group - 1) // group)
         cos_s = cos_ms / 1e3
-        if args.batch > 8:
+        if args.batch > 8 and args.corpus == "f32":
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}
         else:
@@ -201,7 +210,7 @@ def main():
         roof["traffic"] = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         # the committed PMC pass was taken on the default workload at N=1 only
-        if os.path.exists(pmc) and (args.docs, args.dim, args.batch, world) == (10_000_000, 768, 64, 1):
+        if os.path.exists(pmc) and (args.docs, args.dim, args.batch, world, args.corpus) == (10_000_000, 768, 64, 1, "f32"):
             try:
                 roof["traffic"] = json.load(open(pmc)).get("cosine_hbm_bytes_per_launch")
             except Exception:
@@ -213,19 +222,20 @@ def main():
         roof["hbm_GBs_algorithmic"] = bytes_step * args.steps / cos_s / 1e9
         roof["legs"] = "BM25 leg overlapped on a side stream during the timed region (oi_set_overlap)"
         roof["isolated"] = {"avg_launch_ms": iso_ms / max(1, iso_launches),
-                            "frac": (flops_step if args.batch > 8 else bytes_step) * iso_steps / (iso_ms / 1e3)
-                            / (1e12 if args.batch > 8 else 1e9) / roof["peak"],
+                            "frac": (flops_step if roof["bound"] == "mfma" else bytes_step) * iso_steps / (iso_ms / 1e3)
+                            / (1e12 if roof["bound"] == "mfma" else 1e9) / roof["peak"],
                             "note": "%d extra untimed steps with the legs serialised" % iso_steps}
         line = {
             "metric": "queries/sec + p50 latency, 10M-post/768-d hybrid BM25+cosine+RRF top-100",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %d posts x %d-d f32, batch %d queries x 4 BM25 terms, "
+            "vs_baseline": None, "dtype": args.corpus, "data": "synthetic",
+            "config": {"workload": "%s: %d posts x %d-d %s, batch %d queries x 4 BM25 terms, "
                                    "per-list depth %d, RRF top-%d; corpus row-sharded over %d GPU(s)" % (
+                                       "custom (bf16 corpus, the configs[4] regime)" if args.corpus == "bf16" else
                                        "BASELINE configs[2]" if (args.docs, args.batch) == (10_000_000, 64) else
                                        "BASELINE configs[1]" if (args.docs, args.batch) == (1_000_000, 1) else "custom",
-                                       args.docs, args.dim, args.batch, args.depth, args.k, world),
+                                       args.docs, args.dim, args.corpus, args.batch, args.depth, args.k, world),
                        "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
                        "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world},
