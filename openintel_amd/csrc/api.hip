@@ -497,9 +497,9 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         hipStream_t st = ctx->stream; // (the side stream when the legs overlap)
         (void)st;
         OI_REQUIRE(idx->finalized, "search: index not finalized");
-        // Which BM25 kernel: the term-at-a-time kernel is the default for every batch size (0.6 ms per
-        // 64-query batch at 10M docs vs 2.0 ms for the forward scan today); the scan is selected per
-        // index (oi_index_set_bm25_mode) or process-wide with OI_BM25_MODE=scan.
+        // Which BM25 kernel: the term-at-a-time kernel is the default for every batch size (0.61 ms per
+        // 64-query batch at 10M docs; the forward scan draws level at 0.62 ms and loses at larger batches);
+        // the scan is selected per index (oi_index_set_bm25_mode) or process-wide with OI_BM25_MODE=scan.
         static const char *mode_env = getenv("OI_BM25_MODE"); // "taat" | "scan"
         const bool have_fwd = idx->fwd_terms.p && idx->total_tokens > 0;
         const bool want_scan = idx->bm25_mode == 2 || (idx->bm25_mode == 0 && mode_env && strcmp(mode_env, "scan") == 0);
