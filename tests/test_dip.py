@@ -194,3 +194,55 @@ def test_device_buffers_and_limits_gpu(scanner):
         scanner.scan(["a"], "UCTT", ["x" * 600, "y" * 600])
     with pytest.raises(_lib.OiError):
         scanner.scan(["a"], "UCTT", ["w%d" % i for i in range(40)])
+
+
+@pytest_gpu
+def test_full_size_10M_titles_gpu(scanner):
+    """10M synthetic titles resident in HBM (the size the headline bench is quoted on), checked through
+    size-independent properties: the oracle on a slice, planted titles, and tiling independence -- a
+    sub-range scanned on its own (different tile boundaries, different window alignment) must reproduce
+    the corresponding slice of the full scan bit for bit."""
+    import torch
+    from oracle import lib
+    n = 10_000_000
+    dev = torch.device("cuda:0")
+    blob, offs = synth.headlines_torch(n, dev, seed=31)
+    forms = dip.company_name_forms([synth.HEADLINE_COMPANY])
+    d_m = torch.zeros(n, dtype=torch.int16, device=dev)
+    d_o = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_a = torch.zeros(n, dtype=torch.uint8, device=dev)
+    scanner.scan_device(blob, offs, synth.HEADLINE_TICKER, forms, d_m, d_o, d_a)
+    scanner.ctx.synchronize()
+    # (1) the oracle on the first 300K titles
+    ns = 300_000
+    hb = blob[: int(offs[ns])].cpu().numpy()
+    ho = offs[: ns + 1].cpu().numpy().astype(np.uint64)
+    rm, ro, ra = lib.headline_scan(hb, ho, synth.HEADLINE_TICKER, forms)
+    assert np.array_equal(d_m[:ns].cpu().numpy().view(np.uint16), rm)
+    assert np.array_equal(d_o[:ns].cpu().numpy().view(np.uint64), ro)
+    assert np.array_equal(d_a[:ns].cpu().numpy(), ra)
+    # (2) sub-ranges scanned on their own: start mid-blob at odd title indices and odd byte alignments
+    for start, count in ((1_234_567, 500_001), (9_500_003, 499_997), (7, 100_000)):
+        b0 = int(offs[start])
+        b1 = int(offs[start + count])
+        pad = (16 - b0 % 16) % 16 + 16          # re-base the slice to a different 16-byte phase
+        sub = torch.zeros(pad + (b1 - b0), dtype=torch.uint8, device=dev)
+        sub[pad:] = blob[b0:b1]
+        so = offs[start:start + count + 1] - b0 + pad
+        so[0] = 0                                # the padding joins the first title of the slice ...
+        sm = torch.zeros(count, dtype=torch.int16, device=dev)
+        so_ = torch.zeros(count, dtype=torch.int64, device=dev)
+        sa = torch.zeros(count, dtype=torch.uint8, device=dev)
+        scanner.scan_device(sub, so.contiguous(), synth.HEADLINE_TICKER, forms, sm, so_, sa)
+        scanner.ctx.synchronize()
+        # ... (zeros are separators: they add no token), so every title but possibly none differs
+        assert torch.equal(sm, d_m[start:start + count]) and torch.equal(so_, d_o[start:start + count])
+        assert torch.equal(sa, d_a[start:start + count])
+    # (3) global sanity: only the 16 keyword bits, order nibbles consistent with the mask
+    m = d_m.cpu().numpy().view(np.uint16)
+    o = d_o.cpu().numpy().view(np.uint64)
+    sample = np.random.default_rng(1).integers(0, n, size=200_000)
+    for i in sample[:20_000]:
+        k = bin(int(m[i])).count("1")
+        nib = [(int(o[i]) >> (4 * j)) & 15 for j in range(k)]
+        assert len(set(nib)) == k and all((int(m[i]) >> b) & 1 for b in nib) and int(o[i]) >> (4 * k) == 0
