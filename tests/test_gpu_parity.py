@@ -146,6 +146,48 @@ def test_lexicon_device_buffers_and_summary(ctx, O):
     assert cnt2.polarity_sum == cnt.polarity_sum
 
 
+def test_full_size_lexicon_10M_posts(ctx, O):
+    """10M synthetic posts in HBM (the size the lexicon figures are quoted on), through size-independent
+    properties: the oracle on a slice, re-based sub-ranges (other tile boundaries, other 16-byte phase)
+    reproducing the full scan bit for bit, and the summary counters against a device-side recount."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    n = 10_000_000
+    blob, offs = synth.posts_torch(n, dev, seed=77)
+    pol = torch.zeros(n, dtype=torch.float64, device=dev)
+    spec = torch.zeros(n, dtype=torch.uint8, device=dev)
+    an = oi.HipLexiconAnalyzer(ctx)
+    an.analyze_device(blob, offs, pol, spec)
+    ctx.synchronize()
+    ns = 300_000
+    rpol, rspec = O.lexicon_analyze(blob[: int(offs[ns])].cpu().numpy(), offs[: ns + 1].cpu().numpy().astype(np.uint64))
+    assert np.array_equal(pol[:ns].cpu().numpy().view(np.uint64), rpol.view(np.uint64))
+    assert np.array_equal(spec[:ns].cpu().numpy(), rspec)
+    for start, count in ((2_345_678, 400_001), (9_600_001, 399_999), (3, 50_000)):
+        b0, b1 = int(offs[start]), int(offs[start + count])
+        pad = (16 - b0 % 16) % 16 + 32
+        sub = torch.full((pad + (b1 - b0),), 32, dtype=torch.uint8, device=dev)   # spaces: no token
+        sub[pad:] = blob[b0:b1]
+        so = (offs[start:start + count + 1] - b0 + pad).contiguous()
+        so[0] = 0
+        sp = torch.zeros(count, dtype=torch.float64, device=dev)
+        ss = torch.zeros(count, dtype=torch.uint8, device=dev)
+        an.analyze_device(sub, so, sp, ss)
+        ctx.synchronize()
+        assert torch.equal(sp.view(torch.int64), pol[start:start + count].view(torch.int64))
+        assert torch.equal(ss, spec[start:start + count])
+    src = (torch.arange(n, device=dev) % 3 == 0).to(torch.uint8)
+    cfg = oi.EngineConfig()
+    cnt = oi.SpeculationEngine.social_counters(ctx, src, pol, spec, cfg)
+    tau = cfg.bull_bear_threshold
+    assert cnt.total == n and cnt.bullish == int((pol > tau).sum()) and cnt.bearish == int((pol < -tau).sum())
+    assert cnt.neutral == n - cnt.bullish - cnt.bearish and cnt.spec_count == int((spec != 0).sum())
+    assert list(cnt.by_source) == [n - int(src.sum()), int(src.sum())]
+    assert abs(cnt.polarity_sum - float(pol.sum())) <= n * 2.0 ** -52 * n   # two different summation trees
+
+
 # ----------------------------------------------------------------------------- retrieval helpers
 def _check_cos_list(scores, docs, count, ref_dense, depth, doc_base=0):
     n = ref_dense.size
