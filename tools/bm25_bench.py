@@ -21,6 +21,7 @@ DIM, DEPTH = 32, 1000   # a narrow embedding keeps the cosine leg out of the way
 dev = torch.device("cuda:0")
 ctx = oi.HipContext(0)
 ctx.use_torch_current_stream()
+ctx.set_overlap(False)  # time the BM25 kernels alone, not beside the cosine leg
 rows = synth.embeddings_torch(n, DIM, dev)
 terms, offs = synth.forward_index_torch(n, dev)
 n_tokens = int(offs[-1].item())
