@@ -568,52 +568,62 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         ctx->stream = ctx->side_stream;
         const int rc = bm25_leg();
         ctx->stream = st;
-        OI_CHECK(rc);
+        if (rc != OI_OK) { (void)hipStreamSynchronize(ctx->side_stream); return rc; } // nothing of this call stays in flight
         OI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side_stream));
     }
     // ---- cosine list
-    if (cos_s && idx->rows_bf16) {
-        // bf16 corpus: same chunk schedule; a workgroup's segment is rounded up to four tiles per wave round
-        const uint64_t bslack = 128ull * ((uint64_t)ctx->num_cus + 1);
-        const uint64_t room = cos_stride - carry_cap;
-        const uint64_t max_chunk = room > bslack ? room - bslack : 0;
-        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
-        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
-        uint64_t r = 0;
-        while (r < n) {
-            if (chunk > max_chunk) chunk = max_chunk;
-            const uint64_t e = std::min(n, r + chunk);
-            OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->rows_bf16, r, e, idx->dim, d_qv, B, idx->doc_id_base, P.cos));
-            const bool last = e == n;
-            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
-                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
-            r = e;
-            chunk *= 8;
+    auto cosine_leg = [&]() -> int {
+        if (cos_s && idx->rows_bf16) {
+            // bf16 corpus: same chunk schedule; a workgroup's segment is rounded up to four tiles per wave round
+            const uint64_t bslack = 128ull * ((uint64_t)ctx->num_cus + 1);
+            const uint64_t room = cos_stride - carry_cap;
+            const uint64_t max_chunk = room > bslack ? room - bslack : 0;
+            if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
+            uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+            uint64_t r = 0;
+            while (r < n) {
+                if (chunk > max_chunk) chunk = max_chunk;
+                const uint64_t e = std::min(n, r + chunk);
+                OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->rows_bf16, r, e, idx->dim, d_qv, B, idx->doc_id_base, P.cos));
+                const bool last = e == n;
+                OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                          last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+                r = e;
+                chunk *= 8;
+            }
+        } else if (cos_s) {
+            OI_REQUIRE(idx->rows, "search: embeddings not set");
+            const uint32_t Bp = oi_cosine_query_padding(B);
+            const float *q = d_qv;
+            if (Bp != B) {
+                DevBuf &qp = ctx->buf("q_padded");
+                OI_CHECK(qp.ensure(sizeof(float) * (size_t)Bp * idx->dim));
+                OI_HIP_CHECK(hipMemsetAsync(qp.p, 0, sizeof(float) * (size_t)Bp * idx->dim, st));
+                OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
+                q = qp.as<float>();
+            }
+            const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
+            if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
+            uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+            uint64_t r = 0;
+            while (r < n) {
+                if (chunk > max_chunk) chunk = max_chunk;
+                const uint64_t e = std::min(n, r + chunk);
+                OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
+                const bool last = e == n;
+                OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                          last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+                r = e;
+                chunk *= 8;
+            }
         }
-    } else if (cos_s) {
-        OI_REQUIRE(idx->rows, "search: embeddings not set");
-        const uint32_t Bp = oi_cosine_query_padding(B);
-        const float *q = d_qv;
-        if (Bp != B) {
-            DevBuf &qp = ctx->buf("q_padded");
-            OI_CHECK(qp.ensure(sizeof(float) * (size_t)Bp * idx->dim));
-            OI_HIP_CHECK(hipMemsetAsync(qp.p, 0, sizeof(float) * (size_t)Bp * idx->dim, st));
-            OI_HIP_CHECK(hipMemcpyAsync(qp.p, d_qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyDeviceToDevice, st));
-            q = qp.as<float>();
-        }
-        const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
-        if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
-        uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
-        uint64_t r = 0;
-        while (r < n) {
-            if (chunk > max_chunk) chunk = max_chunk;
-            const uint64_t e = std::min(n, r + chunk);
-            OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
-            const bool last = e == n;
-            OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
-                                      last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
-            r = e;
-            chunk *= 8;
+        return OI_OK;
+    };
+    {
+        const int rc = cosine_leg();
+        if (rc != OI_OK) { // nothing of this call stays in flight behind an error return
+            if (overlap) (void)hipStreamSynchronize(ctx->side_stream);
+            return rc;
         }
     }
     if (overlap) OI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
