@@ -50,7 +50,8 @@ def _index(ctx, bits, terms, offs, vocab, base=0):
 
 
 @pytest.mark.parametrize("B,dim,n", [(1, 768, 5000), (9, 384, 3000), (40, 768, 9000), (64, 768, 40_000),
-                                     (70, 384, 6000), (33, 1024, 5000), (64, 1024, 20_000), (3, 1024, 33)])
+                                     (70, 384, 6000), (33, 1024, 5000), (64, 1024, 20_000), (3, 1024, 33),
+                                     (256, 1024, 30_000)])  # the batch and width of BASELINE configs[4]
 def test_bf16_cosine_within_tolerance(ctx, O, B, dim, n):
     from openintel_amd import synth
     bits = to_bf16_bits(synth.embeddings_np(n, dim, seed=5 + B))
