@@ -216,6 +216,163 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_filter(
     }
 }
 
+// ------------------------------------------------------------------ more queries per corpus pass
+// The kernel above reads the corpus once per 64 queries (32 at d = 1024): at B = 256 that is 4-8 passes
+// of an HBM-bound scan.  Here the four waves work as TWO PAIRS; a pair owns whole 32-row tiles and each
+// of its waves holds one HALF of K of up to 128 queries in registers (128 x 384 bf16 = 96 KB), streams
+// its half of the rows through its own ring, and the two partial 32 x 128 tiles meet once per tile:
+// one wave writes its accumulators to LDS, one workgroup barrier, the other adds them to its own and
+// filters.  The roles alternate from tile to tile, which balances the epilogue work and makes the one
+// barrier enough (a wave has finished reading the buffer before it becomes the writer).
+template <int D, int NQT>
+__global__ __launch_bounds__(256, 1) void cosine_bf16_pair(
+    const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const uint16_t *__restrict__ queries, // bf16 [32*NQT][D], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int KH = D / 2;                 // K of one wave
+    constexpr int NKC = KH / CB_SLOT_K;       // ring slots per tile and wave
+    constexpr int NBUF = NKC;
+    constexpr int P = NBUF - 1;
+    constexpr int KSTEPS = KH / 16;
+    constexpr int RED = NQT * 16 * 64;        // floats of one partial tile
+    static_assert(KH % CB_SLOT_K == 0 && P >= 1, "unsupported D");
+    static_assert(NQT * KSTEPS * 4 <= 400, "the query block must fit the register file");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                      // [4][NBUF][4 KiB]
+    float *red = reinterpret_cast<float *>(smem + 4 * NBUF * CB_SLOT_BYTES);         // [2 pairs][RED]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 2 * RED);                // [32*NQT]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t pr = w >> 1, kh = w & 1;
+    const uint32_t li = lane & 31, lh = lane >> 5;
+
+    cb_bf16x8 qreg[NQT][KSTEPS]; // this wave's half of K of every query
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            qreg[t][s] = *reinterpret_cast<const cb_bf16x8 *>(queries + (uint64_t)(32 * t + li) * D + kh * KH + 16 * s + 8 * lh);
+    uint32_t tau[NQT];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32u * t + li;
+        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+    }
+    if (tid < 32 * NQT) seg_fill[tid] = 0;
+    __syncthreads();
+
+    // ---- tiles of this PAIR: (blockIdx.x * 2 + pr), + 2 * gridDim.x, ...  Both pairs run the same number of
+    // loop trips (the barrier is workgroup-wide); a pair past its last tile idles through the trip.
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
+    const uint64_t first = (uint64_t)blockIdx.x * 2 + pr, stride = (uint64_t)gridDim.x * 2;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    const uint64_t first0 = (uint64_t)blockIdx.x * 2;
+    const uint64_t trips = first0 < n_tiles ? (n_tiles - first0 + stride - 1) / stride : 0; // pair 0 has the most
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+    float *my_red = red + pr * RED;
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const uint32_t prow = 8 * m + (lane >> 3);
+        voff[m] = prow * (uint32_t)(D * 2) + kh * (uint32_t)(KH * 2) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+    }
+    const uint32_t ring_w = cb_lds_addr(ring) + w * (NBUF * CB_SLOT_BYTES);
+    const unsigned char *ring_rd = ring + w * (NBUF * CB_SLOT_BYTES);
+    uint32_t frag_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
+
+    auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)CB_TILE_ROWS; };
+    auto tile_srd = [&](uint64_t ti) {
+        const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
+        return cb_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 2));
+    };
+    cb_u32x4 cur = tile_srd(0), nxt = tile_srd(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only: retire every load hipcc knows about, here
+    if (my_nt) {
+#pragma unroll
+        for (int kc = 0; kc < P; ++kc)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                cb_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CB_SLOT_BYTES + m * 1024, false);
+    }
+
+    for (uint64_t ti = 0; ti < trips; ++ti) {
+        const bool active = ti < my_nt;
+        const bool has_next_tile = ti + 1 < my_nt;
+        cb_f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        if (active) {
+            cb_wait<4 * (P - 1)>();
+            cb_bf16x8 a_cur = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + frag_off[0]);
+            cb_static_for<0, NKC * 4>([&](auto gi_) {
+                constexpr int gi = decltype(gi_)::value;
+                constexpr int kc = gi / 4, g = gi % 4;
+                constexpr int sn = kc + P;
+                cb_bf16x8 a_nxt = a_cur;
+                if constexpr (g < 3)
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + (kc % NBUF) * CB_SLOT_BYTES + frag_off[g + 1]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+                if constexpr (sn < NKC)
+                    cb_issue_piece(cur, voff[g], sn * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024, false);
+                else
+                    cb_issue_piece(nxt, voff[g], (sn - NKC) * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024,
+                                   !has_next_tile);
+                if constexpr (g == 3 && kc + 1 < NKC) {
+                    if (kc + P < NKC || has_next_tile) cb_wait<4 * (P - 1)>();
+                    else cb_wait<4 * (NKC - 2 - kc)>();
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + ((kc + 1) % NBUF) * CB_SLOT_BYTES + frag_off[0]);
+                }
+                a_cur = a_nxt;
+            });
+        }
+        // ---- the pair's two halves meet: the writer of this trip parks its partial tile in LDS
+        const bool writer = ((ti + kh) & 1) == 0;
+        if (active && writer) {
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) my_red[(t * 16 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (active && !writer) {
+            const uint64_t row0 = tile_row0(ti);
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                const uint32_t q = 32u * t + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float other = my_red[(t * 16 + r) * 64 + lane];
+                    const float s = kh == 0 ? acc[t][r] + other : other + acc[t][r]; // (K half 0) + (K half 1)
+                    if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+                        const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+                        else *overflow = 1u;
+                    }
+                }
+            }
+        }
+        cur = nxt;
+        nxt = tile_srd(ti + 2);
+    }
+    __syncthreads();
+    if (tid < 32 * NQT && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
 // ------------------------------------------------------------------ query staging: f32 -> bf16 (RNE), zero padded
 __global__ __launch_bounds__(256) void cb_stage_queries(const float *__restrict__ q, uint32_t n_queries, uint32_t n_padded,
                                                         uint32_t dim, uint16_t *__restrict__ out) {
@@ -234,11 +391,22 @@ __global__ __launch_bounds__(256) void cb_stage_queries(const float *__restrict_
 
 // ------------------------------------------------------------------ host
 bool oi_cosine_bf16_supported(uint32_t dim) { return dim == 384 || dim == 768 || dim == 1024; }
-uint32_t oi_cosine_bf16_group(uint32_t dim) { return dim == 1024 ? 32u : 64u; } // queries per pass
+// Queries of the next corpus pass.  One wave can hold 64 queries over the whole K (32 at d = 1024); a pair
+// holds 96 (three query tiles: with four, the 768-d build spills and loses more than the saved pass).  The
+// pair kernel is used when it shortens the plan: always at d = 1024, and at 384 / 768 when passes of 96
+// cover what is left in fewer passes than passes of 64.
+static uint32_t cb_group(uint32_t dim, uint32_t left) {
+    const uint32_t solo = dim == 1024 ? 32u : 64u;
+    if (left <= solo) return solo;
+    if (dim == 1024) return 96u;
+    return (left + 95u) / 96u < (left + 63u) / 64u ? 96u : 64u;
+}
 
+// Pool geometry of one chunk.  Segments are per workgroup; a workgroup's waves take 4 tiles per round
+// (solo kernel) or 2 (pair kernel) -- the cap below covers both.
 void oi_cosine_bf16_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
     const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
-    const uint64_t quads = (n_tiles + 3) / 4; // a workgroup's four waves take four tiles at a time
+    const uint64_t quads = (n_tiles + 3) / 4;
     const uint64_t grid = quads < (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (uint64_t)ctx->num_cus;
     *n_segs = (uint32_t)grid;
     *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * CB_TILE_ROWS;
@@ -262,6 +430,25 @@ static int launch_bf16(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, ui
     return OI_OK;
 }
 
+template <int D, int NQT>
+static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                            uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    constexpr int NKC = D / 2 / CB_SLOT_K;
+    constexpr size_t smem = 4 * NKC * CB_SLOT_BYTES + 2 * (NQT * 16 * 64) * 4 + 128 * 4;
+    static_assert(smem <= 160 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_bf16_pair<D, NQT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((cosine_bf16_pair<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
+                       row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
+                       p.carry_cap, p.seg_cap, p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 // All queries of a batch over rows [row_begin, row_end) of a bf16 corpus.  d_queries: f32 [n_queries][dim].
 int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                 const float *d_queries, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool) {
@@ -270,10 +457,10 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
     OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
                "cosine (bf16 corpus): chunk does not fit the candidate pool");
     if (row_end <= row_begin || n_queries == 0) return OI_OK;
-    const uint32_t group = oi_cosine_bf16_group(dim);
+    static const bool solo_only = getenv("OI_BF16_SOLO") != nullptr; // A/B: never use the pair kernel
     const uint32_t n_padded = (n_queries + 31u) & ~31u;
     DevBuf &qb = ctx->buf("q_bf16");
-    OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 32) * dim));
+    OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 128) * dim));
     {
         const uint64_t total = (uint64_t)n_padded * dim;
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((total + 255) / 256, 1024);
@@ -282,22 +469,36 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
         OI_HIP_CHECK(hipGetLastError());
     }
     ProfScope ps(ctx, "cosine");
-    for (uint32_t q0 = 0; q0 < n_queries; q0 += group) {
-        const uint32_t nq_here = std::min(group, n_queries - q0);
-        const bool two = group == 64 && nq_here > 32;
+    for (uint32_t q0 = 0; q0 < n_queries;) {
+        const uint32_t left = n_queries - q0;
+        const uint32_t group = solo_only ? (dim == 1024 ? 32u : 64u) : cb_group(dim, left);
+        const uint32_t nq_here = std::min(group, left);
+        const uint32_t nqt = (nq_here + 31u) / 32u; // query tiles of 32 in this launch
         PoolView p = pool;
         p.keys += (uint64_t)q0 * pool.stride;
         p.carry_cnt += q0;
         p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
         p.tau_keys += q0;
         const uint16_t *qptr = qb.as<uint16_t>() + (uint64_t)q0 * dim;
-        switch (dim) {
-            case 384: OI_CHECK(two ? (launch_bf16<384, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))
-                                   : (launch_bf16<384, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
-            case 768: OI_CHECK(two ? (launch_bf16<768, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))
-                                   : (launch_bf16<768, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
-            default: OI_CHECK((launch_bf16<1024, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p))); break;
+#define CB_SOLO(DD, T) OI_CHECK((launch_bf16<DD, T>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)))
+#define CB_PAIR(DD, T) OI_CHECK((launch_bf16_pair<DD, T>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)))
+        const bool pair = nq_here > (dim == 1024 ? 32u : 64u);
+        if (dim == 1024) {
+            if (!pair) CB_SOLO(1024, 1);
+            else if (nqt == 2) CB_PAIR(1024, 2);
+            else CB_PAIR(1024, 3);
+        } else if (dim == 768) {
+            if (pair) CB_PAIR(768, 3);
+            else if (nqt == 1) CB_SOLO(768, 1);
+            else CB_SOLO(768, 2);
+        } else {
+            if (pair) CB_PAIR(384, 3);
+            else if (nqt == 1) CB_SOLO(384, 1);
+            else CB_SOLO(384, 2);
         }
+#undef CB_SOLO
+#undef CB_PAIR
+        q0 += nq_here;
     }
     return OI_OK;
 }

@@ -51,7 +51,8 @@ def _index(ctx, bits, terms, offs, vocab, base=0):
 
 @pytest.mark.parametrize("B,dim,n", [(1, 768, 5000), (9, 384, 3000), (40, 768, 9000), (64, 768, 40_000),
                                      (70, 384, 6000), (33, 1024, 5000), (64, 1024, 20_000), (3, 1024, 33),
-                                     (256, 1024, 30_000)])  # the batch and width of BASELINE configs[4]
+                                     (256, 1024, 30_000),   # the batch and width of BASELINE configs[4]
+                                     (128, 768, 20_000), (100, 384, 5000), (200, 768, 3000)])  # pair kernel shapes
 def test_bf16_cosine_within_tolerance(ctx, O, B, dim, n):
     from openintel_amd import synth
     bits = to_bf16_bits(synth.embeddings_np(n, dim, seed=5 + B))
