@@ -464,6 +464,13 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
     return OI_OK;
 }
 
+// Rows of the first corpus chunk (scored with no threshold yet: every row lands in the pool, so it is kept
+// small); each later chunk is 8x the one before.  OI_FIRST_CHUNK_MULT scales it (A/B runs).
+static uint64_t oi_first_chunk_rows(uint32_t depth) {
+    static const uint64_t mult = getenv("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(getenv("OI_FIRST_CHUNK_MULT"))) : 1;
+    return std::max<uint64_t>(8192, 32ull * depth) * mult;
+}
+
 // Device-side ranked lists for a batch; all pointers device.
 int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, const uint32_t *d_qo, uint32_t B,
                         uint32_t depth, float *cos_s, uint32_t *cos_d, uint32_t *cos_c, float *bm_s,
@@ -579,7 +586,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             const uint64_t room = cos_stride - carry_cap;
             const uint64_t max_chunk = room > bslack ? room - bslack : 0;
             if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
-            uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+            uint64_t chunk = oi_first_chunk_rows(depth);
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > max_chunk) chunk = max_chunk;
@@ -604,7 +611,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             }
             const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
             if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
-            uint64_t chunk = std::max<uint64_t>(8192, 32ull * depth);
+            uint64_t chunk = oi_first_chunk_rows(depth);
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > max_chunk) chunk = max_chunk;

@@ -42,14 +42,16 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
     uint32_t tau = 0;
     if (lane < NQ) tau = tau_keys[lane];
 
-    for (uint64_t r = row_begin + wave; r < row_end; r += n_waves) {
-        const float4 *row = reinterpret_cast<const float4 *>(rows + r * dim);
-        float4 x[4];
+    // Two rows per trip, every load unpredicated (a lane past the row's end re-reads the row's last float4
+    // and multiplies it by the zeros its query registers hold there): all of a trip's loads are in flight
+    // together instead of each waiting at the end of its own branch.
+    uint32_t vidx[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t v = lane + 64u * c;
-            x[c] = v < nvec ? row[v] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t v = lane + 64u * c;
+        vidx[c] = v < nvec ? v : nvec - 1u;
+    }
+    auto score_row = [&](const float4 (&x)[4], uint64_t r) {
         float mine = 0.f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -67,6 +69,30 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
         if (lane < NQ && mine == mine && oi_f32_key(mine) >= tau)
             oi_pool_append(pools + (uint64_t)lane * pool_stride, pool_counts + (uint64_t)lane * cnt_stride, pool_cap,
                            overflow, oi_rank_key(mine, doc_id_base + (uint32_t)r));
+    };
+    const uint32_t ncol = (nvec + 63u) >> 6; // float4 columns a lane really needs (3 at dim 768)
+    uint64_t r = row_begin + wave;
+    for (; r + n_waves < row_end; r += 2 * n_waves) {
+        const float4 *row0 = reinterpret_cast<const float4 *>(rows + r * dim);
+        const float4 *row1 = reinterpret_cast<const float4 *>(rows + (r + n_waves) * dim);
+        float4 x0[4], x1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            x0[c] = x1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)c < ncol) { x0[c] = row0[vidx[c]]; x1[c] = row1[vidx[c]]; } // (uniform condition)
+        }
+        score_row(x0, r);
+        score_row(x1, r + n_waves);
+    }
+    if (r < row_end) {
+        const float4 *row0 = reinterpret_cast<const float4 *>(rows + r * dim);
+        float4 x0[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            x0[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((uint32_t)c < ncol) x0[c] = row0[vidx[c]];
+        }
+        score_row(x0, r);
     }
 }
 
