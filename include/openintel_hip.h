@@ -77,6 +77,19 @@ void oi_destroy(oi_ctx *ctx);
 int oi_set_stream(oi_ctx *ctx, void *hip_stream);
 int oi_synchronize(oi_ctx *ctx);
 
+/* How the batch cosine scorer multiplies over an f32 corpus (dim 384 / 768, more than 8 queries; other
+ * shapes always use the exact kernel):
+ *   OI_COSINE_EXACT (default)  v_mfma_f32_* on the f32 values: matrix-pipe-bound.
+ *   OI_COSINE_SPLIT            every f32 operand is split exactly into three bf16 values and the dot product
+ *                              taken as six bf16 MFMAs with f32 accumulation (the three smallest of the nine
+ *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
+ *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7) at
+ *                              3/8 of the matrix-pipe time, so the scorer becomes HBM-bound.
+ * The corpus stays f32 in HBM either way.  Also selectable with OI_COSINE_MODE=split at oi_create. */
+#define OI_COSINE_EXACT 0
+#define OI_COSINE_SPLIT 1
+int oi_set_cosine_mode(oi_ctx *ctx, int mode);
+
 /* A hybrid query has two independent legs until fusion.  By default the BM25 leg is issued on an
  * internal side stream (forked from and joined back into the ctx stream inside the call) so that it
  * runs beside the MFMA-bound cosine leg; enable = 0 runs them one after the other. */

@@ -16,6 +16,7 @@ OI_MAX_DEPTH = 1024
 OI_MAX_DIM = 1024
 OI_BM25_BLOCK_DOCS = 32768
 OI_N_CATALYST_KEYWORDS = 16
+OI_COSINE_EXACT, OI_COSINE_SPLIT = 0, 1
 
 OI_ERR_INVALID_ARG = -1
 OI_ERR_HIP = -2
@@ -59,6 +60,7 @@ SIGNATURES = {
     "oi_lexicon_analyze": (_I, [_P, _P, _P, _U64, _P, _P]),
     "oi_lexicon_analyze_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P]),
     "oi_set_overlap": (_I, [_P, _I]),
+    "oi_set_cosine_mode": (_I, [_P, _I]),
     "oi_catalyst_keyword": (C.c_char_p, [_U32]),
     "oi_headline_scan": (_I, [_P, _P, _P, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
     "oi_headline_scan_device": (_I, [_P, _P, _P, _U64, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),

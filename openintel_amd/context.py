@@ -31,6 +31,10 @@ class HipContext:
     def synchronize(self) -> None:
         _lib.check(self.lib.oi_synchronize(self.handle))
 
+    def set_cosine_mode(self, mode: int) -> None:
+        """_lib.OI_COSINE_EXACT (default) or _lib.OI_COSINE_SPLIT (six bf16 MFMAs per f32 product, HBM-bound)."""
+        _lib.check(self.lib.oi_set_cosine_mode(self.handle, int(mode)))
+
     def set_overlap(self, enable: bool) -> None:
         """BM25 leg of a hybrid query beside the cosine leg on a side stream (default) or after it."""
         _lib.check(self.lib.oi_set_overlap(self.handle, 1 if enable else 0))

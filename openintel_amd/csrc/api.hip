@@ -108,6 +108,7 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->device = device_ordinal;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->stream = nullptr;
+    if (const char *m = getenv("OI_COSINE_MODE")) c->cosine_mode = strcmp(m, "split") == 0 ? 1 : 0;
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
@@ -133,6 +134,14 @@ extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return OI_OK;
+}
+
+extern "C" int oi_set_cosine_mode(oi_ctx *ctx, int mode) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT, "oi_set_cosine_mode: unknown mode %d", mode);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->cosine_mode = mode;
     return OI_OK;
 }
 

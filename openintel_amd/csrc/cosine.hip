@@ -255,7 +255,9 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
         p.tau_keys += q0;
         const float *qptr = d_queries + (uint64_t)q0 * dim;
-        if (ksplit) {
+        if (ksplit && ctx->cosine_mode == 1 && oi_cosine_split_supported(dim)) {
+            OI_CHECK(oi_launch_cosine_split(ctx, rows, row_begin, row_end, dim, qptr, nq_here, doc_id_base, p));
+        } else if (ksplit) {
             OI_CHECK(oi_launch_cosine_ksplit(ctx, rows, row_begin, row_end, dim, qptr, nq_here, left >= 64,
                                              doc_id_base, p));
         } else if (left >= 64)

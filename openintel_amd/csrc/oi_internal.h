@@ -67,6 +67,7 @@ struct oi_ctx {
     hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_legs = true;              // oi_set_overlap
+    int cosine_mode = 0;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     bool prof_enabled = false;
@@ -171,6 +172,10 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
 uint64_t oi_cosine_max_chunk_rows(const oi_ctx *ctx, uint32_t dim, uint32_t n_queries, uint64_t stride,
                                   uint32_t carry_cap);
 int oi_launch_l2_normalize(oi_ctx *ctx, float *rows, uint64_t n, uint32_t dim);
+// cosine_split.hip
+bool oi_cosine_split_supported(uint32_t dim);
+int oi_launch_cosine_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                           const float *d_queries, uint32_t nq, uint32_t doc_id_base, const PoolView &p);
 // cosine_bf16.hip
 bool oi_cosine_bf16_supported(uint32_t dim);
 int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
