@@ -99,7 +99,7 @@ __device__ __forceinline__ void cs_split8(const cs_f32x4 &a, const cs_f32x4 &b, 
     h = ph.v; m = pm.v; l = pl.v;
 }
 
-template <int D, int NQT>
+template <int D, int NQT, int DBG = 0> // DBG (diagnostic builds, wrong results): 1 no DMA, 2 no MFMA, 4 no split arithmetic
 __global__ __launch_bounds__(256, 1) void cosine_split_filter(
     const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
     const uint16_t *__restrict__ qsplit, // bf16 [3 planes: H, M, L][32*NQT][D], zero padded
@@ -166,92 +166,155 @@ __global__ __launch_bounds__(256, 1) void cosine_split_filter(
         for (int c = 0; c < 2; ++c) frag_off[g][c] = li * 128 + (((4 * g + 2 * lh + c) ^ ((li >> 1) & 7)) << 4);
 
     auto tile_row0 = [&](uint64_t ti) { return row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)CS_TILE_ROWS; };
+    // Past the workgroup's last tile the descriptor is empty: its loads return zeros, so the tile loop needs no
+    // branch around the prefetch (and no second set of wait counts) -- a branch-free body is also what lets the
+    // scheduler interleave the split arithmetic with the MFMAs.
     auto tile_srd = [&](uint64_t ti) {
-        const uint64_t r0 = tile_row0(ti);
-        return cs_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 4));
+        const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
+        return cs_make_srd(rows + r0 * D, ti < my_nt ? (row_end - r0) * (uint64_t)(D * 4) : 0ull);
     };
-    cs_u32x4 cur = tile_srd(0), nxt = tile_srd(my_nt > 1 ? 1 : 0);
+    cs_u32x4 cur = tile_srd(0), nxt = tile_srd(1);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only: retire every load hipcc knows about, here
 #pragma unroll
     for (int kc = 0; kc < P; ++kc)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
-            cs_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CS_SLOT_BYTES + m * 1024, false);
+            cs_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CS_SLOT_BYTES + m * 1024, (DBG & 1) != 0);
     float *my_red = red + w * RED;
 
+    // ---- deferred epilogue (as in cosine_ksplit.hip).  A tile's partial sums go to LDS right after its last
+    // MFMA; the cross-wave sum + filter of tile t then rides INSIDE tile t+1's MFMA stream (barrier A before
+    // k-step EPI_G0, one output per thread per k-step, barrier B behind the last one), so the DMA ring keeps
+    // being refilled while the epilogue's LDS round trips and stores go out.
+    uint64_t prev_row0 = 0; // first corpus row of the tile whose partials sit in `red`
+    bool have_prev = false;  // false during the first tile: `red` holds nothing yet
+    auto epi_out = [&](int i) {
+        const uint32_t e = tid + 256u * i; // (t = i>>2, r = (e>>6)&15, lane)
+        const float s = (red[e] + red[RED + e]) + (red[2 * RED + e] + red[3 * RED + e]);
+        const uint32_t t = i >> 2, r = (e >> 6) & 15u;
+        const uint32_t q = 32u * t + li;
+        const uint64_t row = prev_row0 + (r & 3u) + 8u * (r >> 2) + 4u * lh;
+        if (have_prev && row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+            const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+            if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+            else *overflow = 1u;
+        }
+    };
+    constexpr int NG = NKC * 2;                              // k-steps per tile
+    constexpr int EPI_G0 = 1;                                // first k-step with outputs
+    constexpr int EPI_PER = (NQT * 4 + (NG - 2) - 1) / (NG - 2); // outputs per thread and k-step (2 at d = 384)
+    constexpr int EPI_STEPS = (NQT * 4 + EPI_PER - 1) / EPI_PER;
+    constexpr int EPI_GB = EPI_G0 + EPI_STEPS;               // k-step of barrier B
+    static_assert(EPI_GB <= NG - 1, "tile too short to host the deferred epilogue");
+
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
-        const bool has_next_tile = ti + 1 < my_nt;
-        cs_f32x16 acc[NQT], cor[NQT]; // hH apart from the five small terms
+        have_prev = ti > 0;
+        // hH accumulates apart from the five small terms; with one query tile the small terms use two
+        // accumulators so that no MFMA waits for the one issued right before it
+        cs_f32x16 acc[NQT], cor[NQT], cor2[NQT == 1 ? 1 : 1];
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; cor[t][r] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cor2[0][r] = 0.f;
 
         cs_wait<4 * (P - 1)>();
-        cs_f32x4 a0 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + frag_off[0][0]);
-        cs_f32x4 a1 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + frag_off[0][1]);
-        cs_static_for<0, NKC * 2>([&](auto gi_) {
+        cs_bf16x8 ah, am, al; // A operands of the current k-step
+        {
+            const cs_f32x4 f0 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + frag_off[0][0]);
+            const cs_f32x4 f1 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + frag_off[0][1]);
+            if constexpr ((DBG & 4) != 0) { CsPack pk; pk.u[0] = __float_as_uint(f0[0]); pk.u[1] = __float_as_uint(f0[1]); pk.u[2] = __float_as_uint(f1[0]); pk.u[3] = __float_as_uint(f1[1]); ah = am = al = pk.v; }
+            else cs_split8(f0, f1, ah, am, al);
+        }
+        cs_static_for<0, NG>([&](auto gi_) {
             constexpr int gi = decltype(gi_)::value; // k-step of the tile
             constexpr int kc = gi / 2, g = gi % 2;
-            constexpr int sn = kc + P;               // slot refilled during this slot's groups
-            cs_bf16x8 ah, am, al;
-            cs_split8(a0, a1, ah, am, al);
-            cs_f32x4 n0 = a0, n1 = a1;
-            if constexpr (g == 0) { // the slot's second half is already there
-                n0 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + (kc % NBUF) * CS_SLOT_BYTES + frag_off[1][0]);
-                n1 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + (kc % NBUF) * CS_SLOT_BYTES + frag_off[1][1]);
+            constexpr int sn = kc + P;               // slot refilled during this slot's k-steps
+            // The NEXT k-step's floats are read now and split into its three operands WHILE this k-step's MFMAs
+            // run: one wave per SIMD issues in order, so the split has to sit between the MFMAs in program order
+            // (sched_group_barrier below) to execute in their shadow.
+            cs_bf16x8 nh = ah, nm = am, nl = al;
+            if constexpr (gi + 1 < NG) {
+                constexpr int nslot = g == 0 ? kc : kc + 1, nhalf = g == 0 ? 1 : 0;
+                const cs_f32x4 f0 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + (nslot % NBUF) * CS_SLOT_BYTES + frag_off[nhalf][0]);
+                const cs_f32x4 f1 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + (nslot % NBUF) * CS_SLOT_BYTES + frag_off[nhalf][1]);
+                if constexpr ((DBG & 4) != 0) { CsPack pk; pk.u[0] = __float_as_uint(f0[0]); pk.u[1] = __float_as_uint(f0[1]); pk.u[2] = __float_as_uint(f1[0]); pk.u[3] = __float_as_uint(f1[1]); nh = nm = nl = pk.v; }
+                else cs_split8(f0, f1, nh, nm, nl);
             }
+            // twelve (six) MFMAs, ordered so that consecutive ones never share an accumulator; the small terms
+            // are added smallest first
+            if constexpr ((DBG & 2) != 0) {
+                asm volatile("" ::"v"(ah), "v"(am), "v"(al));
+            } else if constexpr (NQT == 2) {
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][gi], cor[0], 0, 0, 0);
+                cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[1][gi], cor[1], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[0][gi], cor[0], 0, 0, 0);
+                cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[1][gi], cor[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[0][gi], acc[0], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[0][gi], cor[0], 0, 0, 0);
+                cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[1][gi], cor[1], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[1][gi], acc[1], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[0][gi], cor[0], 0, 0, 0);
+                cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[1][gi], cor[1], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[0][gi], cor[0], 0, 0, 0);
+                cor[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[1][gi], cor[1], 0, 0, 0);
+            } else {
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[0][gi], cor[0], 0, 0, 0);
+                cor2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[0][gi], cor2[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[0][gi], acc[0], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[0][gi], cor[0], 0, 0, 0);
+                cor2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[0][gi], cor2[0], 0, 0, 0);
+                cor[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[0][gi], cor[0], 0, 0, 0);
+            }
+            if constexpr ((DBG & 6) == 0) {
+                // issue order of this k-step: the two LDS reads of the next fragment first, two MFMAs to cover
+                // their latency, then a handful of the split's VALU instructions after every further MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #pragma unroll
-            for (int t = 0; t < NQT; ++t) {
-                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qh[t][gi], cor[t], 0, 0, 0);
-                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ql[t][gi], cor[t], 0, 0, 0);
-                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qm[t][gi], cor[t], 0, 0, 0);
-                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, qh[t][gi], cor[t], 0, 0, 0);
-                cor[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qm[t][gi], cor[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qh[t][gi], acc[t], 0, 0, 0);
+                for (int i = 2; i < NQT * 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, NQT == 2 ? 6 : 15, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
             }
             // two DMA pieces per k-step: slot kc + P goes into the buffer slot kc - 1 has vacated
 #pragma unroll
             for (int m = 2 * g; m < 2 * g + 2; ++m) {
                 if constexpr (sn < NKC)
-                    cs_issue_piece(cur, voff[m], sn * 128, ring_w + (sn % NBUF) * CS_SLOT_BYTES + m * 1024, false);
+                    cs_issue_piece(cur, voff[m], sn * 128, ring_w + (sn % NBUF) * CS_SLOT_BYTES + m * 1024, (DBG & 1) != 0);
                 else
                     cs_issue_piece(nxt, voff[m], (sn - NKC) * 128, ring_w + (sn % NBUF) * CS_SLOT_BYTES + m * 1024,
-                                   !has_next_tile);
+                                   (DBG & 1) != 0);
             }
-            if constexpr (g == 1 && kc + 1 < NKC) {
-                if (kc + P < NKC || has_next_tile) cs_wait<4 * (P - 1)>();
-                else cs_wait<4 * (NKC - 2 - kc)>();
-                n0 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + ((kc + 1) % NBUF) * CS_SLOT_BYTES + frag_off[0][0]);
-                n1 = *reinterpret_cast<const cs_f32x4 *>(ring_rd + ((kc + 1) % NBUF) * CS_SLOT_BYTES + frag_off[0][1]);
+            if constexpr (gi == EPI_G0 - 1 && !(DBG & 8)) cs_barrier();                        // (A) partials visible
+            if constexpr (gi >= EPI_G0 && gi < EPI_GB && !(DBG & 8)) {
+#pragma unroll
+                for (int o = 0; o < EPI_PER; ++o)
+                    if ((gi - EPI_G0) * EPI_PER + o < NQT * 4) epi_out((gi - EPI_G0) * EPI_PER + o);
             }
-            a0 = n0; a1 = n1;
+            if constexpr (gi == EPI_GB && !(DBG & 8)) cs_barrier();                            // (B) `red` is free again
+            // the next k-step reads slot kc + 1 when this one is the slot's first half: it has to have landed
+            // (the two pieces of slot kc + P issued just above may still be in flight with P - 2 younger slots)
+            if constexpr (g == 0 && kc + 1 < NKC) cs_wait<4 * (P - 2) + 2>();
+            ah = nh; am = nm; al = nl;
         });
 
-        // ---- the four K-slices meet: partials to LDS, one sum per output in a fixed order, filter, append
+        // this tile's partial sums -> LDS (summed across the waves during the next tile, or below)
 #pragma unroll
         for (int t = 0; t < NQT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) my_red[(t * 16 + r) * 64 + lane] = acc[t][r] + cor[t][r];
-        cs_barrier();
-        const uint64_t row0 = tile_row0(ti);
-#pragma unroll
-        for (int i = 0; i < NQT * 4; ++i) {
-            const uint32_t e = tid + 256u * i; // (t = i>>2, r = (e>>6)&15, lane)
-            const float s = (red[e] + red[RED + e]) + (red[2 * RED + e] + red[3 * RED + e]);
-            const uint32_t t = i >> 2, r = (e >> 6) & 15u;
-            const uint32_t q = 32u * t + li;
-            const uint64_t row = row0 + (r & 3u) + 8u * (r >> 2) + 4u * lh;
-            if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
-                const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
-                if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
-                else *overflow = 1u;
-            }
-        }
-        cs_barrier(); // `red` is free again
+            for (int r = 0; r < 16; ++r)
+                my_red[(t * 16 + r) * 64 + lane] = acc[t][r] + (NQT == 1 ? cor[t][r] + cor2[0][r] : cor[t][r]);
+        prev_row0 = tile_row0(ti);
         cur = nxt;
-        if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
+        nxt = tile_srd(ti + 2);
     }
+    have_prev = true;
+    cs_barrier(); // the last tile's epilogue has no MFMA stream to hide in
+#pragma unroll
+    for (int i = 0; i < NQT * 4; ++i) epi_out(i);
+    cs_barrier();
     if (tid < 32 * NQT && tid < n_queries) {
         const uint32_t c = seg_fill[tid];
         seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
@@ -284,18 +347,18 @@ __global__ __launch_bounds__(256) void cs_stage_queries(const float *__restrict_
 // ------------------------------------------------------------------ host
 bool oi_cosine_split_supported(uint32_t dim) { return dim == 384 || dim == 768; }
 
-template <int D, int NQT>
+template <int D, int NQT, int DBG = 0>
 static int launch_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int KS = D / 4, NKC = KS / 32, NBUF = NKC <= 6 ? NKC : NKC / 2;
     constexpr size_t smem = 4 * NBUF * CS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
     static bool attr = false;
     if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_split_filter<D, NQT>),
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_split_filter<D, NQT, DBG>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
-    hipLaunchKernelGGL((cosine_split_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
+    hipLaunchKernelGGL((cosine_split_filter<D, NQT, DBG>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
                        p.carry_cap, p.seg_cap, p.overflow);
     OI_HIP_CHECK(hipGetLastError());
@@ -317,6 +380,19 @@ int oi_launch_cosine_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         OI_HIP_CHECK(hipGetLastError());
     }
     const uint16_t *q = qb.as<uint16_t>();
+    static const int dbg = getenv("OI_CS_DEBUG") ? atoi(getenv("OI_CS_DEBUG")) : 0; // ablation builds (timings only)
+    if (dim == 768 && nq > 32 && dbg) {
+        switch (dbg) {
+            case 1: return launch_split<768, 2, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 2: return launch_split<768, 2, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 4: return launch_split<768, 2, 4>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 6: return launch_split<768, 2, 6>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 8: return launch_split<768, 2, 8>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 9: return launch_split<768, 2, 9>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            case 15: return launch_split<768, 2, 15>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+            default: break;
+        }
+    }
     if (dim == 768) return nq > 32 ? launch_split<768, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
                                    : launch_split<768, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
     return nq > 32 ? launch_split<384, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
