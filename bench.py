@@ -250,7 +250,7 @@ def main():
             "other_kernels_ms_per_step": {t: v[0] / max(1, args.steps) for t, v in other.items()},
             "build_s": t_build,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)
         print(json.dumps(line), flush=True)
