@@ -383,11 +383,13 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
             const uint32_t row = 16 * rt + li;
             frag_off[rt][g] = row * 128 + (((4 * g + kk) ^ ((row >> 1) & 7)) << 4);
         }
+    // Past the workgroup's last tile the descriptor is EMPTY (its loads return zeros): the tile loop then needs no
+    // branch around the prefetch and a single set of wait counts -- a branch-free tile body.
     auto tile_srd = [&](uint64_t ti) {
-        const uint64_t r0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
-        return ks_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 4));
+        const uint64_t r0 = row_begin + (blockIdx.x + (ti < my_nt ? ti : 0) * gridDim.x) * (uint64_t)KS_TILE_ROWS;
+        return ks_make_srd(rows + r0 * D, ti < my_nt ? (row_end - r0) * (uint64_t)(D * 4) : 0ull);
     };
-    u32x4 cur = tile_srd(0), nxt = tile_srd(my_nt > 1 ? 1 : 0);
+    u32x4 cur = tile_srd(0), nxt = tile_srd(1);
     __builtin_amdgcn_s_waitcnt(0x0F70); // retire every load hipcc knows about before the DMA ring starts
 #pragma unroll
     for (int kc = 0; kc < P; ++kc)
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
 
     float *my_red = red + w * RED_FLOATS;
     uint64_t prev_row0 = 0;
+    bool have_prev = false; // false during the first tile: `red` holds nothing yet
     // element e = tid + 256 i of a partial tile is ((rt*NQ16 + t)*4 + reg)*64 + lane with
     // reg = tid>>6, t = i % NQ16, rt = i / NQ16
     auto epi_out = [&](int i) {
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
         const uint32_t t = (uint32_t)i % NQ16, rt = (uint32_t)i / NQ16;
         const uint32_t q = 16u * t + li;
         const uint64_t row = prev_row0 + 16u * rt + 4u * kk + w;
-        if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+        if (have_prev && row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
             const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
             if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
             else *overflow = 1u;
@@ -416,8 +419,7 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
     static_assert(NG >= 6, "tile too short to host the deferred epilogue");
 
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
-        const bool has_next_tile = ti + 1 < my_nt;
-        const bool have_prev = ti > 0;
+        have_prev = ti > 0;
         f32x4v acc[2][NQ16];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -450,21 +452,18 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
                         ks_issue_piece(cur, voff[m], sn * KS_CHUNK_K * 4, ring_w + (sn % NBUF) * KS_SLOT_BYTES + m * 1024, false);
                     else
                         ks_issue_piece(nxt, voff[m], (sn - NKC) * KS_CHUNK_K * 4,
-                                       ring_w + (sn % NBUF) * KS_SLOT_BYTES + m * 1024, !has_next_tile);
+                                       ring_w + (sn % NBUF) * KS_SLOT_BYTES + m * 1024, false);
                 }
             }
-            if constexpr (gi == 1) { if (have_prev) ks_barrier(); }                       // (A) partials visible
+            if constexpr (gi == 1) ks_barrier();                                          // (A) partials visible
             if constexpr (gi >= 2 && gi < NG - 1) {
-                if (have_prev) {
 #pragma unroll
-                    for (int o = 0; o < OPG; ++o)
-                        if ((gi - 2) * OPG + o < N_OUT) epi_out((gi - 2) * OPG + o);
-                }
+                for (int o = 0; o < OPG; ++o)
+                    if ((gi - 2) * OPG + o < N_OUT) epi_out((gi - 2) * OPG + o);
             }
-            if constexpr (gi == NG - 1) { if (have_prev) ks_barrier(); }                  // (B) `red` is free again
+            if constexpr (gi == NG - 1) ks_barrier();                                     // (B) `red` is free again
             if constexpr (g == 1 && kc + 1 < NKC) {
-                if (kc + P < NKC || has_next_tile) ks_wait<4 * (P - 1)>();
-                else ks_wait<4 * (NKC - 2 - kc)>();
+                ks_wait<4 * (P - 1)>();
                 n0 = *reinterpret_cast<const f32x4 *>(ring_rd + ((kc + 1) % NBUF) * KS_SLOT_BYTES + frag_off[0][0]);
                 n1 = *reinterpret_cast<const f32x4 *>(ring_rd + ((kc + 1) % NBUF) * KS_SLOT_BYTES + frag_off[1][0]);
             }
@@ -479,8 +478,9 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
                 for (int r = 0; r < 4; ++r) my_red[((rt * NQ16 + t) * 4 + r) * 64 + lane] = acc[rt][t][r];
         prev_row0 = row_begin + (blockIdx.x + ti * gridDim.x) * (uint64_t)KS_TILE_ROWS;
         cur = nxt;
-        if (ti + 2 < my_nt) nxt = tile_srd(ti + 2);
+        nxt = tile_srd(ti + 2);
     }
+    have_prev = my_nt > 0;
     ks_barrier();
 #pragma unroll
     for (int i = 0; i < N_OUT; ++i) epi_out(i);
