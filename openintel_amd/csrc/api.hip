@@ -453,7 +453,7 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
         OI_CHECK(flag.ensure(16));
         OI_HIP_CHECK(hipMemsetAsync(flag.p, 0, 16, ctx->stream));
     }
-    const uint32_t cos_segs = (uint32_t)ctx->num_cus;
+    const uint32_t cos_segs = (uint32_t)ctx->num_cus * (B <= 8 ? 8u : 1u); // one per workgroup: GEMV grids are 8 per CU
     const uint32_t bm_segs = bm_blocks ? bm_blocks : 1;
     const size_t words = (size_t)B * (2 + cos_segs + 2 + bm_segs);
     DevBuf &st = ctx->buf("pool_state");
@@ -478,6 +478,10 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
 static uint64_t oi_first_chunk_rows(uint32_t depth) {
     static const uint64_t mult = getenv("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(getenv("OI_FIRST_CHUNK_MULT"))) : 1;
     return std::max<uint64_t>(8192, 32ull * depth) * mult;
+}
+static uint64_t oi_chunk_growth() {
+    static const uint64_t g = getenv("OI_CHUNK_GROWTH") ? std::max(2, atoi(getenv("OI_CHUNK_GROWTH"))) : 8;
+    return g;
 }
 
 // Device-side ranked lists for a batch; all pointers device.
@@ -605,7 +609,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
                                           last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
                 r = e;
-                chunk *= 8;
+                chunk *= oi_chunk_growth();
             }
         } else if (cos_s) {
             OI_REQUIRE(idx->rows, "search: embeddings not set");
@@ -630,7 +634,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
                                           last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
                 r = e;
-                chunk *= 8;
+                chunk *= oi_chunk_growth();
             }
         }
         return OI_OK;

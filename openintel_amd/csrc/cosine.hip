@@ -22,9 +22,15 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
                                                            uint64_t row_end, uint32_t dim,
                                                            const float *__restrict__ queries,
                                                            uint32_t doc_id_base, uint64_t *pools,
-                                                           uint32_t *pool_counts, uint32_t cnt_stride,
+                                                           uint32_t *seg_cnt, uint32_t cnt_stride,
                                                            const uint32_t *tau_keys, uint64_t pool_stride,
-                                                           uint32_t pool_cap, uint32_t *overflow) {
+                                                           uint32_t seg_cap, uint32_t *overflow) {
+    // Survivors go to THIS workgroup's segment of the query's pool (LDS fill counter, published once at the
+    // end): no global atomic.  With one global counter per query the first chunk -- scored before any
+    // threshold exists, every row a survivor -- spent 100 us on 8192 serialised returning atomics.
+    __shared__ uint32_t fill[8];
+    if (threadIdx.x < 8) fill[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -66,9 +72,12 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
             a = oi_wave_sum(a);
             if ((int)lane == q) mine = a;
         }
-        if (lane < NQ && mine == mine && oi_f32_key(mine) >= tau)
-            oi_pool_append(pools + (uint64_t)lane * pool_stride, pool_counts + (uint64_t)lane * cnt_stride, pool_cap,
-                           overflow, oi_rank_key(mine, doc_id_base + (uint32_t)r));
+        if (lane < NQ && mine == mine && oi_f32_key(mine) >= tau) {
+            const uint32_t pos = atomicAdd(&fill[lane], 1u); // LDS
+            if (pos < seg_cap)
+                pools[(uint64_t)lane * pool_stride + (uint64_t)blockIdx.x * seg_cap + pos] = oi_rank_key(mine, doc_id_base + (uint32_t)r);
+            else *overflow = 1u;
+        }
     };
     const uint32_t ncol = (nvec + 63u) >> 6; // float4 columns a lane really needs (3 at dim 768)
     uint64_t r = row_begin + wave;
@@ -94,6 +103,26 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
         }
         score_row(x0, r);
     }
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        const uint32_t c = fill[threadIdx.x];
+        seg_cnt[(uint64_t)threadIdx.x * cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
+// Grid and pool geometry of one GEMV chunk: one segment per workgroup; a workgroup's four waves take rows
+// wave, wave + n_waves, ... so each scores at most ceil(n_rows / n_waves) of them.
+static uint64_t gemv_blocks(const oi_ctx *ctx, uint64_t n_rows) {
+    // ~8 waves per SIMD-quad worth of rows in flight; grid capped at 8 blocks per CU
+    uint64_t blocks = (n_rows + 3) / 4;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    return blocks ? blocks : 1;
+}
+void oi_cosine_gemv_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
+    const uint64_t blocks = gemv_blocks(ctx, n_rows), n_waves = blocks * 4;
+    *n_segs = (uint32_t)blocks;
+    *seg_cap = (uint32_t)(4 * ((n_rows + n_waves - 1) / n_waves));
 }
 
 // ------------------------------------------------------------------ MFMA tile kernel (v1)
@@ -205,7 +234,8 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
     static const bool force_v1 = getenv("OI_COSINE_V1") != nullptr; // A/B switch for benchmarking
     const bool ksplit = n_queries > 8 && !force_v1 && oi_cosine_ksplit_supported(dim);
     if (ksplit) oi_cosine_ksplit_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
-    else { // atomic-append kernels use one segment spanning the whole appended region
+    else if (n_queries <= 8) oi_cosine_gemv_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
+    else { // the v1 tile kernel appends with one global counter: one segment spanning the whole appended region
         pool.n_segs = 1;
         pool.seg_cap = (uint32_t)(pool.stride - pool.carry_cap);
     }
@@ -217,11 +247,7 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
     const uint64_t n_rows = row_end - row_begin;
     ProfScope ps(ctx, "cosine");
     if (n_queries <= 8) {
-        // ~8 waves per SIMD-quad worth of rows in flight; grid capped at 8 blocks per CU
-        uint64_t blocks = (n_rows + 3) / 4;
-        const uint64_t cap = (uint64_t)ctx->num_cus * 8;
-        if (blocks > cap) blocks = cap;
-        dim3 g((uint32_t)blocks), b(256);
+        dim3 g((uint32_t)gemv_blocks(ctx, n_rows)), b(256);
 #define OI_GEMV(NQ)                                                                                     \
     hipLaunchKernelGGL(cosine_gemv_filter<NQ>, g, b, 0, ctx->stream, rows, row_begin, row_end, dim,     \
                        d_queries, doc_id_base, pool.keys + pool.carry_cap, pool.seg_cnt,                 \

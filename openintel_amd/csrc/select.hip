@@ -199,11 +199,377 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// select_flat_kernel: the same selection with the pool seen as ONE flat array.
+//
+// The kernel above walks the pool a segment at a time (one wave per segment: a dependent count -> keys
+// load chain per segment, repeated on every radix pass when the pool does not fit its LDS copy); with the
+// 256 short segments a cosine chunk leaves behind, that chain IS the select (40-120 us per launch, on the
+// critical path between two corpus chunks).  Here
+//   * the segment counts are scanned once into LDS offsets; flat index -> (segment, slot) is one binary
+//     search per lane and then a forward walk, because wave w owns the contiguous flat range
+//     [w*kpt*64, (w+1)*kpt*64) and reads it 64 consecutive keys per load (coalesced, all loads in flight);
+//   * the keys then live in REGISTERS (<= 32 per thread: pools up to 32K keys) for everything that follows;
+//     larger pools re-load through the same flat view on every pass;
+//   * pools above 4K keys are cut down first: the threshold that keeps ~2k keys is read off a 1024-key
+//     sample (radix select over one key per thread), one filter pass moves the survivors to LDS, and the
+//     exact selection runs over those.  A sample that keeps fewer than k or more than 4096 keys falls back
+//     to the exact passes over the whole pool: the RESULT never depends on the sample;
+//   * histogram and append atomics are aggregated per wave first (the leading digits of a pool of
+//     near-threshold scores are nearly all equal, i.e. one LDS address).
+#define SEL_MAX_SEGS 4096
+#define SEL_KPT_MAX 32
+#define SEL_CAND 4096
+
+struct SelShared {
+    uint32_t hist[256];
+    uint32_t seg_off[SEL_MAX_SEGS + 1];
+    uint32_t wave_tot[SEL_THREADS / 64];
+    uint32_t cnt, kk, bin_cnt, n_samples;
+    uint64_t prefix;
+    unsigned long long min_key;
+};
+
+struct SelFlat {
+    const uint64_t *pool;
+    const uint32_t *seg_off; // LDS, n_segs + 1 entries, seg_off[n_segs] = keys in segments
+    uint32_t n, c0, carry_cap, seg_cap, n_segs, steps;
+};
+// A lane's position in the flat view: segment sg holds the segment-relative flat indices [lo, hi).
+struct SelCursor {
+    uint32_t sg, lo, hi;
+};
+// flat index i < n  ->  cursor at its segment (binary search; indices inside the carry region map to e = 0)
+__device__ __forceinline__ SelCursor sel_seek(const SelFlat &K, uint32_t i) {
+    const uint32_t e = i < K.c0 ? 0u : i - K.c0;
+    uint32_t lo = 0, hi = K.n_segs; // seg_off[lo] <= e < seg_off[hi]
+    for (uint32_t s = 0; s < K.steps; ++s) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool up = K.seg_off[mid] <= e;
+        lo = up ? mid : lo;
+        hi = up ? hi : mid;
+    }
+    SelCursor c;
+    c.sg = lo; c.lo = K.seg_off[lo]; c.hi = K.seg_off[lo + 1];
+    return c;
+}
+// pool offset of flat index i < n, i >= every index this cursor was used for before (forward walk)
+__device__ __forceinline__ uint64_t sel_at(const SelFlat &K, SelCursor &c, uint32_t i) {
+    if (i < K.c0) return i;
+    const uint32_t e = i - K.c0;
+    while (e >= c.hi) { // e < seg_off[n_segs]: stops at the segment that holds e (skips empty ones)
+        ++c.sg;
+        c.lo = c.hi;
+        c.hi = K.seg_off[c.sg + 1];
+    }
+    return (uint64_t)K.carry_cap + (uint64_t)c.sg * K.seg_cap + (e - c.lo);
+}
+
+// hist[digit] += 1 for the active lanes; the two most common digits of the wave go in as one atomic each
+__device__ __forceinline__ void sel_hist_add(uint32_t *hist, bool active, uint32_t digit) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned long long m = __ballot(active);
+        if (!m) return;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        const uint32_t d0 = (uint32_t)__shfl((int)digit, (int)leader, OI_WAVE);
+        const unsigned long long same = __ballot(active && digit == d0);
+        if (lane == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+        active = active && digit != d0;
+    }
+    if (active) atomicAdd(&hist[digit], 1u);
+}
+
+// wave-aggregated append of the lanes' keys to dst; *count counts every taken key, stored or not
+__device__ __forceinline__ void sel_append(uint64_t *dst, uint32_t *count, uint32_t cap, bool take, uint64_t key) {
+    const unsigned long long m = __ballot(take);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63, leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, OI_WAVE);
+    const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (take && pos < cap) dst[pos] = key;
+}
+
+// Radix select over the keys `for_each` enumerates (f(valid, key), same keys on every call): finds
+// (shift, prefix) such that exactly kk of them have (key >> shift) >= prefix.  Needs kk <= their number,
+// distinct keys; all threads call.
+template <class FE>
+__device__ __forceinline__ void sel_threshold(FE &&for_each, uint32_t kk_in, SelShared &sh, int &shift_out, uint64_t &prefix_out) {
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { sh.prefix = 0; sh.kk = kk_in; }
+    int shift = 56;
+    for (;; shift -= 8) {
+        if (tid < 256) sh.hist[tid] = 0;
+        __syncthreads();
+        const uint64_t prefix = sh.prefix;
+        const bool top = shift == 56;
+        for_each([&](bool valid, uint64_t kv) {
+            sel_hist_add(sh.hist, valid && (top || (kv >> ((shift + 8) & 63)) == prefix), (uint32_t)(kv >> shift) & 255u);
+        });
+        __syncthreads();
+        if (tid < 64) { // wave 0: the digit holding the kk-th key counted from the top
+            const uint32_t kk = sh.kk;
+            uint32_t mine = 0;
+            for (int i = 0; i < 4; ++i) mine += sh.hist[255 - (tid * 4 + i)];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o, OI_WAVE);
+                if ((int)tid >= o) incl += v;
+            }
+            const unsigned long long ball = __ballot(incl >= kk);
+            const uint32_t owner = ball ? (uint32_t)__builtin_ctzll(ball) : 63u;
+            if (tid == owner) {
+                uint32_t cum = incl - mine;
+                int d = 255 - (int)(tid * 4);
+                for (int i = 0; i < 3; ++i, --d) {
+                    const uint32_t c = sh.hist[d];
+                    if (cum + c >= kk) break;
+                    cum += c;
+                }
+                sh.prefix = (prefix << 8) | (uint64_t)d;
+                sh.kk = kk - cum;
+                sh.bin_cnt = sh.hist[d];
+            }
+        }
+        __syncthreads();
+        if (sh.bin_cnt == 1 || shift == 0) break;
+    }
+    shift_out = shift;
+    prefix_out = sh.prefix;
+    __syncthreads(); // sh.prefix / sh.kk may be rewritten by the next call
+}
+
+// Selects the top min(n, k) keys of K into sel[], returns their number.  KPT > 0: the keys live in registers
+// (n <= KPT * SEL_THREADS); KPT == 0: every pass re-loads them through the flat view.  sh.cnt == 0 on entry.
+template <int KPT>
+__device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k, SelShared &sh, uint64_t *sel,
+                                                    uint64_t *cand) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = K.n;
+    if (n == 0) return 0;
+    const uint32_t kpt = (n + SEL_THREADS - 1) / SEL_THREADS; // keys per thread; wave w owns [w*kpt*64, (w+1)*kpt*64)
+    const uint32_t first = wv * kpt * 64 + lane, last = n - 1;
+    constexpr int NR = KPT > 0 ? KPT : 1;
+    uint64_t key[NR];
+    if constexpr (KPT > 0) {
+        SelCursor cur = sel_seek(K, first < n ? first : last);
+        uint64_t at = sel_at(K, cur, first < n ? first : last);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) { // loads unpredicated (a slot past the end re-reads the previous key): all in flight
+            const uint32_t i = first + (uint32_t)j * 64;
+            if ((uint32_t)j < kpt && i < n) at = sel_at(K, cur, i); // the cursor only walks forward
+            key[j] = K.pool[at];
+        }
+    }
+    auto for_each = [&](auto &&f) {
+        if constexpr (KPT > 0) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if ((uint32_t)j < kpt) f(first + (uint32_t)j * 64 < n, key[j]); // uniform guard
+        } else {
+            SelCursor cur = sel_seek(K, first < n ? first : last);
+            uint64_t at = sel_at(K, cur, first < n ? first : last);
+            for (uint32_t j0 = 0; j0 < kpt; j0 += 4) { // four loads in flight per thread
+                uint64_t kx[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t i = first + (j0 + u) * 64;
+                    ok[u] = j0 + u < kpt && i < n;
+                    if (ok[u]) at = sel_at(K, cur, i);
+                    kx[u] = K.pool[at];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) f(ok[u], kx[u]);
+            }
+        }
+    };
+    if (n <= k) {
+        for_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, 2 * SEL_MAX, valid, kv); });
+        __syncthreads();
+        return n;
+    }
+    int shift;
+    uint64_t prefix;
+    if (KPT != 4 && n > SEL_CAND) {
+        // ---- cut the pool down with a sampled threshold: one key per thread, spread over the wave's range
+        const uint32_t js = lane % kpt, is = first + js * 64;
+        const bool sv = is < n;
+        uint64_t sk;
+        if constexpr (KPT > 0) {
+            sk = key[0];
+#pragma unroll
+            for (int j = 1; j < KPT; ++j) sk = (uint32_t)j == js ? key[j] : sk;
+        } else {
+            SelCursor cur = sel_seek(K, sv ? is : last);
+            sk = K.pool[sel_at(K, cur, sv ? is : last)];
+        }
+        if (tid == 0) sh.n_samples = 0;
+        __syncthreads();
+        {
+            const unsigned long long m = __ballot(sv);
+            if (lane == 0 && m) atomicAdd(&sh.n_samples, (uint32_t)__popcll(m));
+        }
+        __syncthreads();
+        const uint32_t ns = sh.n_samples;
+        uint32_t r = (uint32_t)(((uint64_t)ns * (2 * k) + n - 1) / n) + 1; // keeps ~2k keys (+1 sample of margin)
+        r = r > ns ? ns : r;
+        sel_threshold([&](auto &&f) { f(sv, sk); }, r, sh, shift, prefix);
+        for_each([&](bool valid, uint64_t kv) { sel_append(cand, &sh.cnt, SEL_CAND, valid && (kv >> shift) >= prefix, kv); });
+        __syncthreads();
+        const uint32_t c = sh.cnt;
+        __syncthreads();
+        if (tid == 0) sh.cnt = 0;
+        __syncthreads();
+        if (c >= k && c <= SEL_CAND) { // the top k of the pool are the top k of cand[0..c)
+            uint64_t ck[SEL_CAND / SEL_THREADS];
+#pragma unroll
+            for (int j = 0; j < SEL_CAND / SEL_THREADS; ++j) {
+                const uint32_t i = (uint32_t)j * SEL_THREADS + tid;
+                ck[j] = cand[i < c ? i : c - 1];
+            }
+            auto cand_each = [&](auto &&f) {
+#pragma unroll
+                for (int j = 0; j < SEL_CAND / SEL_THREADS; ++j)
+                    if ((uint32_t)j * SEL_THREADS < c) f((uint32_t)j * SEL_THREADS + tid < c, ck[j]);
+            };
+            if (c == k) { // nothing to select
+                cand_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid, kv); });
+                __syncthreads();
+                return k;
+            }
+            sel_threshold(cand_each, k, sh, shift, prefix);
+            cand_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
+            __syncthreads();
+            return sh.cnt < k ? sh.cnt : k;
+        }
+        // the sample misjudged the pool: exact passes over all of it
+    }
+    sel_threshold(for_each, k, sh, shift, prefix);
+    // every key whose top bits are >= prefix is selected: exactly k of them (keys are distinct)
+    for_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
+    __syncthreads();
+    return sh.cnt < k ? sh.cnt : k;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
+    uint64_t *pools, uint32_t *carry_cnt, uint32_t *seg_cnt, uint32_t *tau_keys, uint64_t pool_stride,
+    uint32_t carry_cap, uint32_t seg_cap, uint32_t n_segs, uint32_t seg_cnt_stride, uint32_t *overflow,
+    uint32_t k, int compact, float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+    __shared__ SelShared sh;
+    __shared__ uint64_t sel[2 * SEL_MAX];
+    __shared__ uint64_t cand[SEL_CAND];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t *pool = pools + (uint64_t)q * pool_stride;
+    uint32_t *segc = seg_cnt + (uint64_t)q * seg_cnt_stride;
+
+    // exclusive scan of the (clamped) segment counts -> sh.seg_off; SEL_MAX_SEGS / SEL_THREADS = 4 per thread
+    constexpr int SPT = SEL_MAX_SEGS / SEL_THREADS;
+    uint32_t c[SPT], local = 0;
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const uint32_t sg = tid * SPT + u;
+        uint32_t v = segc[sg < n_segs ? sg : 0];
+        if (sg >= n_segs) v = 0;
+        if (v > seg_cap) { *overflow = 1u; v = seg_cap; }
+        c[u] = v;
+        local += v;
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, OI_WAVE);
+        if ((int)lane >= o) incl += v;
+    }
+    if (lane == 63) sh.wave_tot[wv] = incl;
+    if (tid == 0) { sh.cnt = 0; sh.min_key = ~0ull; }
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        const uint32_t t = sh.wave_tot[w];
+        base += (uint32_t)w < wv ? t : 0u;
+        total += t;
+    }
+    uint32_t run = base + incl - local;
+#pragma unroll
+    for (int u = 0; u < SPT; ++u) {
+        const uint32_t sg = tid * SPT + u;
+        if (sg < n_segs) sh.seg_off[sg] = run;
+        run += c[u];
+    }
+    if (tid == 0) sh.seg_off[n_segs] = total;
+    __syncthreads();
+
+    SelFlat K;
+    K.pool = pool; K.seg_off = sh.seg_off; K.carry_cap = carry_cap; K.seg_cap = seg_cap; K.n_segs = n_segs;
+    K.c0 = carry_cnt[q] < carry_cap ? carry_cnt[q] : carry_cap;
+    K.n = K.c0 + total;
+    K.steps = 0;
+    while ((1u << K.steps) < n_segs) ++K.steps;
+
+    uint32_t m;
+    if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand);
+    else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand);
+    else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand);
+    else if (K.n <= SEL_KPT_MAX * SEL_THREADS) m = sel_flat_select<SEL_KPT_MAX>(K, k, sh, sel, cand);
+    else m = sel_flat_select<0>(K, k, sh, sel, cand);
+
+    // Sorted output is needed only for a final list; an intermediate compaction just needs the set
+    // and its smallest key (the new threshold).
+    if (out_scores) {
+        uint32_t P = 2;
+        while (P < m) P <<= 1;
+        for (uint32_t i = m + tid; i < P; i += SEL_THREADS) sel[i] = 0; // lowest possible key
+        __syncthreads();
+        bitonic_sort_desc(sel, P);
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) {
+            const uint64_t key = sel[i];
+            out_scores[(uint64_t)q * out_stride + i] = oi_rank_key_score(key);
+            out_docs[(uint64_t)q * out_stride + i] = oi_rank_key_doc(key);
+        }
+        if (tid == 0) { out_counts[q] = m; sh.min_key = m ? sel[m - 1] : 0; }
+    } else {
+        unsigned long long lo = ~0ull;
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) lo = sel[i] < lo ? sel[i] : lo;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long v = __shfl_xor(lo, o, OI_WAVE);
+            lo = v < lo ? v : lo;
+        }
+        if (lane == 0 && lo != ~0ull) atomicMin(&sh.min_key, lo);
+    }
+    __syncthreads();
+    if (compact) {
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = sel[i];
+        for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) segc[sg] = 0;
+        if (tid == 0) {
+            carry_cnt[q] = m;
+            if (m == k && tau_keys) { // k docs at or above this score exist: a valid lower bound of the final k-th
+                const uint32_t t = (uint32_t)(sh.min_key >> 32);
+                if (t > tau_keys[q]) tau_keys[q] = t;
+            }
+        }
+    }
+}
+
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
                      float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
     if (n_queries == 0) return OI_OK;
     OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH && k <= pool.carry_cap, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
     ProfScope ps(ctx, "select");
+    static const bool v1 = getenv("OI_SELECT_V1") != nullptr; // A/B switch: the segment-walking kernel
+    if (!v1 && pool.n_segs <= SEL_MAX_SEGS) {
+        hipLaunchKernelGGL(select_flat_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, pool.keys,
+                           pool.carry_cnt, pool.seg_cnt, pool.tau_keys, pool.stride, pool.carry_cap, pool.seg_cap,
+                           pool.n_segs, pool.seg_cnt_stride, pool.overflow, k, compact ? 1 : 0, out_scores, out_docs,
+                           out_counts, out_stride);
+        OI_HIP_CHECK(hipGetLastError());
+        return OI_OK;
+    }
     hipLaunchKernelGGL(select_topk_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, pool.keys,
                        pool.carry_cnt, pool.seg_cnt, pool.tau_keys, pool.stride, pool.carry_cap, pool.seg_cap,
                        pool.n_segs, pool.seg_cnt_stride, pool.overflow, k, compact ? 1 : 0, out_scores, out_docs,

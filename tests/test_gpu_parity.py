@@ -391,6 +391,50 @@ def test_merge_and_rrf_kernels_bit_exact(ctx, O):
             assert np.array_equal(R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32))
 
 
+@pytest.mark.parametrize("S,depth,mode", [
+    (4, 1000, "normal"), (8, 1000, "normal"), (8, 1000, "ties"), (16, 1000, "normal"), (32, 1000, "normal"),
+    (32, 1024, "flat"), (40, 1000, "normal"), (40, 1000, "ties"), (1024, 64, "normal"), (1024, 64, "sparse"),
+    (300, 10, "sparse"), (64, 512, "skewed"), (9, 1, "normal")])
+def test_select_pool_sizes_bit_exact(ctx, O, S, depth, mode):
+    """The pool selection behind every ranked list (select.hip), driven through oi_merge_lists so that the pool
+    is S segments of up to `depth` keys: every size class of the flat kernel (registers 4/8/16/32 keys per
+    thread, the re-loading path above 32K keys), its sampled cut and that cut's fallbacks -- score ties that
+    reach into the doc-id bits, one constant score, lists from shards of very different quality, empty and
+    ragged segments."""
+    from openintel_amd import merge_lists
+    rng = np.random.default_rng(S * 1000 + depth)
+    B = 3
+    scores = np.zeros((S, B, depth), np.float32); docs = np.zeros((S, B, depth), np.uint32)
+    if mode == "sparse":
+        counts = (rng.integers(0, depth + 1, size=(S, B)) * (rng.random((S, B)) < 0.1)).astype(np.uint32)
+    else:
+        counts = rng.integers(depth // 2, depth + 1, size=(S, B)).astype(np.uint32)
+        counts[0, 0] = depth
+        if S > 1:
+            counts[1, 1] = 0
+    for s in range(S):
+        for b in range(B):
+            c = int(counts[s, b])
+            if mode == "ties":
+                sc = np.round(rng.standard_normal(c), 1).astype(np.float32)
+            elif mode == "flat":
+                sc = np.full(c, 0.25, np.float32)
+            elif mode == "skewed":   # shard s's scores sit around s: the top of the pool comes from a few segments
+                sc = (rng.standard_normal(c) * 0.01 + s).astype(np.float32)
+            else:
+                sc = (rng.standard_normal(c) * 0.05).astype(np.float32)
+            dd = rng.choice(200000, size=c, replace=False).astype(np.uint32) * S + s   # disjoint across shards
+            o = np.lexsort((dd, -sc.astype(np.float64)))
+            scores[s, b, :c], docs[s, b, :c] = sc[o], dd[o]
+    so, do, co = merge_lists(ctx, scores, docs, counts)
+    for b in range(B):
+        ms, md = O.merge_ranked([scores[s, b, :counts[s, b]] for s in range(S)],
+                                [docs[s, b, :counts[s, b]] for s in range(S)], depth)
+        assert co[b] == md.size
+        assert np.array_equal(do[b][:md.size], md)
+        assert np.array_equal(so[b][:md.size].view(np.uint32), ms.view(np.uint32))
+
+
 def test_errors_are_loud(ctx):
     import openintel_amd as oi
     from openintel_amd._lib import OiError
