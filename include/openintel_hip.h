@@ -261,7 +261,9 @@ int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_term
 /* Timing hooks for bench.py: when enabled, HIP events are recorded on the ctx stream
  * around every kernel launch, grouped by tag ("cosine", "bm25", "select", "rrf",
  * "lexicon", "social_summary").  oi_profile_read returns the summed duration (ms) of
- * the launches with that tag and their count since the last reset. */
+ * the launches with that tag and their count since the last reset.  enable: 0 off, 1 every
+ * tagged launch, 2 only the "cosine" launches (two event packets per launch cost a few us of
+ * stream time each: a timed region that only needs its dominant kernel asks for 2). */
 int oi_profile_reset(oi_ctx *ctx, int enable);
 int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out);
 

@@ -40,8 +40,9 @@ class HipContext:
         _lib.check(self.lib.oi_set_overlap(self.handle, 1 if enable else 0))
 
     # ---- HIP-event kernel timing (bench.py)
-    def profile_reset(self, enable: bool = True) -> None:
-        _lib.check(self.lib.oi_profile_reset(self.handle, 1 if enable else 0))
+    def profile_reset(self, enable=True) -> None:
+        """enable: False/0 off, True/1 every tagged launch, 2 only the cosine scorer's launches."""
+        _lib.check(self.lib.oi_profile_reset(self.handle, int(enable)))
 
     def profile_read(self, tag: str):
         ms, n = C.c_double(), C.c_uint64()

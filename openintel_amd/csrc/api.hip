@@ -57,7 +57,7 @@ extern "C" int oi_profile_reset(oi_ctx *ctx, int enable) {
     for (auto &kv : ctx->prof)
         for (auto &s : kv.second) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     ctx->prof.clear();
-    ctx->prof_enabled = enable != 0;
+    ctx->prof_enabled = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return OI_OK;
 }
 
@@ -479,9 +479,12 @@ static uint64_t oi_first_chunk_rows(uint32_t depth) {
     static const uint64_t mult = getenv("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(getenv("OI_FIRST_CHUNK_MULT"))) : 1;
     return std::max<uint64_t>(8192, 32ull * depth) * mult;
 }
-static uint64_t oi_chunk_growth() {
-    static const uint64_t g = getenv("OI_CHUNK_GROWTH") ? std::max(2, atoi(getenv("OI_CHUNK_GROWTH"))) : 8;
-    return g;
+// Measured (tools/growth_ab.sh): 8 is best for the MFMA batch path at 10M and 1.25M rows (more survivors per
+// chunk cost more in the epilogue and the select than the launch they save); the GEMV path (B <= 8) gains
+// 3 % from 16 (1M rows: 3 launches instead of 4).
+static uint64_t oi_chunk_growth(uint32_t B) {
+    static const uint64_t g = getenv("OI_CHUNK_GROWTH") ? std::max(2, atoi(getenv("OI_CHUNK_GROWTH"))) : 0;
+    return g ? g : (B <= 8 ? 16 : 8);
 }
 
 // Device-side ranked lists for a batch; all pointers device.
@@ -609,7 +612,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
                                           last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
                 r = e;
-                chunk *= oi_chunk_growth();
+                chunk *= oi_chunk_growth(B);
             }
         } else if (cos_s) {
             OI_REQUIRE(idx->rows, "search: embeddings not set");
@@ -634,7 +637,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
                                           last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
                 r = e;
-                chunk *= oi_chunk_growth();
+                chunk *= oi_chunk_growth(B);
             }
         }
         return OI_OK;

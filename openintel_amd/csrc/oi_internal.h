@@ -70,7 +70,7 @@ struct oi_ctx {
     int cosine_mode = 0;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
-    bool prof_enabled = false;
+    int prof_enabled = 0; // 0 off, 1 every tagged launch, 2 the cosine scorer only
     std::map<std::string, std::vector<ProfSpan>> prof;
     std::vector<hipEvent_t> event_pool;
 
@@ -82,11 +82,13 @@ struct oi_ctx {
 struct ProfScope {
     oi_ctx *c;
     const char *tag;
+    bool on;
     ProfScope(oi_ctx *ctx, const char *t) : c(ctx), tag(t) {
-        if (c->prof_enabled) c->prof_begin(tag);
+        on = c->prof_enabled == 1 || (c->prof_enabled == 2 && strcmp(t, "cosine") == 0);
+        if (on) c->prof_begin(tag);
     }
     ~ProfScope() {
-        if (c->prof_enabled) c->prof_end(tag);
+        if (on) c->prof_end(tag);
     }
 };
 
