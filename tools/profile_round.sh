@@ -15,3 +15,5 @@ python3 $R/tools/bm25_bench.py 10000000 5 > $OUT/bm25_bench.json 2> $OUT/bm25_be
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/tools/headline_bench.py 10000000 5 > /dev/null 2> $OUT/stats_headline.err && echo "stats headline ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bm25 -- python3 $R/tools/bm25_bench.py 10000000 3 > /dev/null 2> $OUT/stats_bm25.err && echo "stats bm25 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lexicon -- python3 $R/tools/lexicon_bench.py 10000000 5 > /dev/null 2> $OUT/stats_lexicon.err && echo "stats lexicon ok"
+python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
+python3 $R/tools/shard_step_bench.py 1250000 50 > $OUT/shard_step.json 2> $OUT/shard_step.err && echo "shard ok"
