@@ -66,8 +66,9 @@ def main():
     ap.add_argument("--bm25", choices=["taat", "scan"], default="taat", help="BM25 kernel (default: term-at-a-time)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
-    ap.add_argument("--cosine", choices=["exact", "split"], default="exact",
-                    help="f32 corpus products: exact f32 MFMA (default) or split-precision (six bf16 MFMAs per product)")
+    ap.add_argument("--cosine", choices=["exact", "split", "screen"], default="exact",
+                    help="f32 corpus scorer: exact f32 MFMA (default), split-precision products (six bf16 MFMAs), or a "
+                         "bf16 screen with a proven bound + exact f32 rescoring of the survivors (same lists, HBM-bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -103,9 +104,9 @@ def main():
 
     ctx = oi.HipContext(local_rank)
     ctx.use_torch_current_stream()
-    if args.cosine == "split":
+    if args.cosine != "exact":
         from openintel_amd import _lib as _oil
-        ctx.set_cosine_mode(_oil.OI_COSINE_SPLIT)
+        ctx.set_cosine_mode(_oil.OI_COSINE_SPLIT if args.cosine == "split" else _oil.OI_COSINE_SCREEN)
 
     # ---------------------------------------------------------------- corpus shard in HBM
     lo, hi = sharded.shard_bounds(args.docs, world, rank)
@@ -234,7 +235,10 @@ def main():
             "metric": "queries/sec + p50 latency, 10M-post/768-d hybrid BM25+cosine+RRF top-100",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": args.corpus if args.cosine == "exact" else "f32 (bf16x3 split products, f32 accumulate)",
+            "vs_baseline": None,
+            "dtype": args.corpus if args.cosine == "exact" else
+                     "f32 (bf16x3 split products, f32 accumulate)" if args.cosine == "split" else
+                     "f32 (scores: exact f32 dot products; rows are chosen by a bf16 screen with a proven error bound)",
             "data": "synthetic",
             "config": {"workload": "%s: %d posts x %d-d %s, batch %d queries x 4 BM25 terms, "
                                    "per-list depth %d, RRF top-%d; corpus row-sharded over %d GPU(s)" % (

@@ -85,9 +85,15 @@ int oi_synchronize(oi_ctx *ctx);
  *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
  *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7) at
  *                              3/8 of the matrix-pipe time, so the scorer becomes HBM-bound.
- * The corpus stays f32 in HBM either way.  Also selectable with OI_COSINE_MODE=split at oi_create. */
+ *   OI_COSINE_SCREEN           a bf16 screen with a proven error bound picks the rows that can reach the list
+ *                              (one bf16 MFMA per product, rows converted on the fly: HBM-bound), exact f32
+ *                              scores are then computed for those rows only; a query whose survivors do not fit
+ *                              falls back, inside the same call, to the exact kernel.  The lists are the exact
+ *                              scorer's (csrc/cosine_prefilter.hip has the argument).
+ * The corpus stays f32 in HBM either way.  Also selectable with OI_COSINE_MODE=split|screen at oi_create. */
 #define OI_COSINE_EXACT 0
 #define OI_COSINE_SPLIT 1
+#define OI_COSINE_SCREEN 2
 int oi_set_cosine_mode(oi_ctx *ctx, int mode);
 
 /* A hybrid query has two independent legs until fusion.  By default the BM25 leg is issued on an

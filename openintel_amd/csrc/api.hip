@@ -75,6 +75,13 @@ extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *tota
         if (launches_out) *launches_out = 0;
         return OI_OK;
     }
+    if (strcmp(kernel_tag, "screen_gate") == 0) { // diagnostics: did the last screened search fall back to the exact kernel?
+        uint32_t g = 0;                          // (0 no, nonzero yes; -1 when no search has used the screen)
+        if (ctx->last_screen_gate) OI_HIP_CHECK(hipMemcpy(&g, ctx->last_screen_gate, 4, hipMemcpyDeviceToHost));
+        if (total_ms_out) *total_ms_out = ctx->last_screen_gate ? (double)g : -1.0;
+        if (launches_out) *launches_out = 0;
+        return OI_OK;
+    }
     auto it = ctx->prof.find(kernel_tag);
     if (it != ctx->prof.end())
         for (auto &s : it->second) {
@@ -108,7 +115,8 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->device = device_ordinal;
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->stream = nullptr;
-    if (const char *m = getenv("OI_COSINE_MODE")) c->cosine_mode = strcmp(m, "split") == 0 ? 1 : 0;
+    if (const char *m = getenv("OI_COSINE_MODE"))
+        c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "screen") == 0 ? OI_COSINE_SCREEN : OI_COSINE_EXACT;
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
@@ -139,7 +147,8 @@ extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
 
 extern "C" int oi_set_cosine_mode(oi_ctx *ctx, int mode) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT, "oi_set_cosine_mode: unknown mode %d", mode);
+    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT || mode == OI_COSINE_SCREEN,
+               "oi_set_cosine_mode: unknown mode %d", mode);
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->cosine_mode = mode;
     return OI_OK;
@@ -320,7 +329,7 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
         idx->postings.release(); idx->cell_start.release(); idx->idf.release();
-        idx->fwd_terms.release(); idx->fwd_offsets.release();
+        idx->fwd_terms.release(); idx->fwd_offsets.release(); idx->max_row_norm.release();
     }
     delete idx;
 }
@@ -345,6 +354,9 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
         OI_HIP_CHECK(hipMemcpyAsync(idx->rows, rows, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     if (normalize) OI_CHECK(oi_launch_l2_normalize(ctx, idx->rows, idx->n_docs, idx->dim));
+    // the bf16 screen's error bound needs max |row| (cosine_prefilter.hip): one more pass over the rows, now
+    OI_CHECK(idx->max_row_norm.ensure(16));
+    OI_CHECK(oi_launch_row_norm_max(ctx, idx->rows, idx->n_docs, idx->dim, idx->max_row_norm.as<uint32_t>()));
     OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OI_OK;
 }
@@ -627,18 +639,80 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             }
             const uint64_t max_chunk = oi_cosine_max_chunk_rows(ctx, idx->dim, B, cos_stride, carry_cap);
             if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
+            // the exact pipeline; with a gate it is the fallback behind the bf16 screen and every launch exits at
+            // once unless the screen opened the gate
+            auto exact_pipeline = [&](const uint32_t *gate) -> int {
+                SelectExtra ex;
+                ex.run_gate = gate;
+                uint64_t chunk = oi_first_chunk_rows(depth);
+                uint64_t r = 0;
+                while (r < n) {
+                    if (chunk > max_chunk) chunk = max_chunk;
+                    const uint64_t e = std::min(n, r + chunk);
+                    OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
+                    const bool last = e == n;
+                    OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                                              last ? cos_d : nullptr, last ? cos_c : nullptr, depth, gate ? &ex : nullptr));
+                    r = e;
+                    chunk *= oi_chunk_growth(B);
+                }
+                return OI_OK;
+            };
+            static const bool shape16 = !(getenv("OI_KS_SHAPE") && atoi(getenv("OI_KS_SHAPE")) == 32);
+            static const bool cos_v1 = getenv("OI_COSINE_V1") != nullptr || getenv("OI_SELECT_V1") != nullptr;
+            const bool screen = ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && oi_cosine_screen_supported(idx->dim) &&
+                                idx->max_row_norm.p && shape16 && !cos_v1;
+            if (!screen) return exact_pipeline(nullptr);
+
+            // ---- bf16 screen -> margin selects -> exact rescoring -> sorted selection; then the gated exact pipeline
+            // (cosine_prefilter.hip).  Its pool keeps up to 4096 keys per query between chunks.
+            const uint32_t pf_carry = 4096;
+            const uint64_t pf_slack = 128ull * ((uint64_t)ctx->num_cus + 1); // segments round up to 4 tiles per workgroup
+            uint64_t pf_stride = 1ull << 24;
+            if (pf_stride > budget) pf_stride = budget;
+            if (pf_stride < pf_carry + 4 * pf_slack) pf_stride = pf_carry + 4 * pf_slack;
+            if (pf_stride > pf_carry + n + pf_slack) pf_stride = pf_carry + n + pf_slack;
+            const uint32_t segs = (uint32_t)ctx->num_cus;
+            // state, zeroed with one memset: carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][segs]
+            const size_t words = (size_t)B * (4 + segs) + 4;
+            DevBuf &ps = ctx->buf("screen_state"), &pk = ctx->buf("screen_pool"), &rk = ctx->buf("screen_rescored"),
+                   &qb = ctx->buf("screen_q_bf16");
+            OI_CHECK(ps.ensure(sizeof(uint32_t) * words));
+            OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * pf_stride));
+            OI_CHECK(rk.ensure(sizeof(uint64_t) * (size_t)B * pf_carry));
+            const uint32_t n_padded = (B + 31u) & ~31u;
+            OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 64) * idx->dim));
+            OI_HIP_CHECK(hipMemsetAsync(ps.p, 0, sizeof(uint32_t) * words, st));
+            uint32_t *w = ps.as<uint32_t>();
+            uint32_t *pf_cnt = w, *pf_tau = w + B, *rs_cnt = w + 2 * (size_t)B;
+            float *eps2 = reinterpret_cast<float *>(w + 3 * (size_t)B);
+            uint32_t *gate = w + 4 * (size_t)B, *pf_seg = gate + 4;
+            PoolView PF{pk.as<uint64_t>(), pf_cnt, pf_seg, pf_tau, pf_stride, pf_carry, 0, 0, segs, P.cos.overflow};
+            PoolView RS{rk.as<uint64_t>(), rs_cnt, pf_seg, nullptr, pf_carry, pf_carry, 0, 0, segs, P.cos.overflow};
+            OI_CHECK(oi_launch_screen_stage(ctx, d_qv, B, idx->dim, idx->max_row_norm.as<uint32_t>(), qb.as<uint16_t>(),
+                                            eps2, gate));
+            const uint64_t pf_max_chunk = pf_stride - pf_carry - pf_slack;
+            SelectExtra mx;
+            mx.eps2 = eps2;
+            mx.margin_gate = gate;
             uint64_t chunk = oi_first_chunk_rows(depth);
             uint64_t r = 0;
             while (r < n) {
-                if (chunk > max_chunk) chunk = max_chunk;
+                if (chunk > pf_max_chunk) chunk = pf_max_chunk;
                 const uint64_t e = std::min(n, r + chunk);
-                OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
-                const bool last = e == n;
-                OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
-                                          last ? cos_d : nullptr, last ? cos_c : nullptr, depth));
+                OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
+                OI_CHECK(oi_launch_select(ctx, PF, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth, &mx));
                 r = e;
                 chunk *= oi_chunk_growth(B);
             }
+            OI_CHECK(oi_launch_rescore(ctx, idx->rows, n, idx->dim, idx->doc_id_base, d_qv, B, PF, RS));
+            RS.n_segs = 0;
+            OI_CHECK(oi_launch_select(ctx, RS, B, depth, false, cos_s, cos_d, cos_c, depth));
+            ctx->run_gate = gate;
+            ctx->last_screen_gate = gate;
+            const int rc = exact_pipeline(gate);
+            ctx->run_gate = nullptr;
+            return rc;
         }
         return OI_OK;
     };

@@ -245,7 +245,7 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
     OI_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= OI_MAX_DIM, "cosine: dim=%u must be a multiple of 4 in [4,%u]",
                dim, OI_MAX_DIM);
     const uint64_t n_rows = row_end - row_begin;
-    ProfScope ps(ctx, "cosine");
+    ProfScope ps(ctx, ctx->run_gate ? "cosine_gated" : "cosine");
     if (n_queries <= 8) {
         dim3 g((uint32_t)gemv_blocks(ctx, n_rows)), b(256);
 #define OI_GEMV(NQ)                                                                                     \
@@ -281,7 +281,7 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
         p.tau_keys += q0;
         const float *qptr = d_queries + (uint64_t)q0 * dim;
-        if (ksplit && ctx->cosine_mode == 1 && oi_cosine_split_supported(dim)) {
+        if (ksplit && ctx->cosine_mode == OI_COSINE_SPLIT && oi_cosine_split_supported(dim)) {
             OI_CHECK(oi_launch_cosine_split(ctx, rows, row_begin, row_end, dim, qptr, nq_here, doc_id_base, p));
         } else if (ksplit) {
             OI_CHECK(oi_launch_cosine_ksplit(ctx, rows, row_begin, row_end, dim, qptr, nq_here, left >= 64,

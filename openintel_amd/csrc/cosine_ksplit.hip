@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
     const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
     const float *__restrict__ queries, // [32*NQT][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
-    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow,
+    const uint32_t *run_gate) { // run_gate != null: part of the gated exact pipeline (cosine_prefilter.hip)
+    if (run_gate && *run_gate == 0u) return;
     constexpr int KS = D / 4, NKC = KS / KS_CHUNK_K, NBUF = NKC <= 6 ? NKC : NKC / 2, P = NBUF - 1;
     constexpr int NQ16 = 2 * NQT;        // query tiles of 16
     constexpr int QR = KS / 4;           // query registers per tile (one per k-step of 4)
@@ -504,7 +506,7 @@ static int launch_ksplit16(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
     }
     hipLaunchKernelGGL((cosine_ksplit16_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows,
                        row_begin, row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys,
-                       p.stride, p.carry_cap, p.seg_cap, p.overflow);
+                       p.stride, p.carry_cap, p.seg_cap, p.overflow, ctx->run_gate);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
@@ -565,6 +567,7 @@ int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, 
     // 16x16x4 is the default: 3 % faster by wall time than 32x32x2 on the same tile (A/B in one
     // session, 10M x 768, B=64: 9.07 vs 9.35 ms); OI_KS_SHAPE=32 selects the other build.
     static const bool shape16 = !(getenv("OI_KS_SHAPE") && atoi(getenv("OI_KS_SHAPE")) == 32);
+    OI_REQUIRE(shape16 || !ctx->run_gate, "cosine_ksplit: only the 16x16x4 build takes a run gate");
 #define OI_KS(DD)                                                                                       \
     case DD:                                                                                            \
         if (shape16)                                                                                    \

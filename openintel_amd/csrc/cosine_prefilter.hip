@@ -1,0 +1,428 @@
+// cosine_prefilter.hip -- the f32 corpus scored at HBM speed: a bf16 screen with a PROVEN error bound, then
+// exact f32 scores for the few rows that pass it.
+//
+// Builder-defined like the rest of the retrieval path (the reference has none).
+//
+// Why.  The exact f32 MFMA scorer (cosine_ksplit.hip) is bound by the f32 matrix pipes and, under them, by the
+// chip's power limit (8.8 ms per 64-query batch at 10M x 768 = 70 % of the f32 MFMA peak; the same corpus
+// streams from HBM in 5 ms).  A top-k' list does not need the exact score of every row, only of the rows that
+// can reach the list.  So:
+//   1. screen: s~ = sum_k bf16(x_k) * bf16(q_k), accumulated in f32 by v_mfma_f32_32x32x16_bf16 (1/16 of the
+//      f32 MFMA cycles), the f32 rows converted on the fly between LDS and the matrix pipe (v_cvt_pk_bf16_f32,
+//      round to nearest even).  The corpus stays f32 in HBM and is read once: the kernel is a stream.
+//   2. bound: |bf16(v) - v| <= 2^-9 |v|, so |s~ - s| <= (2^-8 + 2^-17) sum_k |x_k q_k| + (f32 accumulation)
+//      <= eps = (2^-8 + 2^-12) * max_row_norm * |q|   (Cauchy-Schwarz; the 2^-12 covers both accumulations
+//      and the rounding of the norms).  max_row_norm is taken when the rows are set, |q| per query.
+//   3. keep: if tau~ is the k'-th largest s~ seen so far, at least k' rows have s >= tau~ - eps, so the final
+//      k'-th exact score is >= tau~ - eps, and any row of the final list has s~ >= tau~ - 2 eps.  The select
+//      after each corpus chunk therefore keeps EVERY key within 2 eps of the k'-th (select.hip, margin mode) and
+//      the screen's threshold is tau~ - 2 eps: a superset of the exact list survives, about 2.3 k' keys for
+//      unit vectors at d = 768.
+//   4. rescore: exact f32 dot products of the survivors only (one wave per (query, row); ~150K rows per batch
+//      instead of 640M), then the ordinary sorted top-k' selection over exact keys.
+//   5. if a query's survivors do not fit (4096 keys: rows within 2 eps of the threshold -- duplicates, or norms
+//      far above the typical row's) or a norm is not finite, a device flag opens the GATED exact pipeline that
+//      follows in the same stream and overwrites the lists; otherwise those launches exit at once.
+// The lists that come out are those of the exact scorer (up to the f32 rounding of two different summation
+// orders, which the parity tolerance already covers); tests/test_gpu_prefilter.py checks both regimes.
+//
+// Kernel shape: cosine_bf16.hip's solo kernel fed with f32 rows.  One workgroup per CU, 4 waves, no K-split:
+// a wave holds all 64 queries over the whole K as bf16 B operands (384 VGPRs at d = 768), owns whole 32-row
+// tiles and streams them through its own LDS ring of 4 KiB slots (32 rows x 32 floats) with
+// buffer_load ... lds, 7 slots ahead, ordered by counted s_waitcnt vmcnt; waves never meet.  Per 16 k of a tile:
+// two conflict-free ds_read_b128, four v_cvt_pk_bf16_f32, two MFMAs.  HBM-bound: 4 d bytes per row and batch.
+#include <cstdlib>
+#include <type_traits>
+
+#include "oi_device.h"
+#include "oi_internal.h"
+
+typedef float pf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t pf_u32x4 __attribute__((ext_vector_type(4)));
+
+#define PF_TILE_ROWS 32
+#define PF_SLOT_K 32                 // floats of K per ring slot row (128 B)
+#define PF_SLOT_BYTES (PF_TILE_ROWS * 128)
+
+__device__ __forceinline__ uint32_t pf_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ pf_u32x4 pf_make_srd(const float *base, uint64_t bytes) {
+    const uint64_t b = (uint64_t)base;
+    pf_u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xFFFFu); // stride 0
+    r[2] = __builtin_amdgcn_readfirstlane((uint32_t)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes));
+    r[3] = 0x00020000u;
+    return r;
+}
+// One 1-KiB LDS-DMA piece (8 rows x 128 B).  Lanes past the descriptor's end read as zero: the ragged last
+// tile and the tile after the last one (empty descriptor) need no branch.  hipcc does not see these loads:
+// they are ordered by pf_wait<N>().
+__device__ __forceinline__ void pf_issue_piece(const pf_u32x4 &srd, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+    uint32_t keep;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(so), "s"(d)
+        : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void pf_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pf_static_for<I + 1, N>(f);
+    }
+}
+template <int N>
+__device__ __forceinline__ void pf_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ pf_bf16x8 pf_pack(const pf_f32x4 &a, const pf_f32x4 &b) {
+    pf_bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3]; // v_cvt_pk_bf16_f32 (RNE)
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    return r;
+}
+
+template <int D, int NQT>
+__global__ __launch_bounds__(256, 1) void cosine_screen_filter(
+    const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const uint16_t *__restrict__ queries, // bf16 [32*NQT][D], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int NKC = D / PF_SLOT_K;                    // ring slots per tile
+    constexpr int NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
+    constexpr int P = NBUF - 1;                           // slots in flight ahead of the one being consumed
+    constexpr int KSTEPS = D / 16;                        // MFMA groups per tile: two per slot
+    static_assert(D % PF_SLOT_K == 0 && NKC % NBUF == 0 && P >= 1 && P < NKC, "unsupported D");
+    static_assert(NQT * KSTEPS * 4 <= 400, "the query block must fit the register file");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                         // [4][NBUF][4 KiB]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * PF_SLOT_BYTES); // [32*NQT]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t li = lane & 31, lh = lane >> 5;
+
+    // ---- every query over the whole K, in registers for the whole launch: B[k = 16 s + 8 lh + 0..7][n = li]
+    pf_bf16x8 qreg[NQT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            qreg[t][s] = *reinterpret_cast<const pf_bf16x8 *>(queries + (uint64_t)(32 * t + li) * D + 16 * s + 8 * lh);
+    uint32_t tau[NQT]; // screen thresholds (tau~ - 2 eps, as orderable keys) of the queries this lane filters
+#pragma unroll
+    for (int t = 0; t < NQT; ++t) {
+        const uint32_t q = 32u * t + li;
+        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+    }
+    if (tid < 32 * NQT) seg_fill[tid] = 0;
+    __syncthreads(); // the only barrier before the end: seg_fill is zero before any wave appends
+
+    // ---- tiles of this WAVE: (blockIdx.x * 4 + w), + 4 * gridDim.x, ...
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + PF_TILE_ROWS - 1) / PF_TILE_ROWS;
+    const uint64_t first = (uint64_t)blockIdx.x * 4 + w, stride = (uint64_t)gridDim.x * 4;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+
+    if (my_nt) {
+        // per-lane source of the 4 DMA pieces of a slot: piece m covers tile rows 8m..8m+7; lane l -> row
+        // 8m + (l>>3), physical 16-B column l&7 holding LOGICAL column (l&7) ^ ((row>>1)&7)
+        uint32_t voff[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const uint32_t prow = 8 * m + (lane >> 3);
+            voff[m] = prow * (uint32_t)(D * 4) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+        }
+        const uint32_t ring_w = pf_lds_addr(ring) + w * (NBUF * PF_SLOT_BYTES);
+        const unsigned char *ring_rd = ring + w * (NBUF * PF_SLOT_BYTES);
+        // fragment of k-step g of a slot: row li, floats 16 g + 8 lh + 0..7 = logical 16-B columns 4g + 2lh, + 1
+        uint32_t frag_off[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) frag_off[g][h] = li * 128 + (((4 * g + 2 * lh + h) ^ ((li >> 1) & 7)) << 4);
+
+        auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)PF_TILE_ROWS; };
+        auto tile_srd = [&](uint64_t ti) { // past this wave's last tile: an EMPTY descriptor (loads return zeros)
+            const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
+            return pf_make_srd(rows + r0 * D, ti < my_nt ? (row_end - r0) * (uint64_t)(D * 4) : 0ull);
+        };
+        pf_u32x4 cur = tile_srd(0), nxt = tile_srd(1);
+        // Every load hipcc knows about (queries, thresholds) is retired HERE, with a wait it models:
+        // otherwise it re-waits for them inside the tile loop and drains the DMA ring.
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+#pragma unroll
+        for (int kc = 0; kc < P; ++kc) // prologue: slots 0..P-1 of the first tile
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                pf_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * PF_SLOT_BYTES + m * 1024);
+
+        for (uint64_t ti = 0; ti < my_nt; ++ti) {
+            pf_f32x16 acc[NQT];
+#pragma unroll
+            for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+            // Slot s of this tile lives in ring buffer s % NBUF.  Per k-step (kc, g): read the next k-step's
+            // floats, NQT MFMAs on the current operand, DMA pieces 2g, 2g+1 of slot kc + P into the buffer
+            // slot kc - 1 has vacated, convert the floats read; at g == 1 the next k-step is (kc + 1, 0),
+            // behind the counted wait that retires slot kc + 1 (P - 1 younger slots stay in flight).
+            pf_wait<4 * (P - 1)>();
+            pf_bf16x8 a_cur = pf_pack(*reinterpret_cast<const pf_f32x4 *>(ring_rd + frag_off[0][0]),
+                                      *reinterpret_cast<const pf_f32x4 *>(ring_rd + frag_off[0][1]));
+            pf_static_for<0, NKC * 2>([&](auto gi_) {
+                constexpr int gi = decltype(gi_)::value;
+                constexpr int kc = gi / 2, g = gi % 2;
+                constexpr int sn = kc + P; // slot refilled during this slot's k-steps
+                pf_f32x4 f0, f1;
+                if constexpr (g == 0) {
+                    f0 = *reinterpret_cast<const pf_f32x4 *>(ring_rd + (kc % NBUF) * PF_SLOT_BYTES + frag_off[1][0]);
+                    f1 = *reinterpret_cast<const pf_f32x4 *>(ring_rd + (kc % NBUF) * PF_SLOT_BYTES + frag_off[1][1]);
+                }
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int m = 2 * g; m < 2 * g + 2; ++m) {
+                    if constexpr (sn < NKC)
+                        pf_issue_piece(cur, voff[m], sn * 128, ring_w + (sn % NBUF) * PF_SLOT_BYTES + m * 1024);
+                    else
+                        pf_issue_piece(nxt, voff[m], (sn - NKC) * 128, ring_w + (sn % NBUF) * PF_SLOT_BYTES + m * 1024);
+                }
+                if constexpr (g == 1 && kc + 1 < NKC) {
+                    pf_wait<4 * (P - 1)>();
+                    f0 = *reinterpret_cast<const pf_f32x4 *>(ring_rd + ((kc + 1) % NBUF) * PF_SLOT_BYTES + frag_off[0][0]);
+                    f1 = *reinterpret_cast<const pf_f32x4 *>(ring_rd + ((kc + 1) % NBUF) * PF_SLOT_BYTES + frag_off[0][1]);
+                }
+                if constexpr (gi + 1 < NKC * 2) a_cur = pf_pack(f0, f1);
+            });
+
+            // ---- filter + append, straight out of the accumulators: register r of query tile t holds
+            // D[row (r&3) + 8 (r>>2) + 4 lh][query 32 t + li]
+            const uint64_t row0 = tile_row0(ti);
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) {
+                const uint32_t q = 32u * t + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float s = acc[t][r];
+                    if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
+                        const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
+                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+                        else *overflow = 1u;
+                    }
+                }
+            }
+            cur = nxt;
+            nxt = tile_srd(ti + 2);
+        }
+    }
+    __syncthreads(); // every wave's appends are counted
+    if (tid < 32 * NQT && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
+// ------------------------------------------------------------------ norms, eps, query staging
+// max over rows of |row| (f32), as the bits of a non-negative float (atomicMax on the bits orders them; a NaN
+// norm has the largest bits and poisons the maximum on purpose: the bound does not hold for such a corpus).
+__global__ __launch_bounds__(256) void pf_row_norm_max_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
+                                                              uint32_t *max_bits) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t nvec = dim >> 2;
+    float best = 0.f;
+    bool bad = false;
+    for (uint64_t r = wave; r < n; r += n_waves) {
+        const float4 *x = reinterpret_cast<const float4 *>(rows + r * dim);
+        float ss = 0.f;
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const float4 a = x[v];
+            ss = fmaf(a.x, a.x, ss); ss = fmaf(a.y, a.y, ss); ss = fmaf(a.z, a.z, ss); ss = fmaf(a.w, a.w, ss);
+        }
+        ss = oi_wave_sum(ss);
+        const float nm = sqrtf(ss);
+        bad = bad || !(nm == nm);
+        best = nm > best ? nm : best;
+    }
+    if (lane == 0) atomicMax(max_bits, bad ? 0x7FC00000u : __float_as_uint(best));
+}
+
+// Per query: bf16 copy (RNE, zero padded to n_padded rows) and the screen's margin 2 eps; a norm that is not
+// finite or too large for the bf16 products to stay finite opens the exact pipeline instead (gate).
+//   state words: eps2[q] (float) at state + q; *gate at gate.
+#define PF_NORM_LIMIT 1.0e15f
+__global__ __launch_bounds__(256) void pf_stage_queries_kernel(const float *__restrict__ q, uint32_t n_queries,
+                                                               uint32_t n_padded, uint32_t dim,
+                                                               const uint32_t *__restrict__ max_norm_bits,
+                                                               uint16_t *__restrict__ out, float *__restrict__ eps2,
+                                                               uint32_t *gate) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t row = wave; row < n_padded; row += n_waves) {
+        float ss = 0.f;
+        for (uint32_t k = lane; k < dim; k += 64) {
+            uint16_t v = 0;
+            if (row < n_queries) {
+                const float f = q[(uint64_t)row * dim + k];
+                ss = fmaf(f, f, ss);
+                const uint32_t u = __float_as_uint(f);
+                v = (u & 0x7F800000u) == 0x7F800000u ? (uint16_t)(u >> 16)                        // inf / NaN: truncate
+                                                     : (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); // RNE
+            }
+            out[(uint64_t)row * dim + k] = v;
+        }
+        if (row < n_queries) {
+            ss = oi_wave_sum(ss);
+            const float qn = sqrtf(ss), mx = __uint_as_float(*max_norm_bits);
+            const bool ok = qn < PF_NORM_LIMIT && mx < PF_NORM_LIMIT; // false for NaN as well
+            if (lane == 0) {
+                // 2 eps, eps = (2^-8 + 2^-12) * max|x| * |q|; 1.001 covers the f32 rounding of the two norms
+                eps2[row] = ok ? 2.0f * (0.00390625f + 0.000244140625f) * 1.001f * mx * qn + 1e-37f : 0.f;
+                if (!ok) *gate = 1u;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact rescoring of the survivors
+// One wave per (query, survivor): s = sum_k x_k q_k in f32 (fma chain per lane, butterfly sum), written as an
+// exact rank key at the same slot of the output pool's carry region.
+__global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict__ rows, uint32_t dim, uint32_t doc_id_base,
+                                                         uint64_t n_rows, const float *__restrict__ queries,
+                                                         const uint64_t *__restrict__ in_pools, const uint32_t *__restrict__ in_cnt,
+                                                         uint64_t in_stride, uint32_t cap, uint64_t *out_pools,
+                                                         uint32_t *out_cnt, uint64_t out_stride) {
+    const uint32_t q = blockIdx.y, lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t c = in_cnt[q];
+    c = c < cap ? c : cap;
+    const uint32_t nvec = dim >> 2;
+    const float4 *qv = reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim);
+    for (uint32_t i = wave; i < c; i += n_waves) {
+        const uint64_t key = in_pools[(uint64_t)q * in_stride + i];
+        const uint32_t doc = oi_rank_key_doc(key);
+        const uint64_t r = (uint64_t)(doc - doc_id_base);
+        float a = 0.f;
+        if (r < n_rows) {
+            const float4 *x = reinterpret_cast<const float4 *>(rows + r * dim);
+            for (uint32_t v = lane; v < nvec; v += 64) {
+                const float4 xv = x[v], yv = qv[v];
+                a = fmaf(xv.x, yv.x, a); a = fmaf(xv.y, yv.y, a); a = fmaf(xv.z, yv.z, a); a = fmaf(xv.w, yv.w, a);
+            }
+        }
+        a = oi_wave_sum(a);
+        if (lane == 0) out_pools[(uint64_t)q * out_stride + i] = oi_rank_key(a, doc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_cnt[q] = c;
+}
+
+// ------------------------------------------------------------------ host
+bool oi_cosine_screen_supported(uint32_t dim) { return dim == 384 || dim == 768; }
+
+// Pool geometry of one chunk: one segment per workgroup; its four waves take 4 tiles per round.
+void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
+    const uint64_t n_tiles = (n_rows + PF_TILE_ROWS - 1) / PF_TILE_ROWS;
+    const uint64_t quads = (n_tiles + 3) / 4;
+    const uint64_t grid = quads < (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (uint64_t)ctx->num_cus;
+    *n_segs = (uint32_t)grid;
+    *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * PF_TILE_ROWS;
+}
+
+int oi_launch_row_norm_max(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint32_t *max_bits) {
+    OI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 4, ctx->stream));
+    if (n == 0) return OI_OK;
+    uint64_t blocks = (n + 3) / 4;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(pf_row_norm_max_kernel, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, n, dim, max_bits);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// bf16 queries (padded to a multiple of 32 rows) + per-query margins + gate, once per search
+int oi_launch_screen_stage(oi_ctx *ctx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                           const uint32_t *max_norm_bits, uint16_t *q_bf16, float *eps2, uint32_t *gate) {
+    const uint32_t n_padded = (n_queries + 31u) & ~31u;
+    hipLaunchKernelGGL(pf_stage_queries_kernel, dim3((n_padded + 3) / 4), dim3(256), 0, ctx->stream, d_queries, n_queries,
+                       n_padded, dim, max_norm_bits, q_bf16, eps2, gate);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+template <int D, int NQT>
+static int launch_screen(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    constexpr int NKC = D / PF_SLOT_K, NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
+    constexpr size_t smem = 4 * NBUF * PF_SLOT_BYTES + 64 * 4;
+    static bool attr = false;
+    if (!attr) {
+        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_screen_filter<D, NQT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL((cosine_screen_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
+                       row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
+                       p.carry_cap, p.seg_cap, p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// All queries of a batch over rows [row_begin, row_end): the bf16 screen.  q_bf16: staged by
+// oi_launch_screen_stage.  One corpus pass per 64 queries.
+int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                                  const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool) {
+    OI_REQUIRE(oi_cosine_screen_supported(dim), "cosine screen: dim %u not instantiated (384, 768)", dim);
+    oi_cosine_screen_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
+    OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
+               "cosine screen: chunk does not fit the candidate pool");
+    if (row_end <= row_begin || n_queries == 0) return OI_OK;
+    ProfScope ps(ctx, "cosine");
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += 64) {
+        const uint32_t nq_here = std::min(64u, n_queries - q0);
+        PoolView p = pool;
+        p.keys += (uint64_t)q0 * pool.stride;
+        p.carry_cnt += q0;
+        p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
+        p.tau_keys += q0;
+        const uint16_t *qptr = q_bf16 + (uint64_t)q0 * dim;
+        const bool two = nq_here > 32;
+        if (dim == 768) {
+            if (two) OI_CHECK((launch_screen<768, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+            else OI_CHECK((launch_screen<768, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+        } else {
+            if (two) OI_CHECK((launch_screen<384, 2>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+            else OI_CHECK((launch_screen<384, 1>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+        }
+    }
+    return OI_OK;
+}
+
+// Exact scores of the screen's survivors: in.carry region (in.carry_cnt keys per query) -> out.carry region.
+int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
+                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out) {
+    if (n_queries == 0) return OI_OK;
+    OI_REQUIRE(out.carry_cap >= in.carry_cap, "rescore: output pool too small");
+    ProfScope ps(ctx, "rescore");
+    hipLaunchKernelGGL(pf_rescore_kernel, dim3(64, n_queries), dim3(256), 0, ctx->stream, rows, dim, doc_id_base, n_rows,
+                       d_queries, in.keys, in.carry_cnt, in.stride, in.carry_cap, out.keys, out.carry_cnt, out.stride);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

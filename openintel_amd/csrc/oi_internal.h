@@ -71,6 +71,10 @@ struct oi_ctx {
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     int prof_enabled = 0; // 0 off, 1 every tagged launch, 2 the cosine scorer only
+    // set by api.hip around the gated exact pipeline that follows a bf16 screen (cosine_prefilter.hip): the exact
+    // cosine kernel and the selects launched meanwhile exit at once unless *run_gate is nonzero
+    const uint32_t *run_gate = nullptr;
+    const uint32_t *last_screen_gate = nullptr; // the gate word of the last screened search (diagnostics)
     std::map<std::string, std::vector<ProfSpan>> prof;
     std::vector<hipEvent_t> event_pool;
 
@@ -103,6 +107,7 @@ struct oi_index {
     bool rows_owned = false;
     uint16_t *rows_bf16 = nullptr; // device; set instead of `rows` for a bf16 corpus
     bool rows_bf16_owned = false;
+    DevBuf max_row_norm; // u32: bits of max_r |row r| (f32), taken when the f32 rows are set; NaN if any norm is
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;
@@ -156,8 +161,17 @@ struct PoolView {
     uint32_t seg_cnt_stride;  // allocated segments per query
     uint32_t *overflow;       // single device word, set nonzero if a segment overflowed (bug guard)
 };
+// Optional behaviour of a select launch (cosine_prefilter.hip): eps2 != null = margin mode (keep every key within
+// eps2[q] of the k-th score; needs compact, no sorted output, carry_cap >= 4096; an overflowing query sets
+// *margin_gate); run_gate != null = the launch exits at once unless *run_gate is nonzero.
+struct SelectExtra {
+    const float *eps2 = nullptr;
+    uint32_t *margin_gate = nullptr;
+    const uint32_t *run_gate = nullptr;
+};
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
-                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride);
+                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride,
+                     const SelectExtra *extra = nullptr);
 // shard s's lists start at scores + s*shard_stride (same for docs) and counts + s*count_stride
 int oi_launch_lists_to_pool(oi_ctx *ctx, const float *scores, const uint32_t *docs,
                             const uint32_t *counts, uint64_t shard_stride, uint64_t count_stride,
@@ -186,6 +200,16 @@ uint32_t oi_cosine_query_padding(uint32_t n_queries);
 // cosine_ksplit.hip
 bool oi_cosine_ksplit_supported(uint32_t dim);
 void oi_cosine_ksplit_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap);
+// cosine_prefilter.hip: the bf16 screen + exact rescoring of an f32 corpus
+bool oi_cosine_screen_supported(uint32_t dim);
+void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap);
+int oi_launch_row_norm_max(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint32_t *max_bits);
+int oi_launch_screen_stage(oi_ctx *ctx, const float *d_queries, uint32_t n_queries, uint32_t dim,
+                           const uint32_t *max_norm_bits, uint16_t *q_bf16, float *eps2, uint32_t *gate);
+int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                                  const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
+int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
+                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out);
 int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                             const float *q, uint32_t nq, bool two_tiles, uint32_t doc_id_base, const PoolView &p);
 // bm25.hip

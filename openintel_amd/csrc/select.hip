@@ -345,10 +345,18 @@ __device__ __forceinline__ void sel_threshold(FE &&for_each, uint32_t kk_in, Sel
 
 // Selects the top min(n, k) keys of K into sel[], returns their number.  KPT > 0: the keys live in registers
 // (n <= KPT * SEL_THREADS); KPT == 0: every pass re-loads them through the flat view.  sh.cnt == 0 on entry.
+//
+// Margin mode (eps2 >= 0; the bf16 screen of cosine_prefilter.hip): the result is not the top k but EVERY key whose
+// score is within eps2 of the k-th largest score -- the set that must survive for the exact top k to be inside
+// it -- left in cand[] (*in_cand = true), at most SEL_CAND keys (more: *margin_overflow = true, the caller opens
+// the exact pipeline), and *margin_tau = the orderable key of (k-th score - eps2), the next chunk's threshold.
 template <int KPT>
 __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k, SelShared &sh, uint64_t *sel,
-                                                    uint64_t *cand) {
+                                                    uint64_t *cand, float eps2, bool *in_cand, uint32_t *margin_tau,
+                                                    bool *margin_overflow) {
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = K.n;
+    *in_cand = false;
+    *margin_overflow = false;
     if (n == 0) return 0;
     const uint32_t kpt = (n + SEL_THREADS - 1) / SEL_THREADS; // keys per thread; wave w owns [w*kpt*64, (w+1)*kpt*64)
     const uint32_t first = wv * kpt * 64 + lane, last = n - 1;
@@ -394,6 +402,7 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
     }
     int shift;
     uint64_t prefix;
+    bool selected = false; // sel[0..k) holds the top k
     if (KPT != 4 && n > SEL_CAND) {
         // ---- cut the pool down with a sampled threshold: one key per thread, spread over the wave's range
         const uint32_t js = lane % kpt, is = first + js * 64;
@@ -438,27 +447,53 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
             };
             if (c == k) { // nothing to select
                 cand_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid, kv); });
-                __syncthreads();
-                return k;
+            } else {
+                sel_threshold(cand_each, k, sh, shift, prefix);
+                cand_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
             }
-            sel_threshold(cand_each, k, sh, shift, prefix);
-            cand_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
             __syncthreads();
-            return sh.cnt < k ? sh.cnt : k;
+            selected = true;
         }
-        // the sample misjudged the pool: exact passes over all of it
+        // else: the sample misjudged the pool -- exact passes over all of it
     }
-    sel_threshold(for_each, k, sh, shift, prefix);
-    // every key whose top bits are >= prefix is selected: exactly k of them (keys are distinct)
-    for_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
+    if (!selected) {
+        sel_threshold(for_each, k, sh, shift, prefix);
+        // every key whose top bits are >= prefix is selected: exactly k of them (keys are distinct)
+        for_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, SEL_MAX, valid && (kv >> shift) >= prefix, kv); });
+        __syncthreads();
+    }
+    const uint32_t m = sh.cnt < k ? sh.cnt : k;
+    if (!(eps2 >= 0.f) || m < k) return m;
+    __syncthreads(); // everyone has read sh.cnt before it is reset below
+    // ---- margin mode: the k-th key is the smallest selected one; keep everything within eps2 of its score
+    unsigned long long lo = ~0ull;
+    for (uint32_t i = tid; i < m; i += SEL_THREADS) lo = sel[i] < lo ? sel[i] : lo;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long v = __shfl_xor(lo, o, OI_WAVE);
+        lo = v < lo ? v : lo;
+    }
+    if (lane == 0 && lo != ~0ull) atomicMin(&sh.min_key, lo);
+    if (tid == 0) sh.cnt = 0;
     __syncthreads();
-    return sh.cnt < k ? sh.cnt : k;
+    const uint32_t t32 = oi_f32_key(oi_key_f32((uint32_t)(sh.min_key >> 32)) - eps2);
+    for_each([&](bool valid, uint64_t kv) { sel_append(cand, &sh.cnt, SEL_CAND, valid && (uint32_t)(kv >> 32) >= t32, kv); });
+    __syncthreads();
+    const uint32_t c = sh.cnt;
+    *in_cand = true;
+    *margin_tau = t32;
+    *margin_overflow = c > SEL_CAND;
+    return c > SEL_CAND ? SEL_CAND : c;
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
     uint64_t *pools, uint32_t *carry_cnt, uint32_t *seg_cnt, uint32_t *tau_keys, uint64_t pool_stride,
     uint32_t carry_cap, uint32_t seg_cap, uint32_t n_segs, uint32_t seg_cnt_stride, uint32_t *overflow,
-    uint32_t k, int compact, float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+    uint32_t k, int compact, float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride,
+    const float *eps2, uint32_t *margin_gate, const uint32_t *run_gate) {
+    // run_gate: this launch belongs to the gated exact pipeline (cosine_prefilter.hip) and only runs when the
+    // screen gave up.  eps2: margin mode (see sel_flat_select); its overflow opens that gate.
+    if (run_gate && *run_gate == 0u) return;
     __shared__ SelShared sh;
     __shared__ uint64_t sel[2 * SEL_MAX];
     __shared__ uint64_t cand[SEL_CAND];
@@ -511,12 +546,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
     K.steps = 0;
     while ((1u << K.steps) < n_segs) ++K.steps;
 
-    uint32_t m;
-    if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand);
-    else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand);
-    else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand);
-    else if (K.n <= SEL_KPT_MAX * SEL_THREADS) m = sel_flat_select<SEL_KPT_MAX>(K, k, sh, sel, cand);
-    else m = sel_flat_select<0>(K, k, sh, sel, cand);
+    uint32_t m, m_tau = 0;
+    bool in_cand = false, m_over = false;
+    const float e2 = eps2 ? eps2[q] : -1.f;
+    if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    else if (K.n <= SEL_KPT_MAX * SEL_THREADS) m = sel_flat_select<SEL_KPT_MAX>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    else m = sel_flat_select<0>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    if (in_cand) { // margin mode: an unsorted superset of the top k in cand[]; only ever compacted
+        if (m_over && tid == 0 && margin_gate) *margin_gate = 1u;
+        for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = cand[i];
+        for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) segc[sg] = 0;
+        if (tid == 0) {
+            carry_cnt[q] = m;
+            if (tau_keys && m_tau > tau_keys[q]) tau_keys[q] = m_tau;
+        }
+        return;
+    }
 
     // Sorted output is needed only for a final list; an intermediate compaction just needs the set
     // and its smallest key (the new threshold).
@@ -548,7 +595,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
         for (uint32_t sg = tid; sg < n_segs; sg += SEL_THREADS) segc[sg] = 0;
         if (tid == 0) {
             carry_cnt[q] = m;
-            if (m == k && tau_keys) { // k docs at or above this score exist: a valid lower bound of the final k-th
+            if (m == k && tau_keys && !eps2) { // k docs at or above this score exist: a valid lower bound of the final
+                // k-th (a margin-mode pool of exactly k keys keeps its threshold: that bound needs the margin)
                 const uint32_t t = (uint32_t)(sh.min_key >> 32);
                 if (t > tau_keys[q]) tau_keys[q] = t;
             }
@@ -557,16 +605,24 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
 }
 
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
-                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride) {
+                     float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride,
+                     const SelectExtra *extra) {
     if (n_queries == 0) return OI_OK;
     OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH && k <= pool.carry_cap, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
     ProfScope ps(ctx, "select");
     static const bool v1 = getenv("OI_SELECT_V1") != nullptr; // A/B switch: the segment-walking kernel
-    if (!v1 && pool.n_segs <= SEL_MAX_SEGS) {
+    const bool special = extra && (extra->eps2 || extra->run_gate);
+    if (special) {
+        OI_REQUIRE(pool.n_segs <= SEL_MAX_SEGS, "select: %u segments (margin / gated selects take <= %u)", pool.n_segs, SEL_MAX_SEGS);
+        OI_REQUIRE(!extra->eps2 || (compact && !out_scores && pool.carry_cap >= SEL_CAND),
+                   "select: margin mode compacts into a carry region of >= %u keys", SEL_CAND);
+    }
+    if ((!v1 || special) && pool.n_segs <= SEL_MAX_SEGS) {
         hipLaunchKernelGGL(select_flat_kernel, dim3(n_queries), dim3(SEL_THREADS), 0, ctx->stream, pool.keys,
                            pool.carry_cnt, pool.seg_cnt, pool.tau_keys, pool.stride, pool.carry_cap, pool.seg_cap,
                            pool.n_segs, pool.seg_cnt_stride, pool.overflow, k, compact ? 1 : 0, out_scores, out_docs,
-                           out_counts, out_stride);
+                           out_counts, out_stride, extra ? extra->eps2 : nullptr, extra ? extra->margin_gate : nullptr,
+                           extra ? extra->run_gate : nullptr);
         OI_HIP_CHECK(hipGetLastError());
         return OI_OK;
     }

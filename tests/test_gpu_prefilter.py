@@ -1,0 +1,260 @@
+"""Screened cosine mode (oi_set_cosine_mode(OI_COSINE_SCREEN), csrc/cosine_prefilter.hip): a bf16 screen with a
+proven error bound chooses the rows that can reach the list, exact f32 scores are computed for those rows only,
+and a query whose survivors do not fit falls back -- inside the same call -- to the exact kernel.  What comes out
+must be the exact scorer's lists: same bar as the exact kernel (1e-5 absolute vs the f64 oracle, COS_TOL), the
+small-integer pipeline bit for bit (that corpus cannot be screened: the fallback is what is tested there), and
+agreement with the exact mode apart from near-ties.  `screen_gate` tells which regime a search ran in."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+COS_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import openintel_amd as oi
+    from openintel_amd import _lib
+    c = oi.HipContext(0)
+    c.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import lib
+    return lib
+
+
+def _gate(ctx):
+    return ctx.profile_read("screen_gate")[0]
+
+
+def _forward(rng, n, vocab=50):
+    lens = rng.integers(1, 9, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    return rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32), offs
+
+
+def _index(ctx, rows, terms, offs, vocab, base=0, normalize=False):
+    import openintel_amd as oi
+    idx = oi.HybridIndex(ctx, rows.shape[0], rows.shape[1], vocab, base)
+    idx.set_embeddings(rows, normalize=normalize)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    return idx
+
+
+def _check(L, b, ref, depth, n, base=0):
+    c = int(L.cos_counts[b])
+    assert c == min(depth, n)
+    d, s = L.cos_docs[b][:c].astype(np.int64) - base, L.cos_scores[b][:c]
+    assert np.unique(d).size == c and d.min() >= 0 and d.max() < n
+    assert ((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (d[:-1] < d[1:]))).all(), "not sorted by (score desc, doc asc)"
+    assert np.abs(s.astype(np.float64) - ref[d]).max() <= COS_TOL
+    kth = np.sort(ref)[::-1][c - 1]
+    assert np.isin(np.nonzero(ref > kth + 2 * COS_TOL)[0], d).all(), "a clearly better doc is missing"
+    assert (ref[d] >= kth - 2 * COS_TOL).all(), "a clearly worse doc is present"
+
+
+@pytest.mark.parametrize("B,dim,n", [(9, 768, 5000), (40, 768, 9000), (64, 768, 60_000), (70, 384, 6000),
+                                     (33, 384, 40_000), (130, 768, 3000), (64, 768, 300_000)])
+def test_screened_lists_meet_the_exact_bar(ctx, O, B, dim, n):
+    from openintel_amd import synth
+    rows = synth.embeddings_np(n, dim, seed=3 + B)
+    q = synth.embeddings_np(B, dim, seed=55 + B)
+    rng = np.random.default_rng(B)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50, base=77)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    for depth in (10, 1000):
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        assert _gate(ctx) == 0.0, "unit vectors: the screen must hold (no fallback)"
+        for b in range(B if n <= 60_000 else 8):
+            _check(L, b, O.dot_scores(rows, q[b]), depth, n, base=77)
+    idx.close()
+
+
+def test_screen_and_exact_modes_agree(ctx, O):
+    from openintel_amd import _lib, synth
+    n, dim, B = 100_000, 768, 64
+    rows = synth.embeddings_np(n, dim, seed=21)
+    q = synth.embeddings_np(B, dim, seed=22)
+    rng = np.random.default_rng(0)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    Ls = idx.search_lists(q, qt, qo, depth=1000)
+    assert _gate(ctx) == 0.0
+    ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
+    Le = idx.search_lists(q, qt, qo, depth=1000)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    assert np.array_equal(Ls.cos_counts, Le.cos_counts)
+    assert np.abs(Ls.cos_scores - Le.cos_scores).max() <= 5e-7    # two f32 summation orders
+    assert (Ls.cos_docs == Le.cos_docs).mean() > 0.999            # order can only differ between near-ties
+    for b in range(B):                                            # and membership only at the k-th boundary
+        odd = np.setxor1d(Ls.cos_docs[b], Le.cos_docs[b])
+        if odd.size:
+            ref = O.dot_scores(rows, q[b])
+            assert np.abs(ref[odd] - np.sort(ref)[::-1][999]).max() <= 1e-6
+    idx.close()
+
+
+@pytest.mark.parametrize("n,dim,B,depth,k", [(70_000, 384, 9, 1000, 100), (40_000, 768, 64, 10, 10),
+                                             (300_000, 384, 33, 100, 50)])
+def test_integer_pipeline_bit_exact(ctx, O, n, dim, B, depth, k):
+    """Small-integer embeddings (exact dot products in any order, thousands of ties, norms far from 1): whichever
+    regime a query lands in, the lists are the oracle's bit for bit, hybrid fusion included."""
+    rng = np.random.default_rng(n + B)
+    rows = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+    q = rng.integers(-3, 4, size=(B, dim)).astype(np.float32)
+    vocab = 300
+    terms, offs = _forward(rng, n, vocab)
+    qt = rng.integers(0, 12, size=B * 4).astype(np.uint32)
+    qo = (np.arange(B + 1) * 4).astype(np.uint32)
+    idx = _index(ctx, rows, terms, offs, vocab, base=1000)
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    R = idx.search(q, qt, qo, k=k, depth=depth)
+    for b in range(B):
+        cs, cd = O.topk(O.dot_scores(rows, q[b]), depth, False, 1000)
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, qt[qo[b]:qo[b + 1]]), depth, True, 1000)
+        fs, fd = O.rrf_fuse(cd, bd, k)
+        assert int(L.cos_counts[b]) == cd.size
+        assert np.array_equal(L.cos_docs[b][:cd.size], cd) and np.array_equal(L.cos_scores[b][:cd.size], cs)
+        assert int(R.counts[b]) == fd.size and np.array_equal(R.docs[b][:fd.size], fd)
+        assert np.array_equal(R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32))
+    idx.close()
+
+
+def test_survivor_overflow_opens_the_exact_pipeline(ctx, O):
+    """6000 exact copies of one row: every copy scores the same, so for a query near that row more keys sit inside
+    the margin than the screen keeps (4096).  The gate must open and the exact kernel's lists come out: the copies
+    in doc-id order first, bit for bit the oracle's ranking."""
+    from openintel_amd import synth
+    rng = np.random.default_rng(3)
+    n, dim, B = 60_000, 768, 16
+    rows = synth.embeddings_np(n, dim, seed=30)
+    copies = rng.choice(n, size=6000, replace=False)
+    rows[copies] = rows[copies[0]]
+    q = synth.embeddings_np(B, dim, seed=31)
+    q[0] = rows[copies[0]]
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    L = idx.search_lists(q, qt, qo, depth=1000)
+    assert _gate(ctx) != 0.0, "6000 tied rows cannot fit the screen's 4096 survivors"
+    ref = O.dot_scores(rows, q[0])
+    d = L.cos_docs[0][:1000].astype(np.int64)
+    assert np.array_equal(d, np.sort(copies)[:1000])                 # ties rank by doc id
+    assert np.abs(L.cos_scores[0][:1000] - ref[d]).max() <= COS_TOL
+    for b in range(1, B):
+        _check(L, b, O.dot_scores(rows, q[b]), 1000, n)
+    L = idx.search_lists(q[1:], qt[1:], qo[:-1], depth=1000)          # without that query the screen holds again
+    assert _gate(ctx) == 0.0
+    for b in range(B - 1):
+        _check(L, b, O.dot_scores(rows, q[b + 1]), 1000, n)
+    idx.close()
+
+
+def test_hard_cases_for_the_bound(ctx, O):
+    """Rows of very different norms (the bound uses the LARGEST), near-duplicates of the best rows (many keys inside
+    the margin), a zero row, unnormalised queries, and a NaN in the corpus (no bound: the gate must open)."""
+    from openintel_amd import synth
+    rng = np.random.default_rng(5)
+    n, dim, B = 50_000, 768, 40
+    rows = synth.embeddings_np(n, dim, seed=8)
+    rows[100:200] *= 3.0                                   # a hundred long rows: they own the top of every list
+    rows[300] = 0.0
+    q = synth.embeddings_np(B, dim, seed=9) * rng.uniform(0.1, 20.0, size=(B, 1)).astype(np.float32)
+    best = int(np.argmax(rows @ q[0]))
+    rows[1000:1400] = rows[best] * (1.0 + 1e-4 * rng.standard_normal((400, 1))).astype(np.float32)   # near-duplicates
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    for depth in (10, 500):
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        for b in range(B):
+            ref = O.dot_scores(rows, q[b])
+            c = int(L.cos_counts[b])
+            d, s = L.cos_docs[b][:c].astype(np.int64), L.cos_scores[b][:c]
+            tol = COS_TOL * max(1.0, float(np.abs(ref).max()))   # scores here reach ~60: the bar scales with them
+            assert c == depth and np.unique(d).size == c and (np.diff(s) <= 0).all()
+            assert np.abs(s.astype(np.float64) - ref[d]).max() <= tol
+            kth = np.sort(ref)[::-1][c - 1]
+            assert np.isin(np.nonzero(ref > kth + 2 * tol)[0], d).all() and (ref[d] >= kth - 2 * tol).all()
+    idx.close()
+    rows[7, 3] = np.nan
+    idx = _index(ctx, rows, terms, offs, 50)
+    L = idx.search_lists(q, qt, qo, depth=10)
+    assert _gate(ctx) != 0.0, "a NaN norm leaves no bound: the exact kernel must take over"
+    ref = O.dot_scores(np.delete(rows, 7, axis=0), q[0])
+    assert int(L.cos_counts[0]) == 10 and 7 not in L.cos_docs[0][:10]   # the exact scorer drops NaN scores
+    assert abs(float(L.cos_scores[0][0]) - float(ref.max())) <= COS_TOL * max(1.0, float(np.abs(ref).max()))
+    idx.close()
+
+
+def test_unsupported_shapes_use_the_exact_kernels(ctx, O):
+    from openintel_amd import synth
+    rng = np.random.default_rng(1)
+    for n, dim, B in ((3000, 1024, 12), (5000, 128, 20), (4000, 768, 3)):
+        rows = synth.embeddings_np(n, dim, seed=2)
+        q = synth.embeddings_np(B, dim, seed=4)
+        terms, offs = _forward(rng, n)
+        idx = _index(ctx, rows, terms, offs, 50)
+        L = idx.search_lists(q, np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32), depth=50)
+        for b in range(B):
+            _check(L, b, O.dot_scores(rows, q[b]), 50, n)
+        idx.close()
+
+
+def test_full_size_screened_10M_768_batch64(ctx):
+    """BASELINE configs[2] in screen mode: size-independent properties at full size -- planted copies of the
+    queries come back first with score ~1, full sorted lists, the exact mode's lists on the same index (apart
+    from near-ties), idempotence, and three queries checked against dense torch scores."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib, synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k = 10_000_000, 768, 64, 1000, 100
+    rows = synth.embeddings_torch(n, dim, dev)
+    qv, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=4096)
+    plant = torch.arange(B, device=dev) * (n // B) + 17
+    rows[plant] = qv
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    idx = oi.HybridIndex(ctx, n, dim, 4096)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    del terms, offs
+    L = idx.search_lists(qv, qt, qo, depth=depth)
+    ctx.synchronize()
+    assert _gate(ctx) == 0.0
+    cs, cd, cc = L.cos_scores.cpu().numpy(), L.cos_docs.cpu().numpy(), L.cos_counts.cpu().numpy()
+    assert (cc == depth).all() and cd.min() >= 0 and cd.max() < n
+    assert np.array_equal(cd[:, 0], plant.cpu().numpy()) and np.abs(cs[:, 0] - 1.0).max() < 1e-5
+    assert (np.diff(cs, axis=1) <= 0).all()
+    R1 = idx.search(qv, qt, qo, k=k, depth=depth)
+    R2 = idx.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    assert torch.equal(R1.docs, R2.docs) and torch.equal(R1.scores, R2.scores)
+    ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
+    Le = idx.search_lists(qv, qt, qo, depth=depth)
+    Re = idx.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    es, ed = Le.cos_scores.cpu().numpy(), Le.cos_docs.cpu().numpy()
+    # same score at every rank (two f32 summation orders), same doc except where neighbours are closer than that
+    assert np.abs(cs - es).max() <= 5e-7 and (cd == ed).mean() > 0.995
+    assert all(np.setxor1d(cd[b], ed[b]).size <= 4 for b in range(B))
+    assert (R1.docs == Re.docs).float().mean().item() > 0.98
+    for b in range(3):
+        full = (rows @ qv[b]).cpu().numpy().astype(np.float64)
+        _check(L_np(cs, cd, cc), b, full, depth, n)
+    idx.close()
+
+
+class L_np:
+    def __init__(self, s, d, c):
+        self.cos_scores, self.cos_docs, self.cos_counts = s, d, c
