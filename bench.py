@@ -66,9 +66,10 @@ def main():
     ap.add_argument("--bm25", choices=["taat", "scan"], default="taat", help="BM25 kernel (default: term-at-a-time)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
-    ap.add_argument("--cosine", choices=["exact", "split", "screen"], default="exact",
-                    help="f32 corpus scorer: exact f32 MFMA (default), split-precision products (six bf16 MFMAs), or a "
-                         "bf16 screen with a proven bound + exact f32 rescoring of the survivors (same lists, HBM-bound)")
+    ap.add_argument("--cosine", choices=["screen", "exact", "split"], default="screen",
+                    help="f32 corpus scorer: a bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
+                         "(default: the exact scorer's lists, HBM-bound), exact f32 MFMA for every row, or split-precision "
+                         "products (six bf16 MFMAs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -104,9 +105,9 @@ def main():
 
     ctx = oi.HipContext(local_rank)
     ctx.use_torch_current_stream()
-    if args.cosine != "exact":
-        from openintel_amd import _lib as _oil
-        ctx.set_cosine_mode(_oil.OI_COSINE_SPLIT if args.cosine == "split" else _oil.OI_COSINE_SCREEN)
+    from openintel_amd import _lib as _oil
+    MODES = {"screen": _oil.OI_COSINE_SCREEN, "exact": _oil.OI_COSINE_EXACT, "split": _oil.OI_COSINE_SPLIT}
+    ctx.set_cosine_mode(MODES[args.cosine])
 
     # ---------------------------------------------------------------- corpus shard in HBM
     lo, hi = sharded.shard_bounds(args.docs, world, rank)
@@ -182,6 +183,31 @@ def main():
     ctx.profile_reset(False)
     ctx.set_overlap(True)
 
+    # The default scorer screens in bf16 and rescores exactly; the same batch through the exact f32 MFMA kernel for
+    # every row is measured beside it (untimed steps), so that the line carries both scorers.
+    exact_side = None
+    if args.cosine == "screen" and args.corpus == "f32" and args.batch > 8:
+        gate_opened = ctx.profile_read("screen_gate")[0]
+        ctx.set_cosine_mode(MODES["exact"])
+        step()
+        fence()
+        ex_steps = max(1, min(5, args.steps))
+        ctx.profile_reset(2)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(ex_steps):
+            step()
+        fence()
+        ex_elapsed = time.perf_counter() - t1
+        ex_ms, ex_launches = ctx.profile_read("cosine")
+        ctx.profile_reset(False)
+        ctx.set_cosine_mode(MODES["screen"])
+        exact_side = {"ms_per_step": ex_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / ex_elapsed,
+                      "cosine_avg_launch_ms": ex_ms / max(1, ex_launches), "steps": ex_steps,
+                      "mfma_frac": 2.0 * n_local * args.dim * args.batch * ex_steps / (ex_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                      "note": "same batch, oi_set_cosine_mode(OI_COSINE_EXACT): f32 MFMA for every row (rank 0's clock, untimed steps)"}
+        screen_fallback = gate_opened != 0.0
+
     # per-batch latency (p50/p95), measured separately with a host sync after every batch
     lat = []
     for _ in range(max(10, min(args.steps, 50))):
@@ -205,8 +231,10 @@ def main():
         if args.corpus == "bf16":  # 2 B per element, one corpus pass per 64 queries (32 at d = 1024)
             group = 32 if args.dim == 1024 else 64
             bytes_step = 2.0 * n_local * args.dim * ((args.batch + group - 1) // group)
+        if args.corpus == "f32" and args.cosine == "screen":  # the screen reads the corpus once per 64 queries
+            bytes_step *= (args.batch + 63) // 64
         cos_s = cos_ms / 1e3
-        if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact":
+        if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}
         else:
@@ -218,10 +246,14 @@ def main():
         # the committed PMC pass was taken on the default workload at N=1 only
         if os.path.exists(pmc) and (args.docs, args.dim, args.batch, world, args.corpus) == (10_000_000, 768, 64, 1, "f32"):
             try:
-                roof["traffic"] = json.load(open(pmc)).get("cosine_hbm_bytes_per_launch")
+                pm = json.load(open(pmc))   # the screen kernel's counters; the exact kernel's under "exact_kernel"
+                roof["traffic"] = (pm if args.cosine == "screen" else pm.get("exact_kernel", {}) if args.cosine == "exact"
+                                   else {}).get("cosine_hbm_bytes_per_launch")
             except Exception:
                 pass
         roof["kernel"] = "cosine scorer (all corpus-chunk launches of a batch)"
+        if args.cosine == "screen" and roof["bound"] == "hbm" and args.batch > 8:
+            roof["kernel"] = "cosine screen (bf16 MFMA over the f32 corpus, all corpus-chunk launches of a batch)"
         roof["launches_per_step"] = cos_launches / max(1, args.steps)
         roof["avg_launch_ms"] = cos_ms / max(1, cos_launches)
         roof["kernel_ms_per_step"] = cos_ms / max(1, args.steps)
@@ -236,9 +268,7 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": args.corpus if args.cosine == "exact" else
-                     "f32 (bf16x3 split products, f32 accumulate)" if args.cosine == "split" else
-                     "f32 (scores: exact f32 dot products; rows are chosen by a bf16 screen with a proven error bound)",
+            "dtype": "f32 (bf16x3 split products, f32 accumulate)" if args.cosine == "split" else args.corpus,
             "data": "synthetic",
             "config": {"workload": "%s: %d posts x %d-d %s, batch %d queries x 4 BM25 terms, "
                                    "per-list depth %d, RRF top-%d; corpus row-sharded over %d GPU(s)" % (
@@ -248,6 +278,10 @@ def main():
                                        args.docs, args.dim, args.corpus, args.batch, args.depth, args.k, world),
                        "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
                        "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
+                       "cosine_scorer": {"screen": "bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
+                                                   "(the exact scorer's lists; gated exact fallback)",
+                                         "exact": "f32 MFMA for every row", "split": "bf16x3 split products"}[args.cosine]
+                                        if args.corpus == "f32" and args.batch > 8 else "exact",
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world},
             "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
             "roofline": roof,
@@ -255,6 +289,9 @@ def main():
                                               note="from the %d serialised steps, not the timed region" % iso_steps),
             "build_s": t_build,
         }
+        if exact_side is not None:
+            line["exact_scorer"] = exact_side
+            line["screen_fell_back_to_exact"] = screen_fallback
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)

@@ -77,20 +77,19 @@ void oi_destroy(oi_ctx *ctx);
 int oi_set_stream(oi_ctx *ctx, void *hip_stream);
 int oi_synchronize(oi_ctx *ctx);
 
-/* How the batch cosine scorer multiplies over an f32 corpus (dim 384 / 768, more than 8 queries; other
- * shapes always use the exact kernel):
- *   OI_COSINE_EXACT (default)  v_mfma_f32_* on the f32 values: matrix-pipe-bound.
- *   OI_COSINE_SPLIT            every f32 operand is split exactly into three bf16 values and the dot product
- *                              taken as six bf16 MFMAs with f32 accumulation (the three smallest of the nine
- *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
- *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7) at
- *                              3/8 of the matrix-pipe time, so the scorer becomes HBM-bound.
- *   OI_COSINE_SCREEN           a bf16 screen with a proven error bound picks the rows that can reach the list
+/* How the batch cosine scorer works over an f32 corpus (dim 384 / 768, more than 8 queries; other shapes
+ * always use the exact kernels).  The corpus stays f32 in HBM in every mode.
+ *   OI_COSINE_SCREEN (default) a bf16 screen with a proven error bound picks the rows that can reach the list
  *                              (one bf16 MFMA per product, rows converted on the fly: HBM-bound), exact f32
  *                              scores are then computed for those rows only; a query whose survivors do not fit
  *                              falls back, inside the same call, to the exact kernel.  The lists are the exact
  *                              scorer's (csrc/cosine_prefilter.hip has the argument).
- * The corpus stays f32 in HBM either way.  Also selectable with OI_COSINE_MODE=split|screen at oi_create. */
+ *   OI_COSINE_EXACT            v_mfma_f32_* on the f32 values for every row: matrix-pipe-bound.
+ *   OI_COSINE_SPLIT            every f32 operand is split exactly into three bf16 values and the dot product
+ *                              taken as six bf16 MFMAs with f32 accumulation (the three smallest of the nine
+ *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
+ *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7).
+ * Also selectable with OI_COSINE_MODE=screen|exact|split at oi_create. */
 #define OI_COSINE_EXACT 0
 #define OI_COSINE_SPLIT 1
 #define OI_COSINE_SCREEN 2

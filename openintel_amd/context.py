@@ -32,7 +32,8 @@ class HipContext:
         _lib.check(self.lib.oi_synchronize(self.handle))
 
     def set_cosine_mode(self, mode: int) -> None:
-        """_lib.OI_COSINE_EXACT (default) or _lib.OI_COSINE_SPLIT (six bf16 MFMAs per f32 product, HBM-bound)."""
+        """_lib.OI_COSINE_SCREEN (default: bf16 screen with a proven bound + exact f32 rescoring, HBM-bound),
+        _lib.OI_COSINE_EXACT (f32 MFMA for every row) or _lib.OI_COSINE_SPLIT (six bf16 MFMAs per f32 product)."""
         _lib.check(self.lib.oi_set_cosine_mode(self.handle, int(mode)))
 
     def set_overlap(self, enable: bool) -> None:

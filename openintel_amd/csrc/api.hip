@@ -116,7 +116,7 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->stream = nullptr;
     if (const char *m = getenv("OI_COSINE_MODE"))
-        c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "screen") == 0 ? OI_COSINE_SCREEN : OI_COSINE_EXACT;
+        c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "exact") == 0 ? OI_COSINE_EXACT : OI_COSINE_SCREEN;
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;

@@ -67,7 +67,7 @@ struct oi_ctx {
     hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_legs = true;              // oi_set_overlap
-    int cosine_mode = 0;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products
+    int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default)
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     int prof_enabled = 0; // 0 off, 1 every tagged launch, 2 the cosine scorer only

@@ -18,8 +18,10 @@ COS_TOL = 1e-5
 @pytest.fixture(scope="module")
 def ctx():
     import openintel_amd as oi
+    from openintel_amd import _lib
     c = oi.HipContext(0)
-    yield c
+    c.set_cosine_mode(_lib.OI_COSINE_EXACT)   # this module pins the exact kernels; the default (screen + exact
+    yield c                                   # rescoring) has the same bars in tests/test_gpu_prefilter.py
     c.close()
 
 

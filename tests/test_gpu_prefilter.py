@@ -195,6 +195,24 @@ def test_hard_cases_for_the_bound(ctx, O):
     idx.close()
 
 
+def test_screen_is_the_default_mode(O):
+    import openintel_amd as oi
+    from openintel_amd import synth
+    c = oi.HipContext(0)                       # no oi_set_cosine_mode
+    assert c.profile_read("screen_gate")[0] == -1.0
+    rng = np.random.default_rng(2)
+    n, dim, B = 20_000, 384, 12
+    rows, q = synth.embeddings_np(n, dim, seed=5), synth.embeddings_np(B, dim, seed=6)
+    terms, offs = _forward(rng, n)
+    idx = _index(c, rows, terms, offs, 50)
+    L = idx.search_lists(q, np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32), depth=100)
+    assert c.profile_read("screen_gate")[0] == 0.0
+    for b in range(B):
+        _check(L, b, O.dot_scores(rows, q[b]), 100, n)
+    idx.close()
+    c.close()
+
+
 def test_unsupported_shapes_use_the_exact_kernels(ctx, O):
     from openintel_amd import synth
     rng = np.random.default_rng(1)
