@@ -358,6 +358,11 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     OI_CHECK(idx->max_row_norm.ensure(16));
     OI_CHECK(oi_launch_row_norm_max(ctx, idx->rows, idx->n_docs, idx->dim, idx->max_row_norm.as<uint32_t>()));
     OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    {   // a corpus whose largest norm is not finite, or so large that bf16 products could overflow, is never screened
+        float mx = 0.f;
+        OI_HIP_CHECK(hipMemcpy(&mx, idx->max_row_norm.p, 4, hipMemcpyDeviceToHost));
+        idx->screen_ok = mx < 1.0e15f; // false for NaN
+    }
     return OI_OK;
 }
 
@@ -641,17 +646,22 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             if (max_chunk == 0) { oi_set_error("search: cosine pool too small"); return OI_ERR_STATE; }
             // the exact pipeline; with a gate it is the fallback behind the bf16 screen and every launch exits at
             // once unless the screen opened the gate
-            auto exact_pipeline = [&](const uint32_t *gate) -> int {
+            // With a gate and the screen's thresholds it is the fallback behind the bf16 screen: tau~ - 2 eps is a valid
+            // lower bound of the exact k'-th score even when the survivors did not fit, so the exact kernel takes all
+            // rows in ONE launch (as many as the pool holds) -- two launches that exit at once when the gate is shut.
+            auto exact_pipeline = [&](const uint32_t *gate, uint32_t *screen_tau) -> int {
                 SelectExtra ex;
                 ex.run_gate = gate;
-                uint64_t chunk = oi_first_chunk_rows(depth);
+                PoolView X = P.cos;
+                if (screen_tau) X.tau_keys = screen_tau;
+                uint64_t chunk = gate ? max_chunk : oi_first_chunk_rows(depth);
                 uint64_t r = 0;
                 while (r < n) {
                     if (chunk > max_chunk) chunk = max_chunk;
                     const uint64_t e = std::min(n, r + chunk);
-                    OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, P.cos));
+                    OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, X));
                     const bool last = e == n;
-                    OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
+                    OI_CHECK(oi_launch_select(ctx, X, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
                                               last ? cos_d : nullptr, last ? cos_c : nullptr, depth, gate ? &ex : nullptr));
                     r = e;
                     chunk *= oi_chunk_growth(B);
@@ -661,8 +671,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             static const bool shape16 = !(getenv("OI_KS_SHAPE") && atoi(getenv("OI_KS_SHAPE")) == 32);
             static const bool cos_v1 = getenv("OI_COSINE_V1") != nullptr || getenv("OI_SELECT_V1") != nullptr;
             const bool screen = ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && oi_cosine_screen_supported(idx->dim) &&
-                                idx->max_row_norm.p && shape16 && !cos_v1;
-            if (!screen) return exact_pipeline(nullptr);
+                                idx->screen_ok && shape16 && !cos_v1;
+            if (!screen) return exact_pipeline(nullptr, nullptr);
 
             // ---- bf16 screen -> margin selects -> exact rescoring -> sorted selection; then the gated exact pipeline
             // (cosine_prefilter.hip).  Its pool keeps up to 4096 keys per query between chunks.
@@ -710,7 +720,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             OI_CHECK(oi_launch_select(ctx, RS, B, depth, false, cos_s, cos_d, cos_c, depth));
             ctx->run_gate = gate;
             ctx->last_screen_gate = gate;
-            const int rc = exact_pipeline(gate);
+            const int rc = exact_pipeline(gate, pf_tau);
             ctx->run_gate = nullptr;
             return rc;
         }

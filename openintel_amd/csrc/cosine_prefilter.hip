@@ -21,8 +21,11 @@
 //   4. rescore: exact f32 dot products of the survivors only (one wave per (query, row); ~150K rows per batch
 //      instead of 640M), then the ordinary sorted top-k' selection over exact keys.
 //   5. if a query's survivors do not fit (4096 keys: rows within 2 eps of the threshold -- duplicates, or norms
-//      far above the typical row's) or a norm is not finite, a device flag opens the GATED exact pipeline that
-//      follows in the same stream and overwrites the lists; otherwise those launches exit at once.
+//      far above the typical row's) or its norm is not finite, a device flag opens the GATED exact launches that
+//      follow in the same stream and overwrite the lists: the exact kernel over all rows with the screen's
+//      thresholds (still valid lower bounds of the exact k'-th scores), then one selection; with the gate shut
+//      both exit at once.  A corpus whose largest norm is not finite is never screened (decided on the host
+//      when the rows are set).
 // The lists that come out are those of the exact scorer (up to the f32 rounding of two different summation
 // orders, which the parity tolerance already covers); tests/test_gpu_prefilter.py checks both regimes.
 //
@@ -294,8 +297,10 @@ __global__ __launch_bounds__(256) void pf_stage_queries_kernel(const float *__re
             const float qn = sqrtf(ss), mx = __uint_as_float(*max_norm_bits);
             const bool ok = qn < PF_NORM_LIMIT && mx < PF_NORM_LIMIT; // false for NaN as well
             if (lane == 0) {
-                // 2 eps, eps = (2^-8 + 2^-12) * max|x| * |q|; 1.001 covers the f32 rounding of the two norms
-                eps2[row] = ok ? 2.0f * (0.00390625f + 0.000244140625f) * 1.001f * mx * qn + 1e-37f : 0.f;
+                // 2 eps, eps = (2^-8 + 2^-12) * max|x| * |q|; 1.001 covers the f32 rounding of the two norms.
+                // A query without a bound gets an infinite margin: its threshold never rises, every key stays
+                // inside the margin, the survivors overflow and the exact kernel scores it against every row.
+                eps2[row] = ok ? 2.0f * (0.00390625f + 0.000244140625f) * 1.001f * mx * qn + 1e-37f : __builtin_inff();
                 if (!ok) *gate = 1u;
             }
         }

@@ -108,6 +108,7 @@ struct oi_index {
     uint16_t *rows_bf16 = nullptr; // device; set instead of `rows` for a bf16 corpus
     bool rows_bf16_owned = false;
     DevBuf max_row_norm; // u32: bits of max_r |row r| (f32), taken when the f32 rows are set; NaN if any norm is
+    bool screen_ok = false; // that maximum is finite and < 1e15: the bf16 screen's bound holds for this corpus
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;

@@ -476,7 +476,8 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
     if (lane == 0 && lo != ~0ull) atomicMin(&sh.min_key, lo);
     if (tid == 0) sh.cnt = 0;
     __syncthreads();
-    const uint32_t t32 = oi_f32_key(oi_key_f32((uint32_t)(sh.min_key >> 32)) - eps2);
+    // an infinite margin (a query without a bound, cosine_prefilter.hip) keeps everything and never raises the threshold
+    const uint32_t t32 = eps2 < __builtin_inff() ? oi_f32_key(oi_key_f32((uint32_t)(sh.min_key >> 32)) - eps2) : 0u;
     for_each([&](bool valid, uint64_t kv) { sel_append(cand, &sh.cnt, SEL_CAND, valid && (uint32_t)(kv >> 32) >= t32, kv); });
     __syncthreads();
     const uint32_t c = sh.cnt;

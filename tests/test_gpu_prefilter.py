@@ -184,11 +184,26 @@ def test_hard_cases_for_the_bound(ctx, O):
             assert np.abs(s.astype(np.float64) - ref[d]).max() <= tol
             kth = np.sort(ref)[::-1][c - 1]
             assert np.isin(np.nonzero(ref > kth + 2 * tol)[0], d).all() and (ref[d] >= kth - 2 * tol).all()
+    # a query without a bound (NaN / infinite / huge norm): that query is scored by the exact kernel against every
+    # row (the others keep their screened thresholds), the gate says so, and the lists are the exact mode's
+    from openintel_amd import _lib
+    q2 = q.copy()
+    q2[3, 5] = np.nan
+    q2[4] *= np.float32(1e20)
+    L = idx.search_lists(q2, qt, qo, depth=100)
+    assert _gate(ctx) != 0.0
+    ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
+    Le = idx.search_lists(q2, qt, qo, depth=100)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    assert np.array_equal(L.cos_counts, Le.cos_counts) and int(L.cos_counts[3]) == 0 and int(L.cos_counts[4]) == 100
+    assert np.array_equal(L.cos_docs, Le.cos_docs) and np.array_equal(L.cos_scores, Le.cos_scores)
     idx.close()
+    # a NaN in the corpus: no bound for any query -- such an index is never screened (decided when the rows are set)
     rows[7, 3] = np.nan
     idx = _index(ctx, rows, terms, offs, 50)
+    g0 = _gate(ctx)
     L = idx.search_lists(q, qt, qo, depth=10)
-    assert _gate(ctx) != 0.0, "a NaN norm leaves no bound: the exact kernel must take over"
+    assert _gate(ctx) == g0, "the screen must not have run"
     ref = O.dot_scores(np.delete(rows, 7, axis=0), q[0])
     assert int(L.cos_counts[0]) == 10 and 7 not in L.cos_docs[0][:10]   # the exact scorer drops NaN scores
     assert abs(float(L.cos_scores[0][0]) - float(ref.max())) <= COS_TOL * max(1.0, float(np.abs(ref).max()))
