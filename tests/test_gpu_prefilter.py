@@ -228,6 +228,53 @@ def test_screen_is_the_default_mode(O):
     c.close()
 
 
+def test_two_screened_shards_equal_one(ctx, O):
+    """Row-sharding under the screen: each shard bounds with ITS largest norm and returns exact scores of its own
+    rows; merged, the two shards' lists are the unsharded index's bit for bit (same rescoring arithmetic per row),
+    and the packed exchange path fuses to the same answer."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k = 300_000, 384, 24, 200, 50
+    rows = synth.embeddings_torch(n, dim, dev)
+    qv, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=4096)
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    one = oi.HybridIndex(ctx, n, dim, 4096)
+    one.set_embeddings(rows, normalize=False)
+    one.set_forward(terms, offs)
+    one.finalize()
+    L1 = one.search_lists(qv, qt, qo, depth=depth)
+    R1 = one.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    assert _gate(ctx) == 0.0
+    half = 140_000
+    shards, lists, tot, dfs = [], [], 0, []
+    for lo, hi in ((0, half), (half, n)):
+        t_lo, t_hi = int(offs[lo]), int(offs[hi])
+        ix = oi.HybridIndex(ctx, hi - lo, dim, 4096, doc_id_base=lo)
+        ix.set_embeddings(rows[lo:hi], normalize=False)
+        ix.set_forward(terms[t_lo:t_hi].contiguous(), (offs[lo:hi + 1] - offs[lo]).contiguous())
+        t, df = ix.local_stats()
+        tot += t; dfs.append(df); shards.append(ix)
+    gdf = (dfs[0].astype(np.uint64) + dfs[1]).astype(np.uint32)
+    for ix in shards:
+        ix.finalize(n, tot, gdf)
+        lists.append(ix.search_lists(qv, qt, qo, depth=depth))
+        assert _gate(ctx) == 0.0
+    ctx.synchronize()
+    st = lambda f: torch.stack([getattr(l, f) for l in lists])
+    ms, md, mc = oi.merge_lists(ctx, st("cos_scores"), st("cos_docs"), st("cos_counts"))
+    ctx.synchronize()
+    assert torch.equal(md, L1.cos_docs) and torch.equal(ms, L1.cos_scores) and torch.equal(mc, L1.cos_counts)
+    packed = torch.cat([ix.search_lists_packed(qv, qt, qo, depth=depth) for ix in shards])
+    Rp = oi.fuse_packed(ctx, packed, 2, B, depth, k)
+    ctx.synchronize()
+    assert torch.equal(Rp.docs, R1.docs) and torch.equal(Rp.scores, R1.scores) and torch.equal(Rp.counts, R1.counts)
+    for ix in shards + [one]:
+        ix.close()
+
+
 def test_unsupported_shapes_use_the_exact_kernels(ctx, O):
     from openintel_amd import synth
     rng = np.random.default_rng(1)
