@@ -80,7 +80,8 @@ int oi_synchronize(oi_ctx *ctx);
 /* How the batch cosine scorer works over an f32 corpus (dim 384 / 768, more than 8 queries; other shapes
  * always use the exact kernels).  The corpus stays f32 in HBM in every mode.
  *   OI_COSINE_SCREEN (default) a bf16 screen with a proven error bound picks the rows that can reach the list
- *                              (one bf16 MFMA per product, rows converted on the fly: HBM-bound), exact f32
+ *                              (one bf16 MFMA per product, rows converted on the fly: HBM-bound; the bound is
+ *                              built from the MEASURED rounding errors of the corpus and of each query), exact f32
  *                              scores are then computed for those rows only; a query whose survivors do not fit
  *                              falls back, inside the same call, to the exact kernel.  The lists are the exact
  *                              scorer's (csrc/cosine_prefilter.hip has the argument).
@@ -262,6 +263,16 @@ int oi_rrf_fuse(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a,
 int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_terms,
               const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
               int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+
+/* Diagnostics of the OI_COSINE_SCREEN mode (tests/test_gpu_prefilter.py; not on the query path).  For host
+ * queries [n_queries][dim] against rows [row_begin, row_begin + n_rows) of an f32 index:
+ *   screen_scores_out[q * n_rows + r]  the screen's raw score s~ (bf16 operands, the screen's own conversion and
+ *                                      matrix instruction);  NULL = skip
+ *   eps_out[q]                         the proven bound of that query: |s~ - s| <= eps for EVERY row of the index
+ *                                      (infinite when the query has no bound and takes the exact kernel)
+ * Both outputs are host buffers; the call is synchronous. */
+int oi_screen_probe(oi_index *idx, const float *query_vecs, uint32_t n_queries, uint64_t row_begin,
+                    uint32_t n_rows, float *screen_scores_out, float *eps_out);
 
 /* Timing hooks for bench.py: when enabled, HIP events are recorded on the ctx stream
  * around every kernel launch, grouped by tag ("cosine", "bm25", "select", "rrf",

@@ -80,6 +80,7 @@ SIGNATURES = {
     "oi_merge_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_rrf_fuse": (_I, [_P, _P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_search": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
+    "oi_screen_probe": (_I, [_P, _P, _U32, _U64, _U32, _P, _P]),
     "oi_profile_reset": (_I, [_P, _I]),
     "oi_profile_read": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_U64)]),
 }

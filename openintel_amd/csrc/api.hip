@@ -354,14 +354,15 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
         OI_HIP_CHECK(hipMemcpyAsync(idx->rows, rows, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     if (normalize) OI_CHECK(oi_launch_l2_normalize(ctx, idx->rows, idx->n_docs, idx->dim));
-    // the bf16 screen's error bound needs max |row| (cosine_prefilter.hip): one more pass over the rows, now
+    // the bf16 screen's error bound needs max |row| and max |bf16(row) - row| (cosine_prefilter.hip): one more pass
+    // over the rows, now
     OI_CHECK(idx->max_row_norm.ensure(16));
     OI_CHECK(oi_launch_row_norm_max(ctx, idx->rows, idx->n_docs, idx->dim, idx->max_row_norm.as<uint32_t>()));
     OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     {   // a corpus whose largest norm is not finite, or so large that bf16 products could overflow, is never screened
-        float mx = 0.f;
-        OI_HIP_CHECK(hipMemcpy(&mx, idx->max_row_norm.p, 4, hipMemcpyDeviceToHost));
-        idx->screen_ok = mx < 1.0e15f; // false for NaN
+        float mx[2] = {0.f, 0.f}; // X = max |row|, E = max |bf16(row) - row|
+        OI_HIP_CHECK(hipMemcpy(mx, idx->max_row_norm.p, 8, hipMemcpyDeviceToHost));
+        idx->screen_ok = mx[0] < 1.0e15f && mx[1] < 1.0e15f; // false for NaN
     }
     return OI_OK;
 }
@@ -916,6 +917,41 @@ extern "C" int oi_search(oi_index *idx, const float *qv, const uint32_t *qt, con
     OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));
     return check_overflow_locked(ctx);
+}
+
+// ---------------------------------------------------------------- diagnostics of the bf16 screen
+extern "C" int oi_screen_probe(oi_index *idx, const float *query_vecs, uint32_t B, uint64_t row_begin, uint32_t n_rows,
+                               float *screen_scores_out, float *eps_out) {
+    if (!idx || !query_vecs) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(B >= 1 && B <= 4096, "screen probe: n_queries=%u outside [1,4096]", B);
+    OI_REQUIRE(idx->rows, "screen probe: the index holds no f32 rows");
+    OI_REQUIRE(idx->dim % 16 == 0, "screen probe: dim %u is not a multiple of 16", idx->dim);
+    OI_REQUIRE(row_begin <= idx->n_docs && n_rows <= idx->n_docs - row_begin && n_rows <= (1u << 20),
+               "screen probe: rows [%llu, +%u) outside the index (or more than 2^20)", (unsigned long long)row_begin, n_rows);
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n_padded = (B + 31u) & ~31u;
+    DevBuf &qf = ctx->buf("probe_q"), &qb = ctx->buf("probe_q_bf16"), &ws = ctx->buf("probe_state"), &out = ctx->buf("probe_out");
+    OI_CHECK(qf.ensure(sizeof(float) * (size_t)B * idx->dim));
+    OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 64) * idx->dim));
+    OI_CHECK(ws.ensure(sizeof(float) * (size_t)B + 16));
+    OI_CHECK(out.ensure(sizeof(float) * ((size_t)B * n_rows + 1)));
+    OI_HIP_CHECK(hipMemcpyAsync(qf.p, query_vecs, sizeof(float) * (size_t)B * idx->dim, hipMemcpyHostToDevice, st));
+    OI_HIP_CHECK(hipMemsetAsync(ws.p, 0, sizeof(float) * (size_t)B + 16, st));
+    float *eps2 = ws.as<float>();
+    uint32_t *gate = reinterpret_cast<uint32_t *>(eps2 + B);
+    OI_CHECK(oi_launch_screen_stage(ctx, qf.as<float>(), B, idx->dim, idx->max_row_norm.as<uint32_t>(), qb.as<uint16_t>(), eps2, gate));
+    if (screen_scores_out && n_rows) {
+        OI_CHECK(oi_launch_screen_probe(ctx, idx->rows, row_begin, n_rows, idx->dim, qb.as<uint16_t>(), B, out.as<float>()));
+        OI_HIP_CHECK(hipMemcpyAsync(screen_scores_out, out.p, sizeof(float) * (size_t)B * n_rows, hipMemcpyDeviceToHost, st));
+    }
+    if (eps_out) OI_HIP_CHECK(hipMemcpyAsync(eps_out, eps2, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    if (eps_out)
+        for (uint32_t i = 0; i < B; ++i) eps_out[i] *= 0.5f; // the kernel stores the margin 2 eps
+    return OI_OK;
 }
 
 // ---------------------------------------------------------------- packed multi-GPU exchange

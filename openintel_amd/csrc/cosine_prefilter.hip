@@ -10,13 +10,25 @@
 //   1. screen: s~ = sum_k bf16(x_k) * bf16(q_k), accumulated in f32 by v_mfma_f32_32x32x16_bf16 (1/16 of the
 //      f32 MFMA cycles), the f32 rows converted on the fly between LDS and the matrix pipe (v_cvt_pk_bf16_f32,
 //      round to nearest even).  The corpus stays f32 in HBM and is read once: the kernel is a stream.
-//   2. bound: |bf16(v) - v| <= 2^-9 |v|, so |s~ - s| <= (2^-8 + 2^-17) sum_k |x_k q_k| + (f32 accumulation)
-//      <= eps = (2^-8 + 2^-12) * max_row_norm * |q|   (Cauchy-Schwarz; the 2^-12 covers both accumulations
-//      and the rounding of the norms).  max_row_norm is taken when the rows are set, |q| per query.
+//   2. bound (round 2: re-derived -- the round-1 constant assumed a unit roundoff of 2^-9 for bf16; it is 2^-8,
+//      and a product of two rounded values can be off by 2^-7, so that bound was too small by 2x and a row of
+//      the exact list could be screened out).  Nothing is assumed about the rounding now; it is MEASURED.  With
+//      x~ = bf16(x), q~ = bf16(q), e_x = x~ - x, e_q = q~ - q (both exact in f32):
+//          s~ - s  =  sum_k x~_k q~_k - x_k q_k  =  e_x . q~  +  x . e_q
+//      so by Cauchy-Schwarz   |s~ - s| <= |e_x| |q~| + |x| |e_q|   for the exact sums, and the f32 accumulation
+//      of the screen (products of bf16 values are exact in f32; <= d additions, each off by at most 2^-23 of
+//      the running sum even if the matrix pipe truncates) and of the rescoring add <= d 2^-22 |x~| |q~|.  Hence
+//          eps_q = E |q~| + X |e_q| + d 2^-22 (X + E) |q~|  (+ an absolute term for flushed denormals)
+//      with X = max_r |x_r| and E = max_r |bf16(x_r) - x_r| taken over the corpus when the rows are set (one
+//      pass, the same v_cvt_pk_bf16_f32 the screen uses) and |q~|, |e_q| per query at search time.  For
+//      unit Gaussian rows at d = 768 that is E ~ 0.5 * 2^-8, |e_q| ~ 0.45 * 2^-8: eps ~ 0.0042, about half
+//      of the worst case 2^-7 -- and when every coordinate sits at a bf16 tie (the adversarial case,
+//      tests/test_gpu_prefilter.py) E and |e_q| grow to 2^-8 |x| and the margin grows with them: the
+//      bound holds for ANY data, it is only tight for typical data.
 //   3. keep: if tau~ is the k'-th largest s~ seen so far, at least k' rows have s >= tau~ - eps, so the final
 //      k'-th exact score is >= tau~ - eps, and any row of the final list has s~ >= tau~ - 2 eps.  The select
 //      after each corpus chunk therefore keeps EVERY key within 2 eps of the k'-th (select.hip, margin mode) and
-//      the screen's threshold is tau~ - 2 eps: a superset of the exact list survives, about 2.3 k' keys for
+//      the screen's threshold is tau~ - 2 eps: a superset of the exact list survives, about 2.4 k' keys for
 //      unit vectors at d = 768.
 //   4. rescore: exact f32 dot products of the survivors only (one wave per (query, row); ~150K rows per batch
 //      instead of 640M), then the ordinary sorted top-k' selection over exact keys.
@@ -243,35 +255,62 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
 }
 
 // ------------------------------------------------------------------ norms, eps, query staging
-// max over rows of |row| (f32), as the bits of a non-negative float (atomicMax on the bits orders them; a NaN
-// norm has the largest bits and poisons the maximum on purpose: the bound does not hold for such a corpus).
+// Over the rows: X = max_r |x_r| and E = max_r |bf16(x_r) - x_r| (f32, as the bits of non-negative floats:
+// atomicMax on the bits orders them; a NaN has the largest bits and poisons the maximum on purpose -- the bound
+// does not hold for such a corpus).  The conversion is the screen's own (pf_pack -> v_cvt_pk_bf16_f32), so
+// whatever it does to a value (round to nearest even, a flushed denormal) is what E measures.
+//   out[0] = bits(X), out[1] = bits(E)
 __global__ __launch_bounds__(256) void pf_row_norm_max_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
-                                                              uint32_t *max_bits) {
+                                                              uint32_t *out) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t nvec = dim >> 2;
-    float best = 0.f;
+    float best = 0.f, best_e = 0.f;
     bool bad = false;
     for (uint64_t r = wave; r < n; r += n_waves) {
         const float4 *x = reinterpret_cast<const float4 *>(rows + r * dim);
-        float ss = 0.f;
+        float ss = 0.f, se = 0.f;
         for (uint32_t v = lane; v < nvec; v += 64) {
             const float4 a = x[v];
             ss = fmaf(a.x, a.x, ss); ss = fmaf(a.y, a.y, ss); ss = fmaf(a.z, a.z, ss); ss = fmaf(a.w, a.w, ss);
+            const pf_f32x4 f = {a.x, a.y, a.z, a.w};
+            const pf_bf16x8 b = pf_pack(f, f);
+            const float e0 = (float)b[0] - a.x, e1 = (float)b[1] - a.y, e2 = (float)b[2] - a.z, e3 = (float)b[3] - a.w;
+            se = fmaf(e0, e0, se); se = fmaf(e1, e1, se); se = fmaf(e2, e2, se); se = fmaf(e3, e3, se);
         }
         ss = oi_wave_sum(ss);
-        const float nm = sqrtf(ss);
-        bad = bad || !(nm == nm);
+        se = oi_wave_sum(se);
+        const float nm = sqrtf(ss), ne = sqrtf(se);
+        bad = bad || !(nm == nm) || !(ne == ne);
         best = nm > best ? nm : best;
+        best_e = ne > best_e ? ne : best_e;
     }
-    if (lane == 0) atomicMax(max_bits, bad ? 0x7FC00000u : __float_as_uint(best));
+    if (lane == 0) {
+        atomicMax(out, bad ? 0x7FC00000u : __float_as_uint(best));
+        atomicMax(out + 1, bad ? 0x7FC00000u : __float_as_uint(best_e));
+    }
+}
+
+// The margin of one query (see the header): |s~ - s^| <= eps for every row of the corpus, s^ the rescoring
+// kernel's f32 score.  X, E: the corpus maxima above; qn = |q|, qtn = |bf16(q)|, en = |bf16(q) - q|, all f32.
+//   * 1.001 covers the f32 rounding of the five norms (sums of <= 1024 squares: 1e-4 at the very most);
+//   * squares below 2^-126 may have been flushed out of a norm: each norm is short by at most
+//     sqrt(d) 2^-63 < 4e-18, added back here;
+//   * products / inputs below 2^-126 may be flushed by the conversions and the matrix pipe: d 2^-120 (X + |q|).
+#define PF_NORM_LIMIT 1.0e15f
+#define PF_QNORM_MIN 1.0e-12f
+__device__ __forceinline__ float pf_eps(float X, float E, float qn, float qtn, float en, uint32_t dim) {
+    const float tiny = 4.0e-18f, d = (float)dim;
+    const float Xs = X + tiny, Es = E + tiny, qts = qtn + tiny, ens = en + tiny;
+    const float acc = d * 2.384185791015625e-07f; // d * 2^-22
+    return 1.001f * (Es * qts + Xs * ens + acc * (Xs + Es) * qts) + d * 7.5231638452626401e-37f * (Xs + qn) + 1.0e-30f;
 }
 
 // Per query: bf16 copy (RNE, zero padded to n_padded rows) and the screen's margin 2 eps; a norm that is not
-// finite or too large for the bf16 products to stay finite opens the exact pipeline instead (gate).
+// finite, too large for the bf16 products to stay finite, or too small for its rounding errors to be measured in
+// f32 opens the exact pipeline instead (gate).
 //   state words: eps2[q] (float) at state + q; *gate at gate.
-#define PF_NORM_LIMIT 1.0e15f
 __global__ __launch_bounds__(256) void pf_stage_queries_kernel(const float *__restrict__ q, uint32_t n_queries,
                                                                uint32_t n_padded, uint32_t dim,
                                                                const uint32_t *__restrict__ max_norm_bits,
@@ -280,30 +319,63 @@ __global__ __launch_bounds__(256) void pf_stage_queries_kernel(const float *__re
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t row = wave; row < n_padded; row += n_waves) {
-        float ss = 0.f;
+        float ss = 0.f, st = 0.f, se = 0.f;
         for (uint32_t k = lane; k < dim; k += 64) {
             uint16_t v = 0;
             if (row < n_queries) {
                 const float f = q[(uint64_t)row * dim + k];
-                ss = fmaf(f, f, ss);
                 const uint32_t u = __float_as_uint(f);
                 v = (u & 0x7F800000u) == 0x7F800000u ? (uint16_t)(u >> 16)                        // inf / NaN: truncate
                                                      : (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16); // RNE
+                const float ft = __uint_as_float((uint32_t)v << 16), e = ft - f; // exact: f rounded to 8 of its 24 bits
+                ss = fmaf(f, f, ss);
+                st = fmaf(ft, ft, st);
+                se = fmaf(e, e, se);
             }
             out[(uint64_t)row * dim + k] = v;
         }
         if (row < n_queries) {
             ss = oi_wave_sum(ss);
-            const float qn = sqrtf(ss), mx = __uint_as_float(*max_norm_bits);
-            const bool ok = qn < PF_NORM_LIMIT && mx < PF_NORM_LIMIT; // false for NaN as well
+            st = oi_wave_sum(st);
+            se = oi_wave_sum(se);
+            const float qn = sqrtf(ss), qtn = sqrtf(st), en = sqrtf(se);
+            const float X = __uint_as_float(max_norm_bits[0]), E = __uint_as_float(max_norm_bits[1]);
+            const bool ok = qn < PF_NORM_LIMIT && qn >= PF_QNORM_MIN && qtn < PF_NORM_LIMIT && X < PF_NORM_LIMIT &&
+                            E < PF_NORM_LIMIT && en == en; // false for NaN as well
             if (lane == 0) {
-                // 2 eps, eps = (2^-8 + 2^-12) * max|x| * |q|; 1.001 covers the f32 rounding of the two norms.
                 // A query without a bound gets an infinite margin: its threshold never rises, every key stays
                 // inside the margin, the survivors overflow and the exact kernel scores it against every row.
-                eps2[row] = ok ? 2.0f * (0.00390625f + 0.000244140625f) * 1.001f * mx * qn + 1e-37f : __builtin_inff();
+                eps2[row] = ok ? 2.0f * pf_eps(X, E, qn, qtn, en, dim) : __builtin_inff();
                 if (!ok) *gate = 1u;
             }
         }
+    }
+}
+
+// Diagnostics (oi_screen_probe): the screen's raw scores.  Same operands and the same instruction as the screen
+// (bf16 rows by pf_pack, the staged bf16 queries, v_mfma_f32_32x32x16_bf16 accumulating 16 k at a time in K
+// order), one wave per 32 rows x 32 queries; out[q * n_rows + r].
+__global__ __launch_bounds__(64) void pf_probe_kernel(const float *__restrict__ rows, uint64_t row_begin, uint32_t n_rows,
+                                                      uint32_t dim, const uint16_t *__restrict__ queries,
+                                                      uint32_t n_queries, float *__restrict__ out) {
+    const uint32_t lane = threadIdx.x, li = lane & 31, lh = lane >> 5;
+    const uint32_t r0 = blockIdx.x * 32, q0 = blockIdx.y * 32;
+    pf_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const uint32_t row = r0 + li < n_rows ? r0 + li : n_rows - 1; // (rows past the end are not written)
+    const float *x = rows + (row_begin + row) * (uint64_t)dim;
+    const uint16_t *qq = queries + (uint64_t)(q0 + li) * dim;     // the staged block is zero padded to 32 rows
+    for (uint32_t k = 0; k < dim; k += 16) {
+        const pf_bf16x8 a = pf_pack(*reinterpret_cast<const pf_f32x4 *>(x + k + 8 * lh),
+                                    *reinterpret_cast<const pf_f32x4 *>(x + k + 8 * lh + 4));
+        const pf_bf16x8 b = *reinterpret_cast<const pf_bf16x8 *>(qq + k + 8 * lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * lh, qx = q0 + li;
+        if (rr < n_rows && qx < n_queries) out[(uint64_t)qx * n_rows + rr] = acc[r];
     }
 }
 
@@ -352,7 +424,7 @@ void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_s
 }
 
 int oi_launch_row_norm_max(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint32_t *max_bits) {
-    OI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 4, ctx->stream));
+    OI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 8, ctx->stream)); // [0] = X, [1] = E
     if (n == 0) return OI_OK;
     uint64_t blocks = (n + 3) / 4;
     const uint64_t cap = (uint64_t)ctx->num_cus * 8;
@@ -428,6 +500,17 @@ int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t 
     ProfScope ps(ctx, "rescore");
     hipLaunchKernelGGL(pf_rescore_kernel, dim3(64, n_queries), dim3(256), 0, ctx->stream, rows, dim, doc_id_base, n_rows,
                        d_queries, in.keys, in.carry_cnt, in.stride, in.carry_cap, out.keys, out.carry_cnt, out.stride);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
+// Diagnostics: raw screen scores s~ of rows [row_begin, row_begin + n_rows) for every query of the staged block.
+int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
+                           const uint16_t *q_bf16, uint32_t n_queries, float *d_out) {
+    if (n_rows == 0 || n_queries == 0) return OI_OK;
+    OI_REQUIRE(dim % 16 == 0, "screen probe: dim %u is not a multiple of 16", dim);
+    hipLaunchKernelGGL(pf_probe_kernel, dim3((n_rows + 31) / 32, (n_queries + 31) / 32), dim3(64), 0, ctx->stream, rows,
+                       row_begin, n_rows, dim, q_bf16, n_queries, d_out);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

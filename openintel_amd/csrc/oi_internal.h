@@ -107,8 +107,9 @@ struct oi_index {
     bool rows_owned = false;
     uint16_t *rows_bf16 = nullptr; // device; set instead of `rows` for a bf16 corpus
     bool rows_bf16_owned = false;
-    DevBuf max_row_norm; // u32: bits of max_r |row r| (f32), taken when the f32 rows are set; NaN if any norm is
-    bool screen_ok = false; // that maximum is finite and < 1e15: the bf16 screen's bound holds for this corpus
+    DevBuf max_row_norm; // u32[2]: bits of X = max_r |row r| and E = max_r |bf16(row r) - row r| (f32), taken when the f32 rows
+                         // are set; NaN if any norm is
+    bool screen_ok = false; // those maxima are finite and < 1e15: the bf16 screen's bound holds for this corpus
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;
@@ -209,6 +210,8 @@ int oi_launch_screen_stage(oi_ctx *ctx, const float *d_queries, uint32_t n_queri
                            const uint32_t *max_norm_bits, uint16_t *q_bf16, float *eps2, uint32_t *gate);
 int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                   const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
+int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
+                           const uint16_t *q_bf16, uint32_t n_queries, float *d_out);
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
                       const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out);
 int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,

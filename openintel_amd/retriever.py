@@ -211,6 +211,18 @@ class HybridIndex(PostRetriever):
                                       _lib.ptr(out.docs), _lib.ptr(out.counts)))
         return out
 
+    def screen_probe(self, query_vecs, row_begin: int = 0, n_rows: int = 0):
+        """Diagnostics of the bf16 screen (oi_screen_probe): (s~ [B, n_rows] or None, eps [B]) for host queries --
+        the screen's raw scores of rows [row_begin, row_begin + n_rows) and each query's proven bound."""
+        qv = _np(query_vecs, np.float32)
+        B = int(qv.shape[0])
+        assert int(qv.shape[1]) == self.dim
+        st = np.zeros((B, n_rows), np.float32) if n_rows else None
+        eps = np.zeros(B, np.float32)
+        _lib.check(self.lib.oi_screen_probe(self.handle, _lib.ptr(qv), B, int(row_begin), int(n_rows), _lib.ptr(st),
+                                            _lib.ptr(eps)))
+        return st, eps
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.oi_index_destroy(self.handle)
