@@ -60,6 +60,10 @@ class HipLexiconAnalyzer(PostAnalyzer):
             raise SourceFailure("hip-analyzer", msg)  # the mapping INTEGRATION.md prescribes
         return pol, spec
 
+    def score_texts(self, texts: Sequence[str]):
+        """(polarity f64[n], speculative u8[n]) of plain strings: pack_posts + analyze_packed."""
+        return self.analyze_packed(*pack_posts(texts))
+
     def analyze_device(self, d_blob, d_offsets, d_polarity, d_speculative) -> None:
         """torch CUDA tensors in HBM (uint8 blob, int64/uint64 offsets[n+1], float64[n], uint8[n]);
         asynchronous on the ctx stream."""

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 
 #include "oi_internal.h"
 
@@ -17,6 +18,18 @@ void oi_set_error(const char *fmt, ...) {
 
 extern "C" const char *oi_last_error(void) { return g_err; }
 extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
+
+// ---------------------------------------------------------------- per-(kernel, device) one-shots
+int oi_dyn_lds(oi_ctx *ctx, const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> done;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_pair(kernel, ctx->device);
+    if (done.count(key)) return OI_OK;
+    OI_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done.insert(key);
+    return OI_OK;
+}
 
 // ---------------------------------------------------------------- buffers
 int DevBuf::ensure(size_t bytes) {
@@ -494,14 +507,14 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
 // Rows of the first corpus chunk (scored with no threshold yet: every row lands in the pool, so it is kept
 // small); each later chunk is 8x the one before.  OI_FIRST_CHUNK_MULT scales it (A/B runs).
 static uint64_t oi_first_chunk_rows(uint32_t depth) {
-    static const uint64_t mult = getenv("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(getenv("OI_FIRST_CHUNK_MULT"))) : 1;
+    static const uint64_t mult = oi_ablation_env("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(oi_ablation_env("OI_FIRST_CHUNK_MULT"))) : 1;
     return std::max<uint64_t>(8192, 32ull * depth) * mult;
 }
 // Measured (tools/growth_ab.sh): 8 is best for the MFMA batch path at 10M and 1.25M rows (more survivors per
 // chunk cost more in the epilogue and the select than the launch they save); the GEMV path (B <= 8) gains
 // 3 % from 16 (1M rows: 3 launches instead of 4).
 static uint64_t oi_chunk_growth(uint32_t B) {
-    static const uint64_t g = getenv("OI_CHUNK_GROWTH") ? std::max(2, atoi(getenv("OI_CHUNK_GROWTH"))) : 0;
+    static const uint64_t g = oi_ablation_env("OI_CHUNK_GROWTH") ? std::max(2, atoi(oi_ablation_env("OI_CHUNK_GROWTH"))) : 0;
     return g ? g : (B <= 8 ? 16 : 8);
 }
 
@@ -531,7 +544,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
     // leaves, instead of running after it.  OI_NO_OVERLAP=1 serialises them (A/B runs).
-    static const bool no_overlap = getenv("OI_NO_OVERLAP") != nullptr;
+    static const bool no_overlap = oi_ablation_env("OI_NO_OVERLAP") != nullptr;
     const bool overlap = cos_s && bm_s && ctx->side_stream && ctx->ev_fork && ctx->ev_join && ctx->overlap_legs && !no_overlap;
     // ---- BM25 list
     auto bm25_leg = [&]() -> int {
@@ -669,8 +682,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 }
                 return OI_OK;
             };
-            static const bool shape16 = !(getenv("OI_KS_SHAPE") && atoi(getenv("OI_KS_SHAPE")) == 32);
-            static const bool cos_v1 = getenv("OI_COSINE_V1") != nullptr || getenv("OI_SELECT_V1") != nullptr;
+            static const bool shape16 = !(oi_ablation_env("OI_KS_SHAPE") && atoi(oi_ablation_env("OI_KS_SHAPE")) == 32);
+            static const bool cos_v1 = oi_ablation_env("OI_COSINE_V1") != nullptr || oi_ablation_env("OI_SELECT_V1") != nullptr;
             const bool screen = ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && oi_cosine_screen_supported(idx->dim) &&
                                 idx->screen_ok && shape16 && !cos_v1;
             if (!screen) return exact_pipeline(nullptr, nullptr);

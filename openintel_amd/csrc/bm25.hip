@@ -562,12 +562,7 @@ int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q
     OI_REQUIRE(pool.seg_cap == depth && pool.n_segs == idx->n_blocks && pool.n_segs <= pool.seg_cnt_stride &&
                    pool.carry_cap + (uint64_t)pool.n_segs * depth <= pool.stride,
                "bm25: pool geometry mismatch");
-    static bool attr_set = false;
-    if (!attr_set) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_block_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, BM_SMEM));
-        attr_set = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(bm25_block_kernel), (size_t)(BM_SMEM)));
     // one workgroup per CU is resident (128 KiB of LDS); split the batch so the grid has
     // about 4 workgroups per CU when the corpus has few blocks
     uint32_t ysplit = (uint32_t)((4ull * ctx->num_cus + nb - 1) / nb);

@@ -576,16 +576,10 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     OI_REQUIRE(nq <= BS_MAX_Q, "bm25 scan: %u queries in one pass (limit %u)", nq, BS_MAX_Q);
     DevBuf &bb = ctx->buf("bm25_scan_batch");
     OI_CHECK(bb.ensure(sizeof(BsBatch)));
-    static const int dbg = getenv("OI_BM25_SCAN_DBG") ? atoi(getenv("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
+    static const int dbg = oi_ablation_env("OI_BM25_SCAN_DBG") ? atoi(oi_ablation_env("OI_BM25_SCAN_DBG")) : 0; // ablations (wrong results)
     auto kernel = dbg == 9 ? bm25_scan_kernel<true> : bm25_scan_kernel<false>;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BsShared)));
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bm25_scan_kernel<false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(BsShared)));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(bm25_scan_kernel<true>), (size_t)(sizeof(BsShared))));
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(bm25_scan_kernel<false>), (size_t)(sizeof(BsShared))));
     if (run_setup) {
         hipLaunchKernelGGL(bm25_scan_setup, dim3(1), dim3(1024), 0, ctx->stream, d_q_terms, d_q_offsets, q_begin, nq,
                            idx->vocab, idx->max_query_terms, idx->idf.as<float>(), idx->df_local.as<uint32_t>(),

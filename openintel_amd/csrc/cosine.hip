@@ -231,7 +231,7 @@ uint32_t oi_cosine_query_padding(uint32_t n_queries) {
 int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end,
                            uint32_t dim, const float *d_queries, uint32_t n_queries,
                            uint32_t n_queries_padded, uint32_t doc_id_base, PoolView &pool) {
-    static const bool force_v1 = getenv("OI_COSINE_V1") != nullptr; // A/B switch for benchmarking
+    static const bool force_v1 = oi_ablation_env("OI_COSINE_V1") != nullptr; // A/B switch for benchmarking
     const bool ksplit = n_queries > 8 && !force_v1 && oi_cosine_ksplit_supported(dim);
     if (ksplit) oi_cosine_ksplit_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
     else if (n_queries <= 8) oi_cosine_gemv_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);

@@ -417,12 +417,7 @@ static int launch_bf16(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, ui
                        uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int NKC = D / CB_SLOT_K, NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
     constexpr size_t smem = 4 * NBUF * CB_SLOT_BYTES + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_bf16_filter<D, NQT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_filter<D, NQT>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_bf16_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
                        p.carry_cap, p.seg_cap, p.overflow);
@@ -436,12 +431,7 @@ static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
     constexpr int NKC = D / 2 / CB_SLOT_K;
     constexpr size_t smem = 4 * NKC * CB_SLOT_BYTES + 2 * (NQT * 16 * 64) * 4 + 128 * 4;
     static_assert(smem <= 160 * 1024, "LDS");
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_bf16_pair<D, NQT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_pair<D, NQT>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_bf16_pair<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
                        p.carry_cap, p.seg_cap, p.overflow);
@@ -457,7 +447,7 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
     OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
                "cosine (bf16 corpus): chunk does not fit the candidate pool");
     if (row_end <= row_begin || n_queries == 0) return OI_OK;
-    static const bool solo_only = getenv("OI_BF16_SOLO") != nullptr; // A/B: never use the pair kernel
+    static const bool solo_only = oi_ablation_env("OI_BF16_SOLO") != nullptr; // A/B: never use the pair kernel
     const uint32_t n_padded = (n_queries + 31u) & ~31u;
     DevBuf &qb = ctx->buf("q_bf16");
     OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 128) * dim));

@@ -498,12 +498,7 @@ static int launch_ksplit16(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
                            uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int KS = D / 4, NKC = KS / KS_CHUNK_K, NBUF = NKC <= 6 ? NKC : NKC / 2;
     constexpr size_t smem = 4 * NBUF * KS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_ksplit16_filter<D, NQT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_ksplit16_filter<D, NQT>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_ksplit16_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows,
                        row_begin, row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys,
                        p.stride, p.carry_cap, p.seg_cap, p.overflow, ctx->run_gate);
@@ -516,12 +511,7 @@ static int launch_ksplit_dbg(oi_ctx *ctx, const float *rows, uint64_t row_begin,
                              uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int KS = D / 4, NKC = KS / KS_CHUNK_K, NBUF = NKC <= 6 ? NKC : NKC / 2;
     constexpr size_t smem = 4 * NBUF * KS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_ksplit_filter<D, NQT, DBG>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_ksplit_filter<D, NQT, DBG>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_ksplit_filter<D, NQT, DBG>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows,
                        row_begin, row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys,
                        p.stride, p.carry_cap, p.seg_cap, p.overflow);
@@ -532,9 +522,10 @@ static int launch_ksplit_dbg(oi_ctx *ctx, const float *rows, uint64_t row_begin,
 template <int D, int NQT>
 static int launch_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const float *q,
                          uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+#ifdef OI_ABLATION
     if constexpr (D == 768 && NQT == 2) {
         // ablation builds for tools/ks_ablate.py (timings only; results are wrong by construction)
-        static const int dbg = getenv("OI_KS_DEBUG") ? atoi(getenv("OI_KS_DEBUG")) : 0;
+        static const int dbg = oi_ablation_env("OI_KS_DEBUG") ? atoi(oi_ablation_env("OI_KS_DEBUG")) : 0;
         switch (dbg) {
             case 1: return launch_ksplit_dbg<D, NQT, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
             case 2: return launch_ksplit_dbg<D, NQT, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
@@ -547,6 +538,7 @@ static int launch_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uin
             default: break;
         }
     }
+#endif
     return launch_ksplit_dbg<D, NQT, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 }
 
@@ -566,7 +558,7 @@ int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, 
                             const float *q, uint32_t nq, bool two_tiles, uint32_t doc_id_base, const PoolView &p) {
     // 16x16x4 is the default: 3 % faster by wall time than 32x32x2 on the same tile (A/B in one
     // session, 10M x 768, B=64: 9.07 vs 9.35 ms); OI_KS_SHAPE=32 selects the other build.
-    static const bool shape16 = !(getenv("OI_KS_SHAPE") && atoi(getenv("OI_KS_SHAPE")) == 32);
+    static const bool shape16 = !(oi_ablation_env("OI_KS_SHAPE") && atoi(oi_ablation_env("OI_KS_SHAPE")) == 32);
     OI_REQUIRE(shape16 || !ctx->run_gate, "cosine_ksplit: only the 16x16x4 build takes a run gate");
 #define OI_KS(DD)                                                                                       \
     case DD:                                                                                            \

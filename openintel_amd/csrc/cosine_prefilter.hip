@@ -449,12 +449,7 @@ static int launch_screen(oi_ctx *ctx, const float *rows, uint64_t row_begin, uin
                          uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int NKC = D / PF_SLOT_K, NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
     constexpr size_t smem = 4 * NBUF * PF_SLOT_BYTES + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_screen_filter<D, NQT>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_screen_filter<D, NQT>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_screen_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
                        p.carry_cap, p.seg_cap, p.overflow);

@@ -352,12 +352,7 @@ static int launch_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint
                         uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int KS = D / 4, NKC = KS / 32, NBUF = NKC <= 6 ? NKC : NKC / 2;
     constexpr size_t smem = 4 * NBUF * CS_SLOT_BYTES + 4 * (NQT * 16 * 64) * 4 + 64 * 4;
-    static bool attr = false;
-    if (!attr) {
-        OI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(cosine_split_filter<D, NQT, DBG>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr = true;
-    }
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_split_filter<D, NQT, DBG>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_split_filter<D, NQT, DBG>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
                        p.carry_cap, p.seg_cap, p.overflow);
@@ -380,7 +375,8 @@ int oi_launch_cosine_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
         OI_HIP_CHECK(hipGetLastError());
     }
     const uint16_t *q = qb.as<uint16_t>();
-    static const int dbg = getenv("OI_CS_DEBUG") ? atoi(getenv("OI_CS_DEBUG")) : 0; // ablation builds (timings only)
+#ifdef OI_ABLATION
+    static const int dbg = oi_ablation_env("OI_CS_DEBUG") ? atoi(oi_ablation_env("OI_CS_DEBUG")) : 0; // ablation builds (timings only)
     if (dim == 768 && nq > 32 && dbg) {
         switch (dbg) {
             case 1: return launch_split<768, 2, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
@@ -393,6 +389,7 @@ int oi_launch_cosine_split(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
             default: break;
         }
     }
+#endif
     if (dim == 768) return nq > 32 ? launch_split<768, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
                                    : launch_split<768, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
     return nq > 32 ? launch_split<384, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)

@@ -665,19 +665,19 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     OI_HIP_CHECK(hipMemcpyAsync(dp.p, &prm, sizeof(HlParams), hipMemcpyHostToDevice, ctx->stream));
     // titles per workgroup: the largest tile whose average bytes fill about 3/4 of the LDS window
     static const uint32_t kTiles[] = {256, 192, 128, 96, 64, 48, 32, 16, 8};
-    static const uint32_t forced = getenv("OI_HEADLINE_TILE") ? (uint32_t)atoi(getenv("OI_HEADLINE_TILE")) : 0u;
+    static const uint32_t forced = oi_ablation_env("OI_HEADLINE_TILE") ? (uint32_t)atoi(oi_ablation_env("OI_HEADLINE_TILE")) : 0u;
     const uint64_t avg = blob_bytes / n + 1;
     uint32_t tile = 8;
     for (uint32_t t : kTiles)
         if (avg * t <= (HL_WIN_BYTES * 3) / 4) { tile = t; break; }
     if (forced >= 1 && forced <= HL_MAX_TILE) tile = forced;
-    static const int dbg = getenv("OI_HEADLINE_DBG") ? atoi(getenv("OI_HEADLINE_DBG")) : 0; // ablations (wrong results)
-    static const bool v1 = getenv("OI_HEADLINE_V1") != nullptr; // one lane per title (kept for A/B runs)
+    static const int dbg = oi_ablation_env("OI_HEADLINE_DBG") ? atoi(oi_ablation_env("OI_HEADLINE_DBG")) : 0; // ablations (wrong results)
+    static const bool v1 = oi_ablation_env("OI_HEADLINE_V1") != nullptr; // one lane per title (kept for A/B runs)
     const uint64_t per_wg = v1 ? HL_THREADS : tile;
     OI_REQUIRE((n + per_wg - 1) / per_wg <= 0x7FFFFFFFull, "headline scan: too many titles for one launch");
     const uint32_t grid = (uint32_t)((n + per_wg - 1) / per_wg);
     unsigned long long *d_timing = nullptr;
-    if (getenv("OI_HEADLINE_TIMING")) {
+    if (oi_ablation_env("OI_HEADLINE_TIMING")) {
         DevBuf &tb = ctx->buf("hl_timing");
         OI_CHECK(tb.ensure(8 * sizeof(unsigned long long)));
         OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, 8 * sizeof(unsigned long long), ctx->stream));

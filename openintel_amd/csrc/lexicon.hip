@@ -627,13 +627,12 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
     if (n == 0) return OI_OK;
     OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "lexicon: text blob must be 16-byte aligned in HBM");
     struct HostTables { LexEntry table[LEX_SLOTS]; uint32_t bloom[64]; };
-    static HostTables h;
+    static HostTables h; // built once per process (std::call_once: contexts on several host threads share it)
     static uint32_t h_mult = 0;
-    static bool built = false;
-    if (!built) {
-        if (!build_lex_table(h.table, &h_mult, h.bloom)) { oi_set_error("lexicon: no perfect hash found"); return OI_ERR_STATE; }
-        built = true;
-    }
+    static bool built_ok = false;
+    static std::once_flag once;
+    std::call_once(once, [] { built_ok = build_lex_table(h.table, &h_mult, h.bloom); });
+    if (!built_ok) { oi_set_error("lexicon: no perfect hash found"); return OI_ERR_STATE; }
     DevBuf &tb = ctx->buf("lex_table");
     if (!tb.p) {
         OI_CHECK(tb.ensure(sizeof(h)));
@@ -641,7 +640,7 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
     }
     const LexEntry *d_table = tb.as<LexEntry>();
     const uint32_t *d_bloom = reinterpret_cast<const uint32_t *>(d_table + LEX_SLOTS);
-    static const bool v1 = getenv("OI_LEXICON_V1") != nullptr; // A/B switch: the first-generation scan
+    static const bool v1 = oi_ablation_env("OI_LEXICON_V1") != nullptr; // A/B switch: the first-generation scan
     ProfScope ps(ctx, "lexicon");
     if (v1) {
         const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -41,6 +42,22 @@ void oi_set_error(const char *fmt, ...);
             return OI_ERR_INVALID_ARG; \
         }                             \
     } while (0)
+
+// ---------------------------------------------------------------- process-wide one-shots and build switches
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: set once per (kernel, device),
+// under a process-wide mutex -- contexts on different devices / host threads all pass through here (api.hip).
+struct oi_ctx;
+int oi_dyn_lds(oi_ctx *ctx, const void *kernel, size_t bytes);
+
+// A/B switches, ablation builds ("timings only, results wrong by construction") and the first-generation kernels are
+// reachable through environment variables ONLY in a -DOI_ABLATION build (tools/*.sh, tools/ks_ablate.py build one
+// with OI_EXTRA_HIPCC_FLAGS=-DOI_ABLATION).  The product build ignores them: a stray variable cannot change what
+// the C ABI returns.  (OI_COSINE_MODE / OI_BM25_MODE select between documented, tested, equivalent modes and stay.)
+#ifdef OI_ABLATION
+inline const char *oi_ablation_env(const char *name) { return getenv(name); }
+#else
+inline const char *oi_ablation_env(const char *) { return nullptr; }
+#endif
 
 // ---------------------------------------------------------------- buffers
 // Grow-only device buffer: the hot path never calls hipMalloc once warmed up.

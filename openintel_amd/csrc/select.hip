@@ -611,7 +611,7 @@ int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint
     if (n_queries == 0) return OI_OK;
     OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH && k <= pool.carry_cap, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
     ProfScope ps(ctx, "select");
-    static const bool v1 = getenv("OI_SELECT_V1") != nullptr; // A/B switch: the segment-walking kernel
+    static const bool v1 = oi_ablation_env("OI_SELECT_V1") != nullptr; // A/B switch: the segment-walking kernel
     const bool special = extra && (extra->eps2 || extra->run_gate);
     if (special) {
         OI_REQUIRE(pool.n_segs <= SEL_MAX_SEGS, "select: %u segments (margin / gated selects take <= %u)", pool.n_segs, SEL_MAX_SEGS);

@@ -50,3 +50,17 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oi_oracle" not in src and "liboi_oracle" not in src, f
+
+
+def test_product_build_has_no_ablation_switches():
+    """A/B switches, 'wrong results' ablation variants and the v1 kernels are reachable only in a -DOI_ABLATION
+    build (oi_internal.h: oi_ablation_env): their environment-variable names must not even be in the product
+    binary, so a stray variable cannot change what the C ABI returns."""
+    from openintel_amd import build, _lib
+    build.build()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"OI_KS_DEBUG", b"OI_CS_DEBUG", b"OI_BM25_SCAN_DBG", b"OI_HEADLINE_DBG", b"OI_COSINE_V1",
+                 b"OI_SELECT_V1", b"OI_LEXICON_V1", b"OI_HEADLINE_V1", b"OI_NO_OVERLAP", b"OI_CHUNK_GROWTH",
+                 b"OI_FIRST_CHUNK_MULT", b"OI_KS_SHAPE", b"OI_BF16_SOLO", b"OI_HEADLINE_TILE", b"OI_HEADLINE_TIMING"):
+        assert name not in blob, name
+    assert b"OI_COSINE_MODE" in blob and b"OI_BM25_MODE" in blob   # the two documented mode selectors stay

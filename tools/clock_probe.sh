@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the OI_* A/B and ablation switches only exist in an ablation build of the library:
+#   OI_EXTRA_HIPCC_FLAGS=-DOI_ABLATION python -m openintel_amd.build --force
+# (the product build ignores them; rebuild without the flag afterwards).
 # Effective shader clock of the cosine kernel per ablation mode: GRBM_GUI_ACTIVE / 8 XCDs / wall time
 # (MI355X_MICROARCH.md, DVFS give-back).  Usage: tools/clock_probe.sh "0 5 12 4"
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE: the OI_* A/B and ablation switches only exist in an ablation build of the library:
+#   OI_EXTRA_HIPCC_FLAGS=-DOI_ABLATION python -m openintel_amd.build --force
+# (the product build ignores them; rebuild without the flag afterwards).
 # A/B of the corpus-chunk schedule (OI_CHUNK_GROWTH, OI_FIRST_CHUNK_MULT): full step, shard step, batch-1 query.
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/growth

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostics: run bench.py with the K-split kernel's ablation switches (OI_KS_DEBUG bits:
 1 = no DMA, 2 = no MFMA, 4 = no epilogue) and print the cosine kernel time of each variant.
-Results of ablated variants are WRONG by construction; only the timings are meaningful."""
+Results of ablated variants are WRONG by construction; only the timings are meaningful.
+Needs an ablation build: OI_EXTRA_HIPCC_FLAGS=-DOI_ABLATION python -m openintel_amd.build --force
+(the product build compiles these variants out and ignores OI_KS_DEBUG)."""
 import json
 import os
 import subprocess
