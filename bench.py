@@ -26,29 +26,52 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 
 
 def cpu_baseline(n_total, dim, vocab, depth, k, sample_docs, sample_queries):
-    """The CPU oracle (kind "port": the build's own scalar C restatement; the reference has no
-    retrieval code and its Rust cannot be built here) timed on a bounded slice of the same
-    workload.  Brute-force cost is linear in corpus size, so the full-corpus rate is the
-    sample rate scaled by sample_docs / n_total."""
+    """The CPU oracle (kind "port": the build's own scalar C restatement -- the reference has no retrieval code and
+    its Rust cannot be built here, so this is NOT "the reference Rust CPU path") timed on a bounded slice of the
+    same workload, single-thread AND on all host cores (OpenMP over the queries of the batch; every query is the
+    same scalar pipeline, tests/test_oracle_retrieval.py).  Brute force is linear in the corpus size (dot products
+    N*d, the BM25 scan of the forward index, the O(N) selection), so the full-corpus rate is the slice rate scaled
+    by sample_docs / n_total; the all-cores leg is also run at half the slice to show that linearity in the line."""
     import numpy as np
     from openintel_amd import synth
     from oracle import lib as O
     rows = synth.embeddings_np(sample_docs, dim)
-    q = synth.embeddings_np(sample_queries, dim, seed=synth.SEED_QUERY)
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # the all-cores leg is parallel over queries: give it as many queries as there are threads (up to 4 batches)
+    n_qn = max(sample_queries, min(4 * sample_queries, nproc))
+    threads = max(1, min(nproc, O.max_threads(), n_qn))
+    q = synth.embeddings_np(n_qn, dim, seed=synth.SEED_QUERY)
     terms, offs = synth.forward_index_np(sample_docs, vocab)
-    qt, qo = synth.query_terms_np(sample_queries, vocab)
-    df, tot = O.bm25_df(terms, offs, vocab)
-    t0 = time.perf_counter()
-    for b in range(sample_queries):
-        _, cd = O.topk(O.dot_scores(rows, q[b]), depth)
-        _, bd = O.topk(O.bm25_scores(terms, offs, vocab, qt[qo[b]:qo[b + 1]], df=df), depth, True)
-        O.rrf_fuse(cd, bd, k)
-    dt = time.perf_counter() - t0
-    qps_sample = sample_queries / dt
+    qt, qo = synth.query_terms_np(n_qn, vocab)
+    df, _ = O.bm25_df(terms, offs, vocab)
+
+    def run(n_docs, n_q, n_threads):
+        o = offs[:n_docs + 1]
+        t0 = time.perf_counter()
+        _, _, _, used = O.hybrid_search_batch(rows[:n_docs], terms[:int(o[-1])], o, vocab, q[:n_q], qt[:int(qo[n_q])],
+                                              qo[:n_q + 1], k, depth, n_threads=n_threads, df=df)
+        return time.perf_counter() - t0, used
+
+    n_q1 = max(1, min(sample_queries, 16))            # the single-thread leg: a quarter of the batch is ~2.5 s
+    dt1, _ = run(sample_docs, n_q1, 1)
+    dtn, used = run(sample_docs, n_qn, threads)
+    dth, _ = run(sample_docs // 2, n_qn, threads)
+    scale = sample_docs / n_total
+    single = n_q1 / dt1 * scale
+    multi = n_qn / dtn * scale
     return {
-        "value": qps_sample * sample_docs / n_total, "unit": "queries/s", "cores": 1, "kind": "port",
-        "sample": "%d queries against a %d-doc slice (%.1f s of single-thread C oracle); rate scaled by %d/%d "
-                  "(brute-force cost is linear in corpus size)" % (sample_queries, sample_docs, dt, sample_docs, n_total),
+        "value": multi, "unit": "queries/s", "cores": used, "kind": "port",
+        "sample": "%d queries against a %d-doc slice on %d threads (%.1f s); rate scaled by %d/%d (brute force is linear "
+                  "in corpus size: the same batch on half the slice took %.2fx the time)" % (
+                      n_qn, sample_docs, used, dtn, sample_docs, n_total, dth / dtn),
+        "single_thread": {"value": single, "unit": "queries/s", "cores": 1,
+                          "sample": "%d queries against the same %d-doc slice, one thread (%.1f s)" % (n_q1, sample_docs, dt1)},
+        "nproc": nproc, "parallel_speedup": multi / single,
+        "compiler": O.CFLAGS, "label": "build's CPU restatement (scalar C oracle), not the reference's Rust",
     }
 
 
@@ -70,6 +93,7 @@ def main():
                     help="f32 corpus scorer: a bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
                          "(default: the exact scorer's lists, HBM-bound), exact f32 MFMA for every row, or split-precision "
                          "products (six bf16 MFMAs)")
+    ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -129,7 +153,11 @@ def main():
     torch.cuda.empty_cache()
     sr = sharded.make_hip_sharded(ctx, idx, dev)
     sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
-    qv, qt, qo = synth.query_batch_torch(args.batch, args.dim, dev, vocab=args.vocab)
+    # Distinct query batches rotated through the steps (step i uses batch i mod NB): no step can profit from the
+    # previous step's thresholds, pools or cache contents being those of the same queries.
+    NB = max(1, args.query_batches)
+    batches = [synth.query_batch_torch(args.batch, args.dim, dev, vocab=args.vocab, seed=synth.SEED_QUERY + 7919 * i)
+               for i in range(NB)]
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
@@ -137,11 +165,15 @@ def main():
                           torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
                           torch.zeros((args.batch,), dtype=torch.int32, device=dev))
 
+    step_no = [0]
+
     def step():
+        qv, qt, qo = batches[step_no[0] % NB]
+        step_no[0] += 1
         if world == 1:
             idx.search(qv, qt, qo, k=args.k, depth=args.depth, out=out)   # one C-ABI call: the whole query
             return out.docs
-        return sr.search(qv, qt, qo, args.k, args.depth)[1]
+        return sr.search(qv, qt, qo, args.k, args.depth, check=False)[1]  # overflow flag checked after the loops
 
     def fence():
         if world > 1:
@@ -167,6 +199,7 @@ def main():
     elapsed = float(tm.item())
     cos_ms, cos_launches = ctx.profile_read("cosine")
     ctx.profile_reset(False)
+    ctx.synchronize()   # outside the timed region: a pool overflow in any of the K steps is an error, not a number
     # The BM25 leg runs beside the cosine leg on a side stream, so the live cosine duration above includes
     # the CUs it lends to BM25 workgroups.  A few untimed steps with the legs one after the other give the
     # kernel's own duration as well (reported next to the live figure, never instead of it).
@@ -249,6 +282,9 @@ def main():
                 pm = json.load(open(pmc))   # the screen kernel's counters; the exact kernel's under "exact_kernel"
                 roof["traffic"] = (pm if args.cosine == "screen" else pm.get("exact_kernel", {}) if args.cosine == "exact"
                                    else {}).get("cosine_hbm_bytes_per_launch")
+                roof["traffic_source"] = ("NOT measured in this run: read from the committed profiles/pmc_traffic.json (%s), a separate "
+                                          "rocprofv3 --pmc pass of this workload (tools/pmc_profile.sh; FETCH_SIZE/WRITE_SIZE with the "
+                                          "guide's gfx950 corrections), per launch" % pm.get("source", "see file"))
             except Exception:
                 pass
         roof["kernel"] = "cosine scorer (all corpus-chunk launches of a batch)"
@@ -278,6 +314,7 @@ def main():
                                        args.docs, args.dim, args.corpus, args.batch, args.depth, args.k, world),
                        "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
                        "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
+                       "query_batches_rotated": NB,
                        "cosine_scorer": {"screen": "bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
                                                    "(the exact scorer's lists; gated exact fallback)",
                                          "exact": "f32 MFMA for every row", "split": "bf16x3 split products"}[args.cosine]
@@ -290,10 +327,10 @@ def main():
             "build_s": t_build,
         }
         if exact_side is not None:
-            line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring, bound hbm), "
-                                     "a departure from BASELINE north_star's 'cosine GEMM on fp32 MFMA' target made in round 1 "
-                                     "(profiles r01d on; DESIGN 4.1a). The north star's f32-MFMA GEMM is exact_scorer, same K "
-                                     "steps; --cosine exact makes it the headline. QPS before r01d is the exact scorer's.")
+            line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring, bound hbm; "
+                                     "round 2: error bound re-derived from measured rounding errors and adversarially tested, "
+                                     "DESIGN 4.1a). The north star's f32-MFMA GEMM over every row is exact_scorer, same K steps; "
+                                     "--cosine exact makes it the headline.")
             line["exact_scorer"] = exact_side
             line["screen_fell_back_to_exact"] = screen_fallback
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only

@@ -21,9 +21,16 @@ import numpy as np
 
 
 def shard_bounds(n_total: int, world: int, rank: int):
-    """Contiguous row range of `rank`; block-aligned to 4 rows so shard bases stay 16-byte aligned."""
+    """Contiguous row range of `rank`; block-aligned to 4 rows so shard bases stay 16-byte aligned.
+
+    Raises ValueError when the rounding would leave some rank without rows (an index shard needs >= 1 row).
+    The check depends on (n_total, world) only, so EVERY rank raises before any of them enters a collective --
+    a rank that failed alone would leave the others hanging in all_reduce / all_gather."""
     per = (n_total + world - 1) // world
     per = (per + 3) // 4 * 4
+    if world < 1 or n_total < 1 or (world - 1) * per >= n_total:
+        raise ValueError("cannot shard %d rows over %d ranks in 4-row blocks: the last rank(s) would be empty"
+                         % (n_total, world))
     lo = min(n_total, rank * per)
     hi = min(n_total, lo + per)
     return lo, hi
@@ -57,8 +64,13 @@ class ShardedRetriever:
         self.local.finalize(n_global, tok_global, gdf.cpu().numpy().astype(np.uint32))
 
     # ---- query
-    def search(self, qv, qt, qo, k: int, depth: int):
-        """Returns (scores [B,k], docs [B,k], counts [B]) -- identical on every rank."""
+    def search(self, qv, qt, qo, k: int, depth: int, check: bool = True):
+        """Returns (scores [B,k], docs [B,k], counts [B]) -- identical on every rank.
+
+        The device path is asynchronous and the library reports a candidate-pool overflow (OI_ERR_OVERFLOW, a bug
+        guard) only at a host-visible point: with check=True (default) the engine is synchronised after the fuse so
+        that a truncated list can never be returned silently; a pipelined caller (bench.py's timed loop) passes
+        check=False and calls `self.check()` once after the loop."""
         import torch
         if self.fuse_packed is not None:
             B = int(qv.shape[0])
@@ -68,7 +80,10 @@ class ShardedRetriever:
                 self.dist.all_gather_into_tensor(flat, packed, group=self.group)   # the ONE exchange per batch
             else:
                 flat = packed
-            return self.fuse_packed(flat, self.world, B, depth, k)
+            out = self.fuse_packed(flat, self.world, B, depth, k)
+            if check:
+                self.check()
+            return out
         L = self.local.search_lists(qv, qt, qo, depth=depth)
         if self.world == 1:
             cos_d, cos_c, bm_d, bm_c = L.cos_docs, L.cos_counts, L.bm25_docs, L.bm25_counts
@@ -89,6 +104,85 @@ class ShardedRetriever:
             _, cos_d, cos_c = self.merge(g_sc[:, 0].contiguous(), g_dc[:, 0].contiguous(), g_cn[:, 0].contiguous())
             _, bm_d, bm_c = self.merge(g_sc[:, 1].contiguous(), g_dc[:, 1].contiguous(), g_cn[:, 1].contiguous())
         return self.fuse(cos_d, cos_c, bm_d, bm_c, k)
+
+
+    def check(self) -> None:
+        """Synchronise the local engine and raise if it flagged an overflow (HybridIndex: oi_synchronize)."""
+        ctx = getattr(self.local, "ctx", None)
+        if ctx is not None:
+            ctx.synchronize()
+
+
+class ShardedAnalyzer:
+    """the lexicon path over sharded posts.
+
+    Replaces the two loops of SpeculationEngine::social_summary (src/domain/engine/speculation_engine.rs:76-97)
+    when the posts of one report are spread over ranks: every rank scores ITS posts (LexiconAnalyzer::score,
+    lexicon.rs:53-73) and reduces them to the raw sums (`oi_social_counters`: total, by_source[2], bullish, bearish,
+    neutral, spec_count -- u64 -- and polarity_sum, f64); ONE all-gather of those 8 words per rank follows.  The
+    integer fields are summed (exact); the f64 partials are added in RANK order, so the result is the same bits on
+    every rank and run to run, and differs from the reference's input-order sum only by the reassociation bound of
+    DESIGN.md section 5.  The global counters then go through SpeculationEngine.aggregate_counters (host scalars).
+
+    `analyze_shard(*shard_inputs)` returns an object with those eight fields (the HIP one: make_hip_sharded_analyzer;
+    tests/test_sharded_gloo.py injects the CPU oracle)."""
+
+    WORDS = 8
+
+    def __init__(self, analyze_shard: Callable, device, group=None):
+        import torch.distributed as dist
+        self.analyze_shard, self.device, self.group, self.dist = analyze_shard, device, group, dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def summary(self, *shard_inputs):
+        """Global raw sums as a _lib.SocialCounters (identical on every rank)."""
+        import torch
+        from . import _lib
+        c = self.analyze_shard(*shard_inputs)
+        ints = [int(c.total), int(c.by_source[0]), int(c.by_source[1]), int(c.bullish), int(c.bearish), int(c.neutral),
+                int(c.spec_count)]
+        words = np.zeros(self.WORDS, dtype=np.int64)
+        words[:7] = ints
+        words[7:8] = np.array([float(c.polarity_sum)], dtype=np.float64).view(np.int64)   # the f64's bits
+        mine = torch.from_numpy(words).to(self.device)
+        if self.world > 1:
+            allw = torch.empty(self.world * self.WORDS, dtype=torch.int64, device=self.device)
+            self.dist.all_gather_into_tensor(allw, mine, group=self.group)                 # the ONE exchange
+        else:
+            allw = mine
+        g = allw.cpu().numpy().reshape(self.world, self.WORDS)
+        out = _lib.SocialCounters()
+        tot = g[:, :7].sum(axis=0)
+        out.total, out.bullish, out.bearish, out.neutral, out.spec_count = (int(tot[0]), int(tot[3]), int(tot[4]),
+                                                                            int(tot[5]), int(tot[6]))
+        out.by_source[0], out.by_source[1] = int(tot[1]), int(tot[2])
+        psum = 0.0
+        for r in range(self.world):                      # rank order: reproducible
+            psum += float(g[r, 7:8].view(np.float64)[0])
+        out.polarity_sum = psum
+        return out
+
+
+def make_hip_sharded_analyzer(ctx, device, cfg=None, group=None) -> ShardedAnalyzer:
+    """Wire the HIP lexicon scan + summary reduction of `ctx` into a ShardedAnalyzer.  Shard inputs: torch CUDA
+    tensors (uint8 text blob, int64 offsets[n+1], uint8 sources[n] or None)."""
+    import torch
+    from .analyzer import HipLexiconAnalyzer
+    from .domain import EngineConfig
+    from .engine import SpeculationEngine
+    cfg = cfg or EngineConfig()
+    an = HipLexiconAnalyzer(ctx)
+
+    def analyze_shard(d_blob, d_offsets, d_sources=None):
+        n = int(d_offsets.numel()) - 1
+        pol = torch.empty(max(n, 1), dtype=torch.float64, device=device)[:n]
+        spec = torch.empty(max(n, 1), dtype=torch.uint8, device=device)[:n]
+        if n:
+            an.analyze_device(d_blob, d_offsets, pol, spec)
+        return SpeculationEngine.social_counters(ctx, d_sources, pol, spec, cfg)
+
+    return ShardedAnalyzer(analyze_shard, device, group)
 
 
 def make_hip_sharded(ctx, index, device, group=None) -> ShardedRetriever:

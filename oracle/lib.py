@@ -130,6 +130,8 @@ def _L() -> C.CDLL:
         lib.oio_topk.restype = C.c_uint32
         lib.oio_merge_ranked.restype = C.c_uint32
         lib.oio_rrf_fuse.restype = C.c_uint32
+        lib.oio_hybrid_search_batch.restype = C.c_int
+        lib.oio_max_threads.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -379,3 +381,33 @@ def hybrid_search(rows_normalized: np.ndarray, term_ids, doc_offsets, vocab: int
     b_s, b_d = topk(bs, depth, True, doc_base)
     f_s, f_d = rrf_fuse(c_d, b_d, k)
     return dict(cos=(c_s, c_d), bm25=(b_s, b_d), fused=(f_s, f_d))
+
+
+CFLAGS = "gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fopenmp"   # oracle/Makefile
+
+
+def max_threads() -> int:
+    return int(_L().oio_max_threads())
+
+
+def hybrid_search_batch(rows_normalized, term_ids, doc_offsets, vocab: int, query_vecs, query_terms, q_term_offsets,
+                        k: int, depth: int, n_threads: int = 1, df=None):
+    """A whole batch through the scalar pipeline, on n_threads host threads (parallel over queries; identical
+    results for any thread count).  Returns (scores [B,k], docs [B,k], counts [B], threads_used)."""
+    rows = np.ascontiguousarray(rows_normalized, dtype=np.float32)
+    t = np.ascontiguousarray(term_ids, dtype=np.uint32)
+    o = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+    qv = np.ascontiguousarray(query_vecs, dtype=np.float32)
+    qt = np.ascontiguousarray(query_terms, dtype=np.uint32)
+    qo = np.ascontiguousarray(q_term_offsets, dtype=np.uint32)
+    if qt.size == 0:
+        qt = np.zeros(1, np.uint32)
+    B = qv.shape[0]
+    if df is not None:
+        df = np.ascontiguousarray(df, dtype=np.uint32)
+    so, do, co = np.zeros((B, k), np.float32), np.zeros((B, k), np.uint32), np.zeros(B, np.uint32)
+    used = _L().oio_hybrid_search_batch(_p(rows), C.c_uint64(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(t), _p(o),
+                                        C.c_uint32(vocab), _p(df) if df is not None else None, _p(qv), _p(qt), _p(qo),
+                                        C.c_uint32(B), C.c_uint32(depth), C.c_uint32(k), C.c_int(n_threads), _p(so),
+                                        _p(do), _p(co))
+    return so, do, co, int(used)

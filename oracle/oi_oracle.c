@@ -587,3 +587,51 @@ uint32_t oio_rrf_fuse(const uint32_t *docs_a, uint32_t n_a, const uint32_t *docs
     free(u);
     return out;
 }
+
+/* ---- batch driver for the CPU baseline (bench.py) ------------------------------------------ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int oio_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int oio_hybrid_search_batch(const float *rows, uint64_t n_docs, uint32_t dim, const uint32_t *term_ids,
+                            const uint64_t *doc_offsets, uint32_t vocab, const uint32_t *df,
+                            const float *query_vecs, const uint32_t *query_terms,
+                            const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
+                            int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    int used = 1;
+    if (n_threads < 1) n_threads = 1;
+    const uint64_t total_tokens = doc_offsets[n_docs];
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+        /* per-thread scratch: one dense score array and the two ranked lists of a query */
+        float *dense = (float *)malloc((size_t)(n_docs ? n_docs : 1) * sizeof(float));
+        float *cs = (float *)malloc((size_t)depth * sizeof(float)), *bs = (float *)malloc((size_t)depth * sizeof(float));
+        uint32_t *cd = (uint32_t *)malloc((size_t)depth * sizeof(uint32_t));
+        uint32_t *bd = (uint32_t *)malloc((size_t)depth * sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int64_t q = 0; q < (int64_t)n_queries; q++) {
+            oio_dot_scores(rows, n_docs, dim, query_vecs + (size_t)q * dim, dense);
+            const uint32_t nc = oio_topk(dense, n_docs, depth, 0, 0, cs, cd);
+            oio_bm25_scores(term_ids, doc_offsets, n_docs, vocab, df, n_docs, total_tokens,
+                            query_terms + q_term_offsets[q], q_term_offsets[q + 1] - q_term_offsets[q], dense);
+            const uint32_t nb = oio_topk(dense, n_docs, depth, 1, 0, bs, bd);
+            counts_out[q] = oio_rrf_fuse(cd, nc, bd, nb, k, scores_out + (size_t)q * k, docs_out + (size_t)q * k);
+        }
+        free(dense); free(cs); free(bs); free(cd); free(bd);
+    }
+    return used;
+}

@@ -260,6 +260,20 @@ uint32_t oio_rrf_fuse(const uint32_t *docs_a, uint32_t n_a,
                       const uint32_t *docs_b, uint32_t n_b, uint32_t k,
                       float *scores_out, uint32_t *docs_out);
 
+/* A batch of hybrid queries, one after the other or on `n_threads` host threads (OpenMP over the QUERIES: every
+ * query is still the scalar single-thread pipeline above -- oio_dot_scores, oio_topk, oio_bm25_scores, oio_topk,
+ * oio_rrf_fuse -- so the results are identical for any thread count).  bench.py's cpu_baseline times this
+ * (n_threads = 1 and n_threads = all cores); tests compare it with the per-query calls.  Query q owns
+ * query_terms[q_term_offsets[q] .. q_term_offsets[q+1]).  Outputs row stride k; counts_out[q] valid entries.
+ * Returns the number of threads actually used (1 when built without OpenMP). */
+int oio_hybrid_search_batch(const float *rows, uint64_t n_docs, uint32_t dim, const uint32_t *term_ids,
+                            const uint64_t *doc_offsets, uint32_t vocab, const uint32_t *df,
+                            const float *query_vecs, const uint32_t *query_terms,
+                            const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
+                            int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+/* Host threads OpenMP would use by default (1 when built without it). */
+int oio_max_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,44 @@ def test_lexicon_device_buffers_and_summary(ctx, O):
     assert cnt2.polarity_sum == cnt.polarity_sum
 
 
+def test_sharded_analyzer_hip_shards_equal_the_oracle(ctx, O):
+    """SURVEY 8(e) row 2 on the GPU: the posts cut into 3 shards, each through the HIP scan + summary reduction, the
+    per-shard counters combined exactly as ShardedAnalyzer.summary combines the all-gathered words (the gloo test
+    covers the collective itself).  Integer fields exact; polarity_sum = the rank-order sum of the shard partials."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import sharded, synth
+    dev = torch.device("cuda:0")
+    blob, offs = synth.posts_torch(200_000, dev)
+    n = offs.numel() - 1
+    src = (torch.arange(n, device=dev) % 5 < 2).to(torch.uint8)
+    sa = sharded.make_hip_sharded_analyzer(ctx, dev)
+    whole = sa.summary(blob, offs, src)                                   # world 1
+    rpol, rspec = O.lexicon_analyze(blob.cpu().numpy(), offs.cpu().numpy().astype(np.uint64))
+    ref = O.social_summary(src.cpu().numpy(), rpol, rspec)
+    ints = lambda c: (c.total, c.by_source[0], c.by_source[1], c.bullish, c.bearish, c.neutral, c.spec_count)
+    assert ints(whole) == (n, ref.mentions_by_source[0], ref.mentions_by_source[1], ref.bullish, ref.bearish,
+                           ref.neutral, ref.spec_count)
+    bound = n * 2.0 ** -52 * max(1.0, float(np.abs(np.cumsum(rpol)).max()))
+    assert abs(whole.polarity_sum - ref.polarity_sum) <= bound
+    cuts = [0, 70_001, 70_001 + 50_000, n]                                # ragged shards, unaligned byte starts
+    parts = []
+    for lo, hi in zip(cuts, cuts[1:]):
+        b0, b1 = int(offs[lo]), int(offs[hi])
+        sb = torch.zeros(b1 - b0 + 64, dtype=torch.uint8, device=dev)     # the scan wants a 16-byte aligned blob:
+        assert sb.data_ptr() % 16 == 0                                     # a shard's text is its own allocation
+        sb[:b1 - b0] = blob[b0:b1]
+        parts.append(sa.analyze_shard(sb[:b1 - b0], (offs[lo:hi + 1] - offs[lo]).contiguous(), src[lo:hi].contiguous()))
+    tot = [sum(ints(p)[i] for p in parts) for i in range(7)]
+    assert tuple(tot) == ints(whole)
+    psum = 0.0
+    for p in parts:
+        psum += p.polarity_sum
+    assert abs(psum - ref.polarity_sum) <= bound
+    rep = oi.SpeculationEngine.aggregate_counters(oi.Ticker.parse("AAPL"), whole, None, None, oi.EngineConfig())
+    assert rep.social.total_mentions == n and rep.social.bullish == ref.bullish
+
+
 def test_full_size_lexicon_10M_posts(ctx, O):
     """10M synthetic posts in HBM (the size the lexicon figures are quoted on), through size-independent
     properties: the oracle on a slice, re-based sub-ranges (other tile boundaries, other 16-byte phase)

@@ -97,3 +97,27 @@ def test_cosine_and_hybrid_smoke_config0():
     res = O.hybrid_search(rows, terms, offs, 64, q, np.array([1, 2, 3, 4], np.uint32), k=10, depth=100)
     assert len(res["fused"][1]) == 10 and len(set(res["fused"][1].tolist())) == 10
     assert set(res["fused"][1].tolist()) <= set(res["cos"][1].tolist()) | set(res["bm25"][1].tolist())
+
+
+def test_batch_driver_equals_per_query_calls_for_any_thread_count():
+    """bench.py's cpu_baseline times oio_hybrid_search_batch on 1 and on all host threads: it must be the same scalar
+    pipeline as the per-query calls, whatever the thread count."""
+    from oracle import lib as O
+    rng = np.random.default_rng(7)
+    n, dim, vocab, B, depth, k = 1500, 24, 40, 9, 60, 15
+    rows = O.l2_normalize_rows(rng.standard_normal((n, dim)).astype(np.float32))
+    lens = rng.integers(1, 9, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32)
+    q = O.l2_normalize_rows(rng.standard_normal((B, dim)).astype(np.float32))
+    qt = rng.integers(0, vocab, size=B * 3).astype(np.uint32)
+    qo = (np.arange(B + 1) * 3).astype(np.uint32)
+    outs = [O.hybrid_search_batch(rows, terms, offs, vocab, q, qt, qo, k, depth, n_threads=t) for t in (1, 2, 5)]
+    assert outs[0][3] == 1 and outs[1][3] in (1, 2)
+    for s, d, c, _ in outs:
+        for b in range(B):
+            fs, fd = O.hybrid_search(rows, terms, offs, vocab, q[b], qt[qo[b]:qo[b + 1]], k, depth)["fused"]
+            assert c[b] == fd.size and np.array_equal(d[b, :fd.size], fd)
+            assert np.array_equal(s[b, :fs.size].view(np.uint32), fs.view(np.uint32))
+    assert O.max_threads() >= 1

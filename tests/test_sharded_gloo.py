@@ -129,11 +129,20 @@ def _free_port():
 
 
 def test_shard_bounds_cover_and_align():
-    for n, w in ((10_000_000, 8), (1001, 3), (7, 8), (12_500_000, 8)):
+    for n, w in ((10_000_000, 8), (1001, 3), (29, 8), (12_500_000, 8), (1, 1)):
         edges = [shard_bounds(n, w, r) for r in range(w)]
         assert edges[0][0] == 0 and edges[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
-        assert all(lo % 4 == 0 for lo, hi in edges if hi > lo)
+        assert all(lo % 4 == 0 and hi > lo for lo, hi in edges)
+
+
+def test_shard_bounds_refuse_empty_shards_on_every_rank():
+    """10 rows over 8 ranks in 4-row blocks would leave ranks 3..7 empty (an index shard needs a row): every rank
+    must fail the same way BEFORE any collective, or the others hang in all_reduce."""
+    for n, w in ((10, 8), (7, 8), (0, 2), (4, 2)):
+        for r in range(w):
+            with pytest.raises(ValueError):
+                shard_bounds(n, w, r)
 
 
 @pytest.mark.timeout(180)
@@ -155,3 +164,60 @@ def test_two_ranks_match_unsharded_oracle(packed):
             assert np.array_equal(d[b, :fd.size].astype(np.uint32), fd)
             assert np.array_equal(s[b, :fs.size].view(np.uint32), fs.view(np.uint32))
     assert np.array_equal(ret[0][1], ret[1][1])              # every rank holds the same answer
+
+
+# ------------------------------------------------------------------ the sharded lexicon path
+def _posts(n, seed):
+    rng = np.random.default_rng(seed)
+    words = ["moon", "buy", "calls", "puts", "crash", "dump", "squeeze", "yolo", "hold", "the", "a", "stock", "AAPL",
+             "bullish", "bearish", "rocket", "short", "long", "sell", "tendies", "bull", "bear", "up", "down"]
+    texts = [" ".join(rng.choice(words, size=rng.integers(1, 25))) for _ in range(n)]
+    src = rng.integers(0, 2, size=n).astype(np.uint8)
+    return texts, src
+
+
+def _oracle_counters(texts, src):
+    blob, offs = O.pack_texts(texts)
+    pol, spec = O.lexicon_analyze(blob, offs)
+    return O.social_summary(src, pol, spec), pol, spec
+
+
+class _Counters:
+    def __init__(self, s):
+        self.total, self.bullish, self.bearish, self.neutral = s.total_mentions, s.bullish, s.bearish, s.neutral
+        self.spec_count, self.polarity_sum = s.spec_count, s.polarity_sum
+        self.by_source = list(s.mentions_by_source)
+
+
+def _analyzer_worker(rank, world, port, ret, n):
+    from openintel_amd.sharded import ShardedAnalyzer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        texts, src = _posts(n, 77)
+        lo, hi = rank * n // world, (rank + 1) * n // world      # posts shard anywhere (no alignment rule)
+        sa = ShardedAnalyzer(lambda t, s: _Counters(_oracle_counters(t, s)[0]), torch.device("cpu"))
+        g = sa.summary(texts[lo:hi], src[lo:hi])
+        ret[rank] = (g.total, g.by_source[0], g.by_source[1], g.bullish, g.bearish, g.neutral, g.spec_count,
+                     g.polarity_sum)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("n", [10, 4001])
+def test_two_ranks_lexicon_summary_matches_unsharded_oracle(n, golden):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_analyzer_worker, args=(world, _free_port(), ret, n), nprocs=world, join=True)
+    texts, src = _posts(n, 77)
+    ref, pol, _ = _oracle_counters(texts, src)
+    assert ret[0] == ret[1], "every rank must hold the same global counters, bit for bit"
+    g = ret[0]
+    assert g[:7] == (ref.total_mentions, ref.mentions_by_source[0], ref.mentions_by_source[1], ref.bullish, ref.bearish,
+                     ref.neutral, ref.spec_count)                                   # integer fields: exact
+    half = _oracle_counters(texts[:n // 2], src[:n // 2])[0].polarity_sum
+    rest = _oracle_counters(texts[n // 2:], src[n // 2:])[0].polarity_sum
+    assert g[7] == half + rest                                                      # rank-order sum of the partials
+    assert abs(g[7] - ref.polarity_sum) <= n * 2.0 ** -52 * max(1.0, float(np.abs(np.cumsum(pol)).max()))
