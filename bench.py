@@ -260,12 +260,11 @@ def main():
         # dominant kernel: the cosine scorer.  Algorithmic work per step on this rank
         # (SURVEY.md 8d): flops = 2 * n_local * d * B, bytes = n_local * d * 4 (corpus read once per batch)
         flops_step = 2.0 * n_local * args.dim * args.batch
-        bytes_step = 4.0 * n_local * args.dim
-        if args.corpus == "bf16":  # 2 B per element, one corpus pass per 64 queries (32 at d = 1024)
-            group = 32 if args.dim == 1024 else 64
-            bytes_step = 2.0 * n_local * args.dim * ((args.batch + group - 1) // group)
-        if args.corpus == "f32" and args.cosine == "screen":  # the screen reads the corpus once per 64 queries
-            bytes_step *= (args.batch + 63) // 64
+        # ALGORITHMIC bytes: the corpus is read once per batch, whatever the kernel does.  A scorer that
+        # keeps the queries in registers takes one corpus pass per 64 queries (bf16 corpus, d = 1024: 64 per pass of
+        # the pair kernel): its extra passes are re-reads and count AGAINST it here (frac falls), never for it.
+        bytes_step = (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim
+        passes = (args.batch + 63) // 64 if args.batch > 8 else 1
         cos_s = cos_ms / 1e3
         if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
@@ -288,7 +287,11 @@ def main():
             except Exception:
                 pass
         roof["kernel"] = "cosine scorer (all corpus-chunk launches of a batch)"
-        if args.cosine == "screen" and roof["bound"] == "hbm" and args.batch > 8:
+        if args.corpus == "bf16":
+            roof["kernel"] = "cosine over the bf16 corpus (bf16 MFMA, all corpus-chunk launches of a batch)"
+        roof["corpus_passes_per_batch"] = passes
+        roof["hbm_GBs_streamed"] = bytes_step * passes * args.steps / (cos_ms / 1e3) / 1e9
+        if args.cosine == "screen" and roof["bound"] == "hbm" and args.batch > 8 and args.corpus == "f32":
             roof["kernel"] = "cosine screen (bf16 MFMA over the f32 corpus, all corpus-chunk launches of a batch)"
         roof["launches_per_step"] = cos_launches / max(1, args.steps)
         roof["avg_launch_ms"] = cos_ms / max(1, cos_launches)

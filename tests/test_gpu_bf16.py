@@ -129,3 +129,53 @@ def test_bf16_device_tensor_and_errors(ctx, O):
     with pytest.raises(_lib.OiError):
         bad.set_embeddings_bf16(np.zeros((100, 96), np.uint16))
     bad.close()
+
+
+def test_full_size_config4_shard_12_5M_1024_bf16_batch256(ctx):
+    """BASELINE configs[4] as ONE GPU of the 8 sees it: a 12.5M-row x 1024-d bf16 shard (25.6 GB), batch 256, depth
+    1000 -> RRF top-100, with a nonzero doc_id_base.  Size-independent properties: planted copies of the (bf16-
+    rounded) queries come back first with the planted score, full sorted lists of in-range unique ids, idempotence,
+    and three queries spot-checked against dense torch scores of the rows as stored."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k, base = 12_500_000, 1024, 256, 1000, 100, 37_500_000   # shard 3 of 8 of the 100M corpus
+    rows = torch.empty((n, dim), dtype=torch.bfloat16, device=dev)
+    step = 2_500_000
+    for r in range(0, n, step):                         # generated in slices: the f32 staging stays at 10 GB
+        rows[r:r + step] = synth.embeddings_torch(step, dim, dev, seed=synth.SEED_EMB + r).to(torch.bfloat16)
+    qv, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=4096)
+    qb = qv.to(torch.bfloat16)                          # what the kernel multiplies with
+    plant = torch.arange(B, device=dev) * (n // B) + 29
+    rows[plant] = qb
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    idx = oi.HybridIndex(ctx, n, dim, 4096, doc_id_base=base)
+    idx.set_embeddings_bf16(rows)
+    idx.set_forward(terms, offs)
+    idx.set_max_query_terms(4)
+    idx.finalize()
+    del terms, offs
+    L = idx.search_lists(qv, qt, qo, depth=depth)
+    ctx.synchronize()
+    cs, cd, cc = L.cos_scores.cpu().numpy(), L.cos_docs.cpu().numpy().astype(np.int64), L.cos_counts.cpu().numpy()
+    assert (cc == depth).all() and cd.min() >= base and cd.max() < base + n
+    self_score = (qb.float() * qb.float()).sum(1).cpu().numpy()
+    assert np.array_equal(cd[:, 0], plant.cpu().numpy() + base)
+    assert np.abs(cs[:, 0] - self_score).max() < 1e-5
+    assert (np.diff(cs, axis=1) <= 0).all()
+    assert all(np.unique(cd[b]).size == depth for b in range(0, B, 17))
+    bs, bc = L.bm25_scores.cpu().numpy(), L.bm25_counts.cpu().numpy()
+    assert (bc == depth).all() and (np.diff(bs, axis=1) <= 0).all() and (bs > 0).all()
+    R1 = idx.search(qv, qt, qo, k=k, depth=depth)
+    R2 = idx.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    assert torch.equal(R1.docs, R2.docs) and torch.equal(R1.scores, R2.scores) and bool((R1.counts == k).all())
+    for b in (0, 100, 255):
+        # (the whole matrix in f32 would be 51 GB: scored in slices)
+        ref = torch.cat([(rows[r:r + step].float() @ qb[b].float()) for r in range(0, n, step)]).cpu().numpy().astype(np.float64)
+        d = cd[b] - base
+        assert np.abs(cs[b].astype(np.float64) - ref[d]).max() <= COS_TOL
+        kth = np.sort(ref)[::-1][depth - 1]
+        assert np.isin(np.nonzero(ref > kth + 2 * COS_TOL)[0], d).all() and (ref[d] >= kth - 2 * COS_TOL).all()
+    idx.close()

@@ -575,3 +575,40 @@ def test_full_size_two_shards_equal_one(ctx, O):
 
 def test_full_size_config2_10M_768_batch64(ctx):
     _planted_check(ctx, 10_000_000, 768, 64, 100, 100)   # BASELINE.json configs[2]
+
+
+def test_full_size_config3_shard_through_sharded_retriever(ctx, O):
+    """BASELINE configs[3] as ONE GPU of the 8 sees it: a 1.25M-row x 768-d f32 shard with a nonzero doc_id_base,
+    driven through ShardedRetriever (world 1: finalize's statistics exchange and the packed list format are the
+    real code path, the all-gather degenerates to the local buffer).  The fused result must equal oi_search on the
+    same index bit for bit; planted copies of the queries come back first; every id is a global one."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import sharded, synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k, base = 1_250_000, 768, 64, 1000, 100, 3_750_000
+    rows = synth.embeddings_torch(n, dim, dev)
+    qv, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=131072)
+    plant = torch.arange(B, device=dev) * (n // B) + 5
+    rows[plant] = qv
+    terms, offs = synth.forward_index_torch(n, dev, vocab=131072)
+    idx = oi.HybridIndex(ctx, n, dim, 131072, doc_id_base=base)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.set_max_query_terms(4)
+    sr = sharded.make_hip_sharded(ctx, idx, dev)
+    sr.finalize()
+    s1, d1, c1 = sr.search(qv, qt, qo, k, depth)
+    R = idx.search(qv, qt, qo, k=k, depth=depth)
+    ctx.synchronize()
+    assert torch.equal(d1, R.docs) and torch.equal(s1, R.scores) and torch.equal(c1, R.counts)
+    d = d1.cpu().numpy().astype(np.int64)
+    assert (c1.cpu().numpy() == k).all() and d.min() >= base and d.max() < base + n
+    L = idx.search_lists(qv, qt, qo, depth=depth)
+    ctx.synchronize()
+    cd, cs = L.cos_docs.cpu().numpy().astype(np.int64), L.cos_scores.cpu().numpy()
+    assert np.array_equal(cd[:, 0], plant.cpu().numpy() + base) and np.abs(cs[:, 0] - 1.0).max() < 1e-5
+    for b in range(3):
+        full = (rows @ qv[b]).cpu().numpy()
+        _check_cos_list(cs[b], cd[b], depth, full, depth, doc_base=base)
+    idx.close()
