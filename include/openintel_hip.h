@@ -204,8 +204,10 @@ int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df
 int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                       const uint32_t *global_df_host);
 
-/* BM25 kernel choice: 0 = default (term-at-a-time over the blocked inverted index), 1 = term-at-a-time,
- * 2 = batch scan of the forward index (bm25_scan.hip).  All produce bit-identical lists. */
+/* BM25 kernel choice: 0 = default (= 3), 1 = term-at-a-time with one workgroup per doc block (bm25.hip, the
+ * first-generation kernel), 2 = batch scan of the forward index (bm25_scan.hip), 3 = term-at-a-time with one wave
+ * per (doc block, query) task (bm25_wave.hip).  All produce bit-identical lists.  OI_BM25_MODE=wave|taat|scan
+ * selects the default process-wide. */
 int oi_index_set_bm25_mode(oi_index *idx, int mode);
 
 /* Contract for the batch BM25 scan (mode 2): no query of a batch has more

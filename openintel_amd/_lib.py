@@ -10,6 +10,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libopenintel_hip.so")
+if os.environ.get("OI_LIB") == "ablation":   # tools/ only: the -DOI_ABLATION build (tools/build_ablation.sh)
+    LIB_PATH = os.path.join(HERE, "libopenintel_hip_ablation.so")
 
 OI_HOST, OI_DEVICE = 0, 1
 OI_MAX_DEPTH = 1024

@@ -436,7 +436,7 @@ extern "C" int oi_index_set_max_query_terms(oi_index *idx, uint32_t max_terms) {
 
 extern "C" int oi_index_set_bm25_mode(oi_index *idx, int mode) {
     if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(mode >= 0 && mode <= 2, "bm25 mode %d outside [0,2]", mode);
+    OI_REQUIRE(mode >= 0 && mode <= 3, "bm25 mode %d outside [0,3]", mode);
     std::lock_guard<std::mutex> g(idx->ctx->mu);
     idx->bm25_mode = mode;
     return OI_OK;
@@ -551,15 +551,51 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         hipStream_t st = ctx->stream; // (the side stream when the legs overlap)
         (void)st;
         OI_REQUIRE(idx->finalized, "search: index not finalized");
-        // Which BM25 kernel: the term-at-a-time kernel is the default for every batch size (0.61 ms per
-        // 64-query batch at 10M docs; the forward scan draws level at 0.62 ms and loses at larger batches);
-        // the scan is selected per index (oi_index_set_bm25_mode) or process-wide with OI_BM25_MODE=scan.
-        static const char *mode_env = getenv("OI_BM25_MODE"); // "taat" | "scan"
+        // Which BM25 kernel.  Default: term-at-a-time with one WAVE per (block, query) task (bm25_wave.hip).  The
+        // first-generation workgroup-per-block kernel (bm25.hip) and the batch scan of the forward index
+        // (bm25_scan.hip) stay selectable per index (oi_index_set_bm25_mode) or process-wide with
+        // OI_BM25_MODE=wave|taat|scan; all three return bit-identical lists.
+        static const char *mode_env = getenv("OI_BM25_MODE");
+        int mode = idx->bm25_mode;
+        if (mode == 0 && mode_env) mode = strcmp(mode_env, "scan") == 0 ? 2 : strcmp(mode_env, "taat") == 0 ? 1 : 3;
+        if (mode == 0) mode = 3;
         const bool have_fwd = idx->fwd_terms.p && idx->total_tokens > 0;
-        const bool want_scan = idx->bm25_mode == 2 || (idx->bm25_mode == 0 && mode_env && strcmp(mode_env, "scan") == 0);
-        const bool scan = have_fwd && want_scan;
+        const bool scan = have_fwd && mode == 2;
+        if (!scan && mode != 1) {
+            // Two phases like the cosine chunks: the first eighth of the doc blocks is scored with no threshold
+            // (every touched doc is a candidate) and fixes tau_q = the depth-th score so far, a lower bound of
+            // the final one; the remaining blocks emit only scores >= tau_q.  A task's pool segment holds a whole
+            // block, so nothing can overflow; the room is address space, not traffic (only emitted keys are
+            // written).  Queries go in passes sized from a 6 GiB pool budget.
+            const uint32_t nb = idx->n_blocks;
+            if (nb == 0 || idx->n_postings == 0) {
+                OI_HIP_CHECK(hipMemsetAsync(bm_c, 0, sizeof(uint32_t) * B, st));
+                return OI_OK;
+            }
+            const uint64_t wstride = (uint64_t)carry_cap + (uint64_t)nb * OI_BM25_BLOCK_DOCS;
+            uint64_t pass = (6ull << 30) / 8 / wstride;
+            pass = std::max<uint64_t>(1, std::min<uint64_t>(pass, std::min<uint32_t>(B, oi_bm25_wave_pass_queries())));
+            DevBuf &wp = ctx->buf("pool_bm_wave"), &wc = ctx->buf("pool_bm_wave_state");
+            OI_CHECK(wp.ensure(sizeof(uint64_t) * (size_t)pass * wstride));
+            const size_t wwords = (size_t)pass * (2 + nb);
+            OI_CHECK(wc.ensure(sizeof(uint32_t) * wwords));
+            const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / 8) : nb;
+            for (uint32_t q0 = 0; q0 < B; q0 += (uint32_t)pass) {
+                const uint32_t nq = std::min<uint32_t>((uint32_t)pass, B - q0);
+                OI_HIP_CHECK(hipMemsetAsync(wc.p, 0, sizeof(uint32_t) * wwords, st));
+                uint32_t *w = wc.as<uint32_t>();
+                PoolView W{wp.as<uint64_t>(), w, w + 2 * (size_t)pass, w + pass, wstride, carry_cap, OI_BM25_BLOCK_DOCS, nb, nb, P.bm.overflow};
+                OI_CHECK(oi_launch_bm25_wave(idx, d_qt, d_qo, q0, nq, W, 0, first));
+                if (first < nb) {
+                    OI_CHECK(oi_launch_select(ctx, W, nq, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth));
+                    OI_CHECK(oi_launch_bm25_wave(idx, d_qt, d_qo, q0, nq, W, first, nb));
+                }
+                OI_CHECK(oi_launch_select(ctx, W, nq, depth, false, bm_s + (size_t)q0 * depth, bm_d + (size_t)q0 * depth, bm_c + q0, depth));
+            }
+            return OI_OK;
+        }
         if (!scan) {
-            // Term-at-a-time over the blocked inverted index.  Two phases, like the cosine chunks: the
+            // Term-at-a-time, one WORKGROUP per doc block (the first-generation kernel).  Two phases, like the cosine chunks: the
             // first eighth of the doc blocks fixes a per-query threshold (the depth-th score seen so far
             // is a lower bound of the final one); the remaining blocks then emit only candidates at or
             // above it, so the final selection scans little.

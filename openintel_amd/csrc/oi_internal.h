@@ -147,7 +147,8 @@ struct oi_index {
     DevBuf fwd_offsets; // u64 per doc + 1
     float avgdl = 0.f;  // global average doc length fixed at finalize
     uint32_t max_query_terms = 16; // contract for the batch-scan path (oi_index_set_max_query_terms)
-    int bm25_mode = 0;             // 0 default (term-at-a-time unless OI_BM25_MODE=scan), 1 term-at-a-time, 2 scan
+    int bm25_mode = 0;             // 0 default (= 3 unless OI_BM25_MODE says otherwise), 1 term-at-a-time per workgroup (bm25.hip),
+                                   // 2 scan of the forward index (bm25_scan.hip), 3 term-at-a-time per wave (bm25_wave.hip)
 };
 
 // ---------------------------------------------------------------- kernels (host launchers)
@@ -242,6 +243,10 @@ uint32_t oi_bm25_scan_pass_queries(uint32_t max_terms_per_query);
 int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
                         uint32_t nq, uint64_t doc_begin, uint64_t doc_end, float avgdl, bool run_setup,
                         const PoolView &pool);
+// bm25_wave.hip: one wave per (block, query) task; `pool` = the view of queries [q_begin, q_begin + nq)
+uint32_t oi_bm25_wave_pass_queries(void);
+int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
+                        uint32_t nq, const PoolView &pool, uint32_t block_begin, uint32_t block_end);
 // Doc blocks [block_begin, block_end); candidates below pool.tau_keys (if set) are dropped.
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
                    uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,

@@ -131,10 +131,11 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
 
-    BM25_DEFAULT, BM25_TAAT, BM25_SCAN = 0, 1, 2
+    BM25_DEFAULT, BM25_TAAT, BM25_SCAN, BM25_WAVE = 0, 1, 2, 3
 
     def set_bm25_mode(self, mode: int) -> None:
-        """BM25_TAAT (term-at-a-time, the default) or BM25_SCAN (batch scan of the forward index)."""
+        """BM25_WAVE (term-at-a-time, one wave per (block, query) task: the default), BM25_TAAT (the first-generation
+        workgroup-per-block kernel) or BM25_SCAN (batch scan of the forward index).  Bit-identical lists."""
         _lib.check(self.lib.oi_index_set_bm25_mode(self.handle, int(mode)))
 
     def set_max_query_terms(self, max_terms: int) -> None:

@@ -386,15 +386,65 @@ def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
     qt, qo = oi.pack_query_terms(queries)
     q = rng.integers(-2, 3, size=(B, 8)).astype(np.float32)
     L = idx.search_lists(q, qt, qo, depth=depth)
-    idx.set_bm25_mode(idx.BM25_TAAT)
-    L2 = idx.search_lists(q, qt, qo, depth=depth)
-    assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
+    for other in (idx.BM25_TAAT, idx.BM25_WAVE):     # the three kernels agree bit for bit
+        idx.set_bm25_mode(other)
+        L2 = idx.search_lists(q, qt, qo, depth=depth)
+        assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
+        assert np.array_equal(L.bm25_counts, L2.bm25_counts)
     for b, tb in enumerate(queries):
         tv = np.array([t for t in tb if t < vocab], np.uint32)
         bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, 77)
         assert int(L.bm25_counts[b]) == bd.size, (b, tb)
         assert np.array_equal(L.bm25_docs[b][:bd.size], bd), (b, tb)
         assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), (b, tb)
+    idx.close()
+
+
+@pytest.mark.parametrize("case", ["every-doc-term", "long-queries", "clustered"])
+def test_bm25_wave_kernel_windows_and_long_queries(ctx, O, case):
+    """bm25_wave.hip off its happy path: a term in EVERY doc (32768 postings per block: the 2048-slot table is cut into
+    doc-id windows), queries of 70..200 terms (term groups beyond the 64 a wave keeps in registers; more than 2048
+    staged terms per pass), and docs clustered at the start of a block (windows halve unevenly).  Same bits as the
+    oracle and as the workgroup-per-block kernel."""
+    import openintel_amd as oi
+    rng = np.random.default_rng(len(case))
+    n, vocab, depth = 100_000, 400, 300
+    lens = rng.integers(1, 12, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(2, vocab, size=int(offs[-1])).astype(np.uint32)
+    if case == "every-doc-term":
+        terms[offs[:-1].astype(np.int64)] = 0                       # term 0 in every doc
+        terms[offs[:-1].astype(np.int64)[lens > 1] + 1] = 1          # term 1 in most docs
+        queries = [[0], [0, 1], [1, 0, 5], [0, 0], [7, 0, 9, 1]] + [rng.integers(0, 40, size=4).tolist() for _ in range(11)]
+    elif case == "long-queries":
+        queries = [rng.integers(0, vocab + 5, size=int(k)).tolist() for k in (70, 128, 200, 65, 64, 1, 0, 150)] + \
+                  [rng.integers(0, vocab, size=150).tolist() for _ in range(12)]   # 20 queries, > 2048 terms in the pass
+    else:
+        first = offs[:-1].astype(np.int64)
+        sel = first[(np.arange(n) % 32768) < 3000]                   # term 3 only in the first 3000 docs of each block
+        terms[terms == 3] = 4
+        terms[sel] = 3
+        queries = [[3], [3, 4], [4, 3, 3], [3, 10, 11, 12]] + [rng.integers(2, 30, size=5).tolist() for _ in range(12)]
+    rows = rng.integers(-2, 3, size=(n, 8)).astype(np.float32)
+    idx = oi.HybridIndex(ctx, n, 8, vocab, doc_id_base=5)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    qt, qo = oi.pack_query_terms(queries)
+    q = rng.integers(-2, 3, size=(len(queries), 8)).astype(np.float32)
+    idx.set_bm25_mode(idx.BM25_WAVE)
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    idx.set_bm25_mode(idx.BM25_TAAT)
+    L2 = idx.search_lists(q, qt, qo, depth=depth)
+    assert np.array_equal(L.bm25_counts, L2.bm25_counts)
+    assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
+    for b, tb in enumerate(queries):
+        tv = np.array([t for t in tb if t < vocab], np.uint32)
+        bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, 5)
+        assert int(L.bm25_counts[b]) == bd.size, (b, len(tb))
+        assert np.array_equal(L.bm25_docs[b][:bd.size], bd), (b, len(tb))
+        assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), (b, len(tb))
     idx.close()
 
 

@@ -33,7 +33,10 @@ idx.finalize()
 qv, qt, qo = synth.query_batch_torch(B, DIM, dev)
 res = {}
 lists = {}
-for name, mode in (("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN)):
+MODES = (("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN))
+if len(sys.argv) > 4 and sys.argv[4] == "wave-only":   # tools/bm25_wave_ablate.sh
+    MODES = MODES[:1]
+for name, mode in MODES:
     idx.set_bm25_mode(mode)
     for _ in range(2):
         r = idx.search_lists(qv, qt, qo, depth=DEPTH)
@@ -46,7 +49,19 @@ for name, mode in (("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN)):
     ctx.profile_reset(False)
     res[name] = {"ms_per_batch": ms / reps, "launches_per_batch": launches / reps}
     lists[name] = (r.bm25_docs.clone(), r.bm25_scores.clone(), r.bm25_counts.clone())
-same = all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["scan"]))
+if len(MODES) == 1:
+    print(json.dumps({"docs": n, "batch": B, **res}))
+    sys.exit(0)
+same = all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["scan"])) and \
+    all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["wave"]))
+# algorithmic bytes of term-at-a-time: 8 B per posting of the batch's terms + 8 B per (block, term) bounds lookup
+df = idx.local_stats()[1].astype("int64")
+qt_h = qt.cpu().numpy()
+taat_bytes = int(8 * df[qt_h].sum() + 8 * ((n + 32767) // 32768) * qt_h.size)
+for k in ("wave", "taat"):
+    res[k]["algorithmic_bytes"] = taat_bytes
+    res[k]["algorithmic_GBs"] = taat_bytes / (res[k]["ms_per_batch"] / 1e3) / 1e9
+    res[k]["frac_of_8TBs"] = res[k]["algorithmic_GBs"] / 8000.0
 scan_bytes = 4 * n_tokens + 8 * (n + 1)
 res["scan"]["algorithmic_GBs"] = scan_bytes / (res["scan"]["ms_per_batch"] / 1e3) / 1e9
 res["scan"]["frac_of_8TBs"] = res["scan"]["algorithmic_GBs"] / 8000.0

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build an ABLATION copy of the library (A/B switches, diagnostic timing builds) next to the product one:
+#   openintel_amd/libopenintel_hip_ablation.so ; use it with OI_LIB=ablation (tools only; never the tests/bench).
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+mkdir -p $R/openintel_amd/csrc/_obj_abl
+cd $R/openintel_amd/csrc/_obj_abl
+for f in $R/openintel_amd/csrc/*.hip; do
+  o=$(basename ${f%.hip}).o
+  if [ ! -f $o ] || [ $f -nt $o ] || [ $R/openintel_amd/csrc/oi_internal.h -nt $o ]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DOI_ABLATION -Wno-unused-result -I$R/include -I$R/openintel_amd/csrc -c $f -o $o &
+  fi
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/openintel_amd/libopenintel_hip_ablation.so *.o
+echo built $R/openintel_amd/libopenintel_hip_ablation.so
