@@ -477,8 +477,9 @@ struct Pools {
 
 // State of both pools in one block, zeroed with ONE memset per search:
 //   cosine: carry_cnt[B] tau[B] seg_cnt[B][CUs]      BM25: carry_cnt[B] seg_cnt[B][n_blocks]
+// `extra_words` more zeroed words follow them (*extra): the bf16 screen's state, so that one memset kernel does both.
 int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_cap, uint32_t bm_blocks,
-                  uint32_t depth, Pools *out) {
+                  uint32_t depth, Pools *out, size_t extra_words = 0, uint32_t **extra = nullptr) {
     DevBuf &flag = ctx->buf("state_flag");
     if (!flag.p) {
         OI_CHECK(flag.ensure(16));
@@ -488,8 +489,9 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
     const uint32_t bm_segs = bm_blocks ? bm_blocks : 1;
     const size_t words = (size_t)B * (2 + cos_segs + 2 + bm_segs);
     DevBuf &st = ctx->buf("pool_state");
-    OI_CHECK(st.ensure(sizeof(uint32_t) * words));
-    OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * words, ctx->stream));
+    OI_CHECK(st.ensure(sizeof(uint32_t) * (words + extra_words)));
+    OI_HIP_CHECK(hipMemsetAsync(st.p, 0, sizeof(uint32_t) * (words + extra_words), ctx->stream));
+    if (extra) *extra = st.as<uint32_t>() + words;
     const uint64_t bm_stride = (uint64_t)carry_cap + (uint64_t)bm_segs * depth;
     DevBuf &pc = ctx->buf("pool_cos"), &pb = ctx->buf("pool_bm");
     OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_stride));
@@ -539,7 +541,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     if (cos_stride < carry_cap + 4 * slack) cos_stride = carry_cap + 4 * slack;
     if (cos_stride > carry_cap + n + slack) cos_stride = carry_cap + n + slack;
     Pools P;
-    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, idx->n_blocks, depth, &P));
+    // the bf16 screen's state words (carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][CUs]) ride in the same memset
+    const size_t screen_words = (size_t)B * (4 + (size_t)ctx->num_cus) + 4;
+    uint32_t *screen_state = nullptr;
+    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, idx->n_blocks, depth, &P, screen_words, &screen_state));
 
     // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
@@ -735,15 +740,13 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             const uint32_t segs = (uint32_t)ctx->num_cus;
             // state, zeroed with one memset: carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][segs]
             const size_t words = (size_t)B * (4 + segs) + 4;
-            DevBuf &ps = ctx->buf("screen_state"), &pk = ctx->buf("screen_pool"), &rk = ctx->buf("screen_rescored"),
-                   &qb = ctx->buf("screen_q_bf16");
-            OI_CHECK(ps.ensure(sizeof(uint32_t) * words));
+            DevBuf &pk = ctx->buf("screen_pool"), &rk = ctx->buf("screen_rescored"), &qb = ctx->buf("screen_q_bf16");
+            OI_REQUIRE(words <= screen_words, "search: screen state does not fit its reservation");
             OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * pf_stride));
             OI_CHECK(rk.ensure(sizeof(uint64_t) * (size_t)B * pf_carry));
             const uint32_t n_padded = (B + 31u) & ~31u;
             OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 64) * idx->dim));
-            OI_HIP_CHECK(hipMemsetAsync(ps.p, 0, sizeof(uint32_t) * words, st));
-            uint32_t *w = ps.as<uint32_t>();
+            uint32_t *w = screen_state; // zeroed with the pool state (prepare_pools)
             uint32_t *pf_cnt = w, *pf_tau = w + B, *rs_cnt = w + 2 * (size_t)B;
             float *eps2 = reinterpret_cast<float *>(w + 3 * (size_t)B);
             uint32_t *gate = w + 4 * (size_t)B, *pf_seg = gate + 4;
