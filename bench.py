@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--depth", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=131072)
-    ap.add_argument("--bm25", choices=["taat", "scan"], default="taat", help="BM25 kernel (default: term-at-a-time)")
+    ap.add_argument("--bm25", choices=["wave", "taat", "scan"], default="wave",
+                    help="BM25 kernel (default wave: term-at-a-time, one wave per task; taat: the first-generation workgroup kernel)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
     ap.add_argument("--cosine", choices=["screen", "exact", "split"], default="screen",
@@ -147,12 +148,13 @@ def main():
         idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
     idx.set_forward(terms, offs)
     idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
-    idx.set_bm25_mode(idx.BM25_SCAN if args.bm25 == "scan" else idx.BM25_TAAT)
+    idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE}[args.bm25])
     n_tokens_local = int(offs[-1].item())
     del terms, offs
     torch.cuda.empty_cache()
     sr = sharded.make_hip_sharded(ctx, idx, dev)
     sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
+    _, df_local = idx.local_stats()                    # for the BM25 leg's algorithmic bytes (rank 0 reports)
     # Distinct query batches rotated through the steps (step i uses batch i mod NB): no step can profit from the
     # previous step's thresholds, pools or cache contents being those of the same queries.
     NB = max(1, args.query_batches)
@@ -160,6 +162,13 @@ def main():
                for i in range(NB)]
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
+    bm25_bytes = None
+    if args.bm25 != "scan":   # mean over the rotated batches of 8 B x (postings of the batch's terms) + 8 B x blocks x terms
+        n_blocks = (n_local + 32767) // 32768
+        per = [8.0 * float(df_local[b[1].cpu().numpy()].astype("int64").sum()) + 8.0 * n_blocks * int(b[1].numel()) for b in batches]
+        bm25_bytes = sum(per) / len(per)
+    else:
+        bm25_bytes = 4.0 * n_tokens_local + 8.0 * (n_local + 1)
 
     out = oi.SearchResult(torch.zeros((args.batch, args.k), dtype=torch.float32, device=dev),
                           torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
@@ -329,6 +338,17 @@ def main():
                                               note="from the %d serialised steps, not the timed region" % iso_steps),
             "build_s": t_build,
         }
+        # BM25 leg: term-at-a-time reads 8 B per posting of the batch's terms + 8 B per (doc block, term) bounds
+        # lookup; its kernels' time comes from the serialised steps above (the leg runs beside the cosine leg otherwise).
+        if bm25_bytes is not None and other["bm25"][0] > 0:
+            bm_ms = other["bm25"][0] / iso_steps
+            line["bm25_roofline"] = {"bound": "hbm", "achieved": bm25_bytes / (bm_ms / 1e3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": bm25_bytes / (bm_ms / 1e3) / 1e9 / PEAK_HBM_GBS, "kernel_ms_per_step": bm_ms,
+                                     "launches_per_step": other["bm25"][1] / iso_steps, "algorithmic_bytes_per_step": bm25_bytes,
+                                     "kernel": "bm25_wave_kernel (term-at-a-time, one wave per (doc block, query) task)" if args.bm25 == "wave"
+                                               else "bm25 (%s)" % args.bm25,
+                                     "note": "algorithmic bytes = 8 B x postings of the batch's terms + 8 B x (blocks x terms); at this "
+                                             "batch size the kernel is latency/issue-bound, not byte-bound (DESIGN 4.3)"}
         if exact_side is not None:
             line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring, bound hbm; "
                                      "round 2: error bound re-derived from measured rounding errors and adversarially tested, "

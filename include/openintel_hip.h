@@ -137,6 +137,16 @@ int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts,
                       const double *polarity, const uint8_t *speculative, uint64_t n_signals,
                       double bull_bear_threshold, int location, oi_social_counters *out_host);
 
+/* LexiconAnalyzer::analyze and the two loops of social_summary in ONE pass over the text (lexicon.rs:53-87 +
+ * speculation_engine.rs:76-97): the per-post signals are reduced where they are computed, so with
+ * d_polarity_out == d_speculative_out == NULL nothing per post is written at all ("0 out if fused
+ * with the A4 reduction").  Buffers in HBM; d_sources (0 = reddit, 1 = bluesky) may be NULL; the outputs, when
+ * given, are exactly oi_lexicon_analyze_device's.  Integer fields exact; polarity_sum a fixed-shape tree sum
+ * (bitwise reproducible; same bound as oi_social_summary's).  Synchronises the ctx stream (the sums come back). */
+int oi_lexicon_summary_device(oi_ctx *ctx, const uint8_t *d_text_blob, const uint64_t *d_offsets, uint64_t n_posts,
+                              uint64_t blob_bytes, const uint8_t *d_sources, double bull_bear_threshold,
+                              double *d_polarity_out, uint8_t *d_speculative_out, oi_social_counters *out_host);
+
 /* ------------------------------------------------------------------------- */
 /* Headline gate (src/domain/dip.rs:204-272)                                   */
 /* ------------------------------------------------------------------------- */

@@ -207,6 +207,17 @@ extern "C" int oi_lexicon_analyze_device(oi_ctx *ctx, const uint8_t *d_blob, con
     return oi_launch_lexicon(ctx, d_blob, d_offsets, n, blob_bytes, d_pol, d_spec);
 }
 
+extern "C" int oi_lexicon_summary_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                                         uint64_t blob_bytes, const uint8_t *d_sources, double tau, double *d_pol,
+                                         uint8_t *d_spec, oi_social_counters *out) {
+    if (!ctx || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (n == 0) { memset(out, 0, sizeof(*out)); return OI_OK; }
+    OI_REQUIRE(d_offsets && (d_blob || blob_bytes == 0), "lexicon summary: null buffer");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    return oi_launch_lexicon_fused(ctx, d_blob, d_offsets, n, blob_bytes, d_pol, d_spec, d_sources, tau, out);
+}
+
 extern "C" int oi_lexicon_analyze(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                                   double *pol_out, uint8_t *spec_out) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }

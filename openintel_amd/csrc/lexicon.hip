@@ -20,6 +20,8 @@
 // 'i' + U+0307.  All other non-ASCII bytes separate tokens.  A lane whose window holds
 // a 0xAA or 0xB0 byte takes a (rare) exact per-char path.
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "oi_device.h"
 #include "oi_internal.h"
@@ -398,12 +400,33 @@ __device__ __noinline__ uint4 lex_load_tail(const uint8_t *blob, uint64_t src, u
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
+// Per-workgroup raw sums of SpeculationEngine::social_summary (speculation_engine.rs:76-97); the host adds the
+// workgroups' partials in block order.
+struct SumPartial {
+    unsigned long long src0, src1, bull, bear, neu, spec;
+    double psum;
+    double pad;
+};
+
+// pol_out / spec_out may be null when `partials` is given (the A4 reduction fused into the scan: SURVEY 8d, "0 out if
+// fused with the A4 reduction"): then nothing per post is written at all.  partials != null: every workgroup leaves
+// its raw sums (sources[i] != 0 counts as source 1; tau = bull/bear threshold, config.rs:21).  The f64 polarity sum
+// has a fixed shape -- per tile: thread t adds its posts (t, t + 256), then the wave tree; a wave adds its tiles in
+// order; then the four waves in order -- so it is bitwise reproducible for a given grid.
+// (launch bound 4 waves per SIMD = 128 VGPRs: the kernel sat at exactly 128 before the fused epilogue)
+__global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
                                                               uint64_t n, uint64_t blob_bytes,
                                                               const LexEntry *table, const uint32_t *bloom,
-                                                              uint32_t mult, double *pol_out, uint8_t *spec_out) {
+                                                              uint32_t mult, double *pol_out, uint8_t *spec_out,
+                                                              const uint8_t *sources, double tau, SumPartial *partials) {
     __shared__ __attribute__((aligned(16))) Lex2Shared s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the summary's running sums live in LDS, one set per wave (loop-carried registers cost the scan a wave of occupancy:
+    // 136 instead of 128 VGPRs, 1.29 -> 1.51 ms at 10M posts)
+    __shared__ uint32_t r_u[5][LEX_THREADS / 64];
+    __shared__ double r_d[LEX_THREADS / 64];
+    if (tid < 5 * (LEX_THREADS / 64)) (&r_u[0][0])[tid] = 0u;
+    if (tid < LEX_THREADS / 64) r_d[tid] = 0.0;
     reinterpret_cast<uint4 *>(s.table)[tid] = reinterpret_cast<const uint4 *>(table)[tid];
     uint32_t bl[8];
 #pragma unroll
@@ -559,11 +582,43 @@ __global__ __launch_bounds__(LEX_THREADS) void lexicon_kernel(const uint8_t *blo
             __syncthreads(); // LDS text is restaged next iteration
         }
         // ---- one PostSignal per post (lexicon.rs:62-72; Polarity::new is the identity on [-1,1])
+        uint32_t a_src1 = 0, a_bull = 0, a_bear = 0, a_neu = 0, a_spec = 0; // this thread's posts of THIS tile
+        double a_psum = 0.0;
         for (uint32_t i = tid; i < np; i += LEX_THREADS) {
             const double bh = (double)s.bull[i], rh = (double)s.bear[i];
             const double p = (bh + rh == 0.0) ? 0.0 : (bh - rh) / (bh + rh);
-            pol_out[p0 + i] = p;
-            spec_out[p0 + i] = (uint8_t)(s.spec[i] != 0);
+            const bool sp = s.spec[i] != 0;
+            if (pol_out) pol_out[p0 + i] = p;
+            if (spec_out) spec_out[p0 + i] = (uint8_t)sp;
+            if (partials) { // speculation_engine.rs:81-97, on the signal just computed
+                a_psum += p;
+                if (p > tau) ++a_bull; else if (p < -tau) ++a_bear; else ++a_neu;
+                a_spec += sp ? 1u : 0u;
+                if (sources) a_src1 += sources[p0 + i] != 0;
+            }
+        }
+        if (partials) { // fold the tile into the wave's running sums (fixed order: tiles in sequence)
+            uint32_t v5[5] = {a_src1, a_bull, a_bear, a_neu, a_spec};
+#pragma unroll
+            for (int k5 = 0; k5 < 5; ++k5) { const uint32_t r = oi_wave_sum(v5[k5]); if (lane == 0) r_u[k5][wv] += r; }
+            const double d = oi_wave_sum(a_psum);
+            if (lane == 0) r_d[wv] += d;
+        }
+    }
+    if (partials) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t[5] = {0, 0, 0, 0, 0};
+            double ds = 0.0;
+            for (int ww = 0; ww < LEX_THREADS / 64; ++ww) {
+                for (int k5 = 0; k5 < 5; ++k5) t[k5] += r_u[k5][ww];
+                ds += r_d[ww];
+            }
+            SumPartial o;
+            o.src1 = t[0]; o.bull = t[1]; o.bear = t[2]; o.neu = t[3]; o.spec = t[4];
+            o.src0 = sources ? (t[1] + t[2] + t[3]) - t[0] : 0; // posts of this workgroup not from source 1
+            o.psum = ds; o.pad = 0.0;
+            partials[blockIdx.x] = o;
         }
     }
 }
@@ -622,8 +677,11 @@ static bool build_lex_table(LexEntry *table, uint32_t *mult_out, uint32_t *bloom
     return false;
 }
 
-int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
-                      uint64_t blob_bytes, double *d_pol, uint8_t *d_spec) {
+// d_pol / d_spec may be null when `summary` is given (nothing per post is written then); summary != null: the fused A4
+// reduction -- the call synchronises the stream and returns the raw sums.
+int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n, uint64_t blob_bytes,
+                            double *d_pol, uint8_t *d_spec, const uint8_t *d_sources, double tau, oi_social_counters *summary) {
+    if (summary) { memset(summary, 0, sizeof(*summary)); summary->total = n; }
     if (n == 0) return OI_OK;
     OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "lexicon: text blob must be 16-byte aligned in HBM");
     struct HostTables { LexEntry table[LEX_SLOTS]; uint32_t bloom[64]; };
@@ -641,22 +699,43 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
     const LexEntry *d_table = tb.as<LexEntry>();
     const uint32_t *d_bloom = reinterpret_cast<const uint32_t *>(d_table + LEX_SLOTS);
     static const bool v1 = oi_ablation_env("OI_LEXICON_V1") != nullptr; // A/B switch: the first-generation scan
-    ProfScope ps(ctx, "lexicon");
-    if (v1) {
-        const uint64_t n_tiles = (n + LEX_PPT - 1) / LEX_PPT;
-        const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
-        const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
-        hipLaunchKernelGGL(lexicon_kernel_v1, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                           blob_bytes, d_table, h_mult, d_pol, d_spec);
-    } else {
-        const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
-        const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
-        const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
-        hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                           blob_bytes, d_table, d_bloom, h_mult, d_pol, d_spec);
+    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
+    const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
+    SumPartial *d_partials = nullptr;
+    if (summary) {
+        DevBuf &pb = ctx->buf("lex_partials");
+        OI_CHECK(pb.ensure(sizeof(SumPartial) * max_grid));
+        d_partials = pb.as<SumPartial>();
     }
-    OI_HIP_CHECK(hipGetLastError());
+    {
+        ProfScope ps(ctx, "lexicon");
+        if (v1 && !summary) {
+            const uint64_t n_tiles1 = (n + LEX_PPT - 1) / LEX_PPT;
+            const uint32_t grid1 = (uint32_t)(n_tiles1 < max_grid ? n_tiles1 : max_grid);
+            hipLaunchKernelGGL(lexicon_kernel_v1, dim3(grid1), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                               blob_bytes, d_table, h_mult, d_pol, d_spec);
+        } else {
+            hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                               blob_bytes, d_table, d_bloom, h_mult, d_pol, d_spec, d_sources, tau, d_partials);
+        }
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    if (!summary) return OI_OK;
+    std::vector<SumPartial> hp(grid);
+    OI_HIP_CHECK(hipMemcpyAsync(hp.data(), d_partials, sizeof(SumPartial) * grid, hipMemcpyDeviceToHost, ctx->stream));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t bb = 0; bb < grid; ++bb) { // block order: reproducible
+        summary->by_source[0] += hp[bb].src0; summary->by_source[1] += hp[bb].src1;
+        summary->bullish += hp[bb].bull; summary->bearish += hp[bb].bear; summary->neutral += hp[bb].neu;
+        summary->spec_count += hp[bb].spec; summary->polarity_sum += hp[bb].psum;
+    }
     return OI_OK;
+}
+
+int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                      uint64_t blob_bytes, double *d_pol, uint8_t *d_spec) {
+    return oi_launch_lexicon_fused(ctx, d_blob, d_offsets, n, blob_bytes, d_pol, d_spec, nullptr, 0.0, nullptr);
 }
 
 // ---- social summary ---------------------------------------------------------------
@@ -666,12 +745,6 @@ int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offs
 // host adds the <= 1024 block partials in block order.
 #define SUM_THREADS 256
 #define SUM_MAX_BLOCKS 1024
-struct SumPartial {
-    unsigned long long src0, src1, bull, bear, neu, spec;
-    double psum;
-    double pad;
-};
-
 __global__ __launch_bounds__(SUM_THREADS) void social_summary_kernel(const uint8_t *sources, const double *pol,
                                                                       const uint8_t *spec, uint64_t n, double tau,
                                                                       SumPartial *partials) {

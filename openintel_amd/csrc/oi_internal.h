@@ -155,6 +155,8 @@ struct oi_index {
 // lexicon.hip
 int oi_launch_lexicon(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
                       uint64_t blob_bytes, double *d_pol, uint8_t *d_spec);
+int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n, uint64_t blob_bytes,
+                            double *d_pol, uint8_t *d_spec, const uint8_t *d_sources, double tau, oi_social_counters *summary);
 int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol,
                              const uint8_t *d_spec, uint64_t n, double tau,
                              oi_social_counters *out_host);

@@ -167,20 +167,14 @@ class ShardedAnalyzer:
 def make_hip_sharded_analyzer(ctx, device, cfg=None, group=None) -> ShardedAnalyzer:
     """Wire the HIP lexicon scan + summary reduction of `ctx` into a ShardedAnalyzer.  Shard inputs: torch CUDA
     tensors (uint8 text blob, int64 offsets[n+1], uint8 sources[n] or None)."""
-    import torch
     from .analyzer import HipLexiconAnalyzer
     from .domain import EngineConfig
-    from .engine import SpeculationEngine
     cfg = cfg or EngineConfig()
     an = HipLexiconAnalyzer(ctx)
 
     def analyze_shard(d_blob, d_offsets, d_sources=None):
-        n = int(d_offsets.numel()) - 1
-        pol = torch.empty(max(n, 1), dtype=torch.float64, device=device)[:n]
-        spec = torch.empty(max(n, 1), dtype=torch.uint8, device=device)[:n]
-        if n:
-            an.analyze_device(d_blob, d_offsets, pol, spec)
-        return SpeculationEngine.social_counters(ctx, d_sources, pol, spec, cfg)
+        # one pass over the shard's text: the scan with the social_summary reduction fused in, nothing written per post
+        return an.summary_device(d_blob, d_offsets, d_sources, tau=cfg.bull_bear_threshold)
 
     return ShardedAnalyzer(analyze_shard, device, group)
 

@@ -148,6 +148,44 @@ def test_lexicon_device_buffers_and_summary(ctx, O):
     assert cnt2.polarity_sum == cnt.polarity_sum
 
 
+def test_lexicon_scan_with_fused_summary(ctx, O):
+    """oi_lexicon_summary_device: A1-A4 in one pass ("0 out if fused with the A4 reduction").  With no per-post
+    outputs the sums must be the oracle's (integers exact, polarity_sum inside the reassociation bound, identical run to
+    run); with outputs given they are oi_lexicon_analyze_device's bit for bit; ragged sizes, one post, sources absent."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    an = oi.HipLexiconAnalyzer(ctx)
+    blob_all, offs_all = synth.posts_torch(260_001, dev)
+    for n in (260_001, 512, 513, 1):
+        offs = offs_all[:n + 1].contiguous()
+        blob = blob_all[:int(offs[-1])].contiguous()
+        src = (torch.arange(n, device=dev) % 7 < 3).to(torch.uint8)
+        c0 = an.summary_device(blob, offs, src)                                   # nothing per post written
+        pol = torch.full((n,), 7.0, dtype=torch.float64, device=dev)
+        spec = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+        c1 = an.summary_device(blob, offs, src, d_polarity=pol, d_speculative=spec)
+        c2 = an.summary_device(blob, offs, None)
+        rpol, rspec = O.lexicon_analyze(blob.cpu().numpy(), offs.cpu().numpy().astype(np.uint64))
+        ref = O.social_summary(src.cpu().numpy(), rpol, rspec)
+        ints = lambda c: (c.total, c.by_source[0], c.by_source[1], c.bullish, c.bearish, c.neutral, c.spec_count)
+        want = (n, ref.mentions_by_source[0], ref.mentions_by_source[1], ref.bullish, ref.bearish, ref.neutral, ref.spec_count)
+        assert ints(c0) == want and ints(c1) == want
+        assert ints(c2) == (n, 0, 0, ref.bullish, ref.bearish, ref.neutral, ref.spec_count)   # no sources: no histogram
+        bound = n * 2.0 ** -52 * max(1.0, float(np.abs(np.cumsum(rpol)).max()))
+        assert abs(c0.polarity_sum - ref.polarity_sum) <= bound
+        assert c0.polarity_sum == c1.polarity_sum == c2.polarity_sum                       # fixed-shape tree: same bits
+        assert np.array_equal(pol.cpu().numpy().view(np.uint64), rpol.view(np.uint64))
+        assert np.array_equal(spec.cpu().numpy(), rspec)
+    # the reference's fixture through the fused path: the pinned summary (SURVEY 8c)
+    texts = ["AAPL to the moon", "buy AAPL calls", "AAPL puts printing, crash incoming", "nothing to see"]
+    b, o = oi.pack_posts(texts)
+    tb = torch.from_numpy(np.concatenate([b, np.zeros(64, np.uint8)])).to(dev)
+    c = an.summary_device(tb[:b.size], torch.from_numpy(o.astype(np.int64)).to(dev), None)
+    assert (c.total, c.bullish, c.bearish, c.neutral, c.spec_count) == (4, 2, 1, 1, 2) and c.polarity_sum == 1.0
+
+
 def test_sharded_analyzer_hip_shards_equal_the_oracle(ctx, O):
     """SURVEY 8(e) row 2 on the GPU: the posts cut into 3 shards, each through the HIP scan + summary reduction, the
     per-shard counters combined exactly as ShardedAnalyzer.summary combines the all-gathered words (the gloo test

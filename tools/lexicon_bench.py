@@ -42,6 +42,15 @@ for _ in range(reps):
     cnt = oi.SpeculationEngine.social_counters(ctx, src, pol, spec, cfg)
 t_sum = (time.perf_counter() - t0) / reps
 s_ms, s_n = ctx.profile_read("social_summary")
+# the fused form: scan + summary in one pass, nothing per post written (oi_lexicon_summary_device)
+for _ in range(2):
+    fc = an.summary_device(blob, offs, src, tau=cfg.bull_bear_threshold)
+ctx.profile_reset(True)
+t0 = time.perf_counter()
+for _ in range(reps):
+    fc = an.summary_device(blob, offs, src, tau=cfg.bull_bear_threshold)
+t_fused = (time.perf_counter() - t0) / reps
+f_ms, f_n = ctx.profile_read("lexicon")
 ctx.profile_reset(False)
 text_bytes = blob.numel()
 alg_bytes = text_bytes + 8 * (n + 1) + 9 * n      # text + offsets in, (f64 + u8) out
@@ -61,6 +70,12 @@ print(json.dumps({
     "lexicon_algorithmic_GBs": alg_bytes / (k_ms / k_n / 1e3) / 1e9, "lexicon_frac_of_8TBs": alg_bytes / (k_ms / k_n / 1e3) / 8e12,
     "lexicon_call_ms": t_lex * 1e3,
     "summary_kernel_ms": s_ms / s_n, "summary_algorithmic_GBs": 10 * n / (s_ms / s_n / 1e3) / 1e9, "summary_call_ms": t_sum * 1e3,
+    "fused_scan_summary": {"kernel_ms": f_ms / f_n, "call_ms": t_fused * 1e3,
+                           "algorithmic_GBs": (text_bytes + 8 * (n + 1) + n) / (f_ms / f_n / 1e3) / 1e9,   # text + offsets + sources in, 64 B/WG out
+                           "frac_of_8TBs": (text_bytes + 8 * (n + 1) + n) / (f_ms / f_n / 1e3) / 8e12,
+                           "integers_equal_unfused": (fc.total, fc.bullish, fc.bearish, fc.neutral, fc.spec_count, fc.by_source[0], fc.by_source[1]) ==
+                                                     (cnt.total, cnt.bullish, cnt.bearish, cnt.neutral, cnt.spec_count, cnt.by_source[0], cnt.by_source[1]),
+                           "polarity_sum": fc.polarity_sum},
     "bit_exact_vs_oracle_on_slice": ok,
     "cpu_oracle": {"posts_per_s": ns / t_cpu, "cores": 1, "sample_posts": ns, "seconds": t_cpu},
     "counters": {"total": cnt.total, "bullish": cnt.bullish, "bearish": cnt.bearish, "neutral": cnt.neutral,
