@@ -23,17 +23,6 @@ from .domain import PostSignal, SocialPost, SourceFailure
 
 class PostAnalyzer(abc.ABC):
     @abc.abstractmethod
-    def summary_device(self, d_blob, d_offsets, d_sources=None, tau: float = 0.2, d_polarity=None, d_speculative=None):
-        """The scan and the social_summary reduction in one pass (oi_lexicon_summary_device): returns the raw sums
-        (_lib.SocialCounters); the per-post outputs are written only if their tensors are given."""
-        import ctypes as C
-        n = d_offsets.numel() - 1
-        out = _lib.SocialCounters()
-        _lib.check(self.ctx.lib.oi_lexicon_summary_device(
-            self.ctx.handle, _lib.ptr(d_blob), _lib.ptr(d_offsets), n, d_blob.numel(), _lib.ptr(d_sources), float(tau),
-            _lib.ptr(d_polarity), _lib.ptr(d_speculative), C.byref(out)))
-        return out
-
     def analyze(self, posts: Sequence[SocialPost]) -> List[PostSignal]:
         ...
 
@@ -82,6 +71,17 @@ class HipLexiconAnalyzer(PostAnalyzer):
         _lib.check(self.ctx.lib.oi_lexicon_analyze_device(
             self.ctx.handle, _lib.ptr(d_blob), _lib.ptr(d_offsets), n, d_blob.numel(),
             _lib.ptr(d_polarity), _lib.ptr(d_speculative)))
+
+    def summary_device(self, d_blob, d_offsets, d_sources=None, tau: float = 0.2, d_polarity=None, d_speculative=None):
+        """The scan and the social_summary reduction in one pass (oi_lexicon_summary_device): returns the raw sums
+        (_lib.SocialCounters); the per-post outputs are written only if their tensors are given."""
+        import ctypes as C
+        n = d_offsets.numel() - 1
+        out = _lib.SocialCounters()
+        _lib.check(self.ctx.lib.oi_lexicon_summary_device(
+            self.ctx.handle, _lib.ptr(d_blob), _lib.ptr(d_offsets), n, d_blob.numel(), _lib.ptr(d_sources), float(tau),
+            _lib.ptr(d_polarity), _lib.ptr(d_speculative), C.byref(out)))
+        return out
 
     def summary_device(self, d_blob, d_offsets, d_sources=None, tau: float = 0.2, d_polarity=None, d_speculative=None):
         """The scan and the social_summary reduction in one pass (oi_lexicon_summary_device): returns the raw sums
