@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-end profile collection on the GPU box (one gpurun call):
-#   rocprofv3 --kernel-trace --stats over bench.py and the three side benches, then the PMC passes.
+#   bench.py (default + configs[1] + configs[4] shard + exact scorer), rocprofv3 --kernel-trace --stats over bench.py and the
+#   side benches, the shard step, then the PMC passes over bench.py (tools/pmc_profile.sh).
 # Usage: tools/profile_round.sh <tag>      (writes under gpurun_out/<tag>/)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -9,11 +10,16 @@ OUT=$R/gpurun_out/$T
 mkdir -p $OUT
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err && echo "bench ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
+python3 $R/bench.py --cosine exact --steps 10 --no-cpu-baseline > $OUT/bench_exact.json 2> $OUT/bench_exact.err && echo "exact ok"
+python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
+python3 $R/bench.py --corpus bf16 --dim 1024 --batch 256 --docs 12500000 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_config4_shard.json 2> $OUT/bench_config4_shard.err && echo "config4 shard ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_config4 -- python3 $R/bench.py --corpus bf16 --dim 1024 --batch 256 --docs 12500000 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/stats_config4.err && echo "stats config4 ok"
 python3 $R/tools/headline_bench.py 10000000 10 > $OUT/headline_bench.json 2> $OUT/headline_bench.err && echo "headline ok"
 python3 $R/tools/lexicon_bench.py 10000000 10 > $OUT/lexicon_bench.json 2> $OUT/lexicon_bench.err && echo "lexicon ok"
-python3 $R/tools/bm25_bench.py 10000000 5 > $OUT/bm25_bench.json 2> $OUT/bm25_bench.err && echo "bm25 ok"
+python3 $R/tools/bm25_bench.py 10000000 10 > $OUT/bm25_bench.json 2> $OUT/bm25_bench.err && echo "bm25 ok"
+python3 $R/tools/bm25_bench.py 10000000 5 256 > $OUT/bm25_bench_b256.json 2> $OUT/bm25_bench_b256.err && echo "bm25 b256 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/tools/headline_bench.py 10000000 5 > /dev/null 2> $OUT/stats_headline.err && echo "stats headline ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bm25 -- python3 $R/tools/bm25_bench.py 10000000 3 > /dev/null 2> $OUT/stats_bm25.err && echo "stats bm25 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lexicon -- python3 $R/tools/lexicon_bench.py 10000000 5 > /dev/null 2> $OUT/stats_lexicon.err && echo "stats lexicon ok"
-python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
 python3 $R/tools/shard_step_bench.py 1250000 50 > $OUT/shard_step.json 2> $OUT/shard_step.err && echo "shard ok"
+bash $R/tools/pmc_profile.sh $T/pmc > $OUT/pmc.log 2>&1 && echo "pmc ok"
