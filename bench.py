@@ -90,12 +90,13 @@ def main():
                     help="BM25 kernel (default wave: term-at-a-time, one wave per task; taat: the first-generation workgroup kernel)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
-    ap.add_argument("--cosine", choices=["screen", "exact", "split"], default="screen",
+    ap.add_argument("--cosine", choices=["screen", "exact", "split", "screen-copy"], default="screen",
                     help="f32 corpus scorer: a bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
                          "(default: the exact scorer's lists, HBM-bound), exact f32 MFMA for every row, or split-precision "
                          "products (six bf16 MFMAs)")
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-screen-copy", action="store_true", help="skip the opt-in screen-copy side measurement")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
     args = ap.parse_args()
@@ -131,7 +132,8 @@ def main():
     ctx = oi.HipContext(local_rank)
     ctx.use_torch_current_stream()
     from openintel_amd import _lib as _oil
-    MODES = {"screen": _oil.OI_COSINE_SCREEN, "exact": _oil.OI_COSINE_EXACT, "split": _oil.OI_COSINE_SPLIT}
+    MODES = {"screen": _oil.OI_COSINE_SCREEN, "exact": _oil.OI_COSINE_EXACT, "split": _oil.OI_COSINE_SPLIT,
+             "screen-copy": _oil.OI_COSINE_SCREEN_COPY}
     ctx.set_cosine_mode(MODES[args.cosine])
 
     # ---------------------------------------------------------------- corpus shard in HBM
@@ -249,6 +251,28 @@ def main():
                       "mfma_frac": 2.0 * n_local * args.dim * args.batch * ex_steps / (ex_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                       "note": "same batch, same K steps, oi_set_cosine_mode(OI_COSINE_EXACT): f32 MFMA for every row (rank 0's clock, outside the headline's timed region)"}
         screen_fallback = gate_opened != 0.0
+        # opt-in OI_COSINE_SCREEN_COPY beside it (same lists; the screen reads a bf16 copy of the rows: half the bytes)
+        copy_side = None
+        if args.dim in (384, 768) and not args.no_screen_copy:
+            ctx.set_cosine_mode(MODES["screen-copy"])
+            step(); step()
+            fence()
+            ctx.profile_reset(2)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(ex_steps):
+                step()
+            fence()
+            cp_elapsed = time.perf_counter() - t1
+            cp_ms, cp_launches = ctx.profile_read("cosine")
+            ctx.profile_reset(False)
+            ctx.set_cosine_mode(MODES["screen"])
+            copy_side = {"ms_per_step": cp_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / cp_elapsed, "steps": ex_steps,
+                         "screen_ms_per_step": cp_ms / ex_steps,
+                         "hbm_frac_on_its_bytes": 2.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (cp_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                         "extra_hbm_bytes": 2 * n_local * args.dim,
+                         "note": "OPT-IN mode oi_set_cosine_mode(OI_COSINE_SCREEN_COPY), not the headline: same bound, same exact f32 rescoring, "
+                                 "identical lists (tests/test_gpu_prefilter.py); the screen streams a bf16 copy (+50 % corpus memory)"}
 
     # per-batch latency (p50/p95), measured separately with a host sync after every batch
     lat = []
@@ -273,6 +297,8 @@ def main():
         # keeps the queries in registers takes one corpus pass per 64 queries (bf16 corpus, d = 1024: 64 per pass of
         # the pair kernel): its extra passes are re-reads and count AGAINST it here (frac falls), never for it.
         bytes_step = (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim
+        if args.corpus == "f32" and args.cosine == "screen-copy":
+            bytes_step = 2.0 * n_local * args.dim   # what that (opt-in) mode's screen has to read once per batch
         passes = (args.batch + 63) // 64 if args.batch > 8 else 1
         cos_s = cos_ms / 1e3
         if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
@@ -329,7 +355,8 @@ def main():
                        "query_batches_rotated": NB,
                        "cosine_scorer": {"screen": "bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
                                                    "(the exact scorer's lists; gated exact fallback)",
-                                         "exact": "f32 MFMA for every row", "split": "bf16x3 split products"}[args.cosine]
+                                         "exact": "f32 MFMA for every row", "split": "bf16x3 split products",
+                                         "screen-copy": "bf16 screen over a bf16 COPY of the rows (opt-in) + exact f32 rescoring"}[args.cosine]
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world},
             "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
@@ -356,6 +383,8 @@ def main():
                                      "--cosine exact makes it the headline.")
             line["exact_scorer"] = exact_side
             line["screen_fell_back_to_exact"] = screen_fallback
+            if copy_side is not None:
+                line["screen_copy_scorer"] = copy_side
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)

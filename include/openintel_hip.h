@@ -90,10 +90,15 @@ int oi_synchronize(oi_ctx *ctx);
  *                              taken as six bf16 MFMAs with f32 accumulation (the three smallest of the nine
  *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
  *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7).
- * Also selectable with OI_COSINE_MODE=screen|exact|split at oi_create. */
+ *   OI_COSINE_SCREEN_COPY      (opt-in) OI_COSINE_SCREEN with the screen reading a bf16 COPY of the rows, made by the
+ *                              library on first use (n_docs x dim x 2 bytes of HBM on top of the f32 corpus) with the
+ *                              screen's own conversion: the same products, the same bound, the same exact f32
+ *                              rescoring from the f32 rows -- the same lists -- at half the screen's bytes per row.
+ * Also selectable with OI_COSINE_MODE=screen|exact|split|screen-copy at oi_create. */
 #define OI_COSINE_EXACT 0
 #define OI_COSINE_SPLIT 1
 #define OI_COSINE_SCREEN 2
+#define OI_COSINE_SCREEN_COPY 3
 int oi_set_cosine_mode(oi_ctx *ctx, int mode);
 
 /* A hybrid query has two independent legs until fusion.  By default the BM25 leg is issued on an

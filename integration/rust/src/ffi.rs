@@ -33,6 +33,7 @@ pub const OI_DEVICE: c_int = 1;
 pub const OI_COSINE_EXACT: c_int = 0;
 pub const OI_COSINE_SPLIT: c_int = 1;
 pub const OI_COSINE_SCREEN: c_int = 2;
+pub const OI_COSINE_SCREEN_COPY: c_int = 3;
 
 extern "C" {
     pub fn oi_abi_version() -> c_int;

@@ -18,7 +18,7 @@ OI_MAX_DEPTH = 1024
 OI_MAX_DIM = 1024
 OI_BM25_BLOCK_DOCS = 32768
 OI_N_CATALYST_KEYWORDS = 16
-OI_COSINE_EXACT, OI_COSINE_SPLIT, OI_COSINE_SCREEN = 0, 1, 2
+OI_COSINE_EXACT, OI_COSINE_SPLIT, OI_COSINE_SCREEN, OI_COSINE_SCREEN_COPY = 0, 1, 2, 3
 
 OI_ERR_INVALID_ARG = -1
 OI_ERR_HIP = -2

@@ -129,7 +129,8 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->stream = nullptr;
     if (const char *m = getenv("OI_COSINE_MODE"))
-        c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "exact") == 0 ? OI_COSINE_EXACT : OI_COSINE_SCREEN;
+        c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "exact") == 0 ? OI_COSINE_EXACT
+                         : strcmp(m, "screen-copy") == 0 ? OI_COSINE_SCREEN_COPY : OI_COSINE_SCREEN;
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
@@ -160,7 +161,7 @@ extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
 
 extern "C" int oi_set_cosine_mode(oi_ctx *ctx, int mode) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT || mode == OI_COSINE_SCREEN,
+    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT || mode == OI_COSINE_SCREEN || mode == OI_COSINE_SCREEN_COPY,
                "oi_set_cosine_mode: unknown mode %d", mode);
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->cosine_mode = mode;
@@ -353,7 +354,7 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
         idx->postings.release(); idx->cell_start.release(); idx->idf.release();
-        idx->fwd_terms.release(); idx->fwd_offsets.release(); idx->max_row_norm.release();
+        idx->fwd_terms.release(); idx->fwd_offsets.release(); idx->max_row_norm.release(); idx->screen_copy.release();
     }
     delete idx;
 }
@@ -366,6 +367,7 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     if (idx->rows_owned && idx->rows) { (void)hipFree(idx->rows); idx->rows = nullptr; idx->rows_owned = false; }
     if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
     idx->rows_bf16 = nullptr; idx->rows_bf16_owned = false;
+    idx->screen_copy.release(); // a copy of the previous rows
     const size_t bytes = (size_t)idx->n_docs * idx->dim * sizeof(float);
     if (location == OI_DEVICE) {
         OI_REQUIRE(((uintptr_t)rows & 15u) == 0, "index: embedding matrix must be 16-byte aligned");
@@ -736,7 +738,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             };
             static const bool shape16 = !(oi_ablation_env("OI_KS_SHAPE") && atoi(oi_ablation_env("OI_KS_SHAPE")) == 32);
             static const bool cos_v1 = oi_ablation_env("OI_COSINE_V1") != nullptr || oi_ablation_env("OI_SELECT_V1") != nullptr;
-            const bool screen = ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && oi_cosine_screen_supported(idx->dim) &&
+            const bool want_copy = ctx->cosine_mode == OI_COSINE_SCREEN_COPY;
+            const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || want_copy) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
                                 idx->screen_ok && shape16 && !cos_v1;
             if (!screen) return exact_pipeline(nullptr, nullptr);
 
@@ -769,12 +772,19 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             SelectExtra mx;
             mx.eps2 = eps2;
             mx.margin_gate = gate;
+            if (want_copy && !idx->screen_copy.p) { // made once, on the first search that asks for it (n x d x 2 B of HBM)
+                OI_CHECK(idx->screen_copy.ensure(sizeof(uint16_t) * (size_t)n * idx->dim + 64));
+                OI_CHECK(oi_launch_make_screen_copy(ctx, idx->rows, n, idx->dim, idx->screen_copy.as<uint16_t>()));
+            }
             uint64_t chunk = oi_first_chunk_rows(depth);
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
                 const uint64_t e = std::min(n, r + chunk);
-                OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
+                // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
+                // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
+                if (want_copy) OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, d_qv, B, idx->doc_id_base, PF));
+                else OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
                 OI_CHECK(oi_launch_select(ctx, PF, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth, &mx));
                 r = e;
                 chunk *= oi_chunk_growth(B);

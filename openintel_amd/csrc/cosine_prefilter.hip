@@ -46,6 +46,7 @@
 // tiles and streams them through its own LDS ring of 4 KiB slots (32 rows x 32 floats) with
 // buffer_load ... lds, 7 slots ahead, ordered by counted s_waitcnt vmcnt; waves never meet.  Per 16 k of a tile:
 // two conflict-free ds_read_b128, four v_cvt_pk_bf16_f32, two MFMAs.  HBM-bound: 4 d bytes per row and batch.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -377,6 +378,24 @@ __global__ __launch_bounds__(64) void pf_probe_kernel(const float *__restrict__ 
         const uint32_t rr = r0 + (r & 3) + 8 * (r >> 2) + 4 * lh, qx = q0 + li;
         if (rr < n_rows && qx < n_queries) out[(uint64_t)qx * n_rows + rr] = acc[r];
     }
+}
+
+// The bf16 screening copy (OI_COSINE_SCREEN_COPY, opt-in): every row converted ONCE, with the conversion the screen
+// uses on the fly (pf_pack), so E -- and therefore the bound -- is the same; the screen then reads 2 d bytes per row.
+__global__ __launch_bounds__(256) void pf_make_copy_kernel(const float *__restrict__ rows, uint64_t n_vec8, uint4 *__restrict__ out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec8; i += (uint64_t)gridDim.x * blockDim.x) {
+        const pf_f32x4 a = *reinterpret_cast<const pf_f32x4 *>(rows + i * 8), b = *reinterpret_cast<const pf_f32x4 *>(rows + i * 8 + 4);
+        const pf_bf16x8 v = pf_pack(a, b);
+        out[i] = *reinterpret_cast<const uint4 *>(&v);
+    }
+}
+int oi_launch_make_screen_copy(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint16_t *out) {
+    const uint64_t n_vec8 = n * dim / 8; // dim is a multiple of 16 on this path
+    if (n_vec8 == 0) return OI_OK;
+    const uint64_t blocks = std::min<uint64_t>((n_vec8 + 255) / 256, (uint64_t)ctx->num_cus * 16);
+    hipLaunchKernelGGL(pf_make_copy_kernel, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, n_vec8, reinterpret_cast<uint4 *>(out));
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
 }
 
 // ------------------------------------------------------------------ exact rescoring of the survivors

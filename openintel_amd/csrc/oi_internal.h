@@ -84,7 +84,8 @@ struct oi_ctx {
     hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_legs = true;              // oi_set_overlap
-    int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default)
+    int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default),
+                                           // 3 = 2 with the screen reading a bf16 COPY of the rows (opt-in)
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     int prof_enabled = 0; // 0 off, 1 every tagged launch, 2 the cosine scorer only
@@ -127,6 +128,7 @@ struct oi_index {
     DevBuf max_row_norm; // u32[2]: bits of X = max_r |row r| and E = max_r |bf16(row r) - row r| (f32), taken when the f32 rows
                          // are set; NaN if any norm is
     bool screen_ok = false; // those maxima are finite and < 1e15: the bf16 screen's bound holds for this corpus
+    DevBuf screen_copy;     // OI_COSINE_SCREEN_COPY: bf16(rows), made on first use (n_docs x dim x 2 B); empty otherwise
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;
@@ -230,6 +232,7 @@ int oi_launch_screen_stage(oi_ctx *ctx, const float *d_queries, uint32_t n_queri
                            const uint32_t *max_norm_bits, uint16_t *q_bf16, float *eps2, uint32_t *gate);
 int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                   const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
+int oi_launch_make_screen_copy(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint16_t *out);
 int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
                            const uint16_t *q_bf16, uint32_t n_queries, float *d_out);
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,

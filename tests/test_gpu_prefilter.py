@@ -444,3 +444,61 @@ def test_full_size_screened_10M_768_batch64(ctx):
 class L_np:
     def __init__(self, s, d, c):
         self.cos_scores, self.cos_docs, self.cos_counts = s, d, c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# OI_COSINE_SCREEN_COPY (opt-in): the screen reads a bf16 copy of the rows.  Same products, same bound, same exact
+# rescoring from the f32 rows: the lists must be the default screen's BIT FOR BIT, the adversary included.
+@pytest.mark.parametrize("B,dim,n,depth", [(64, 768, 120_000, 1000), (40, 384, 50_000, 100), (130, 768, 30_000, 500)])
+def test_screen_copy_mode_returns_the_same_lists(ctx, O, B, dim, n, depth):
+    from openintel_amd import _lib, synth
+    rows = synth.embeddings_np(n, dim, seed=90 + B)
+    q = synth.embeddings_np(B, dim, seed=91 + B)
+    rng = np.random.default_rng(B)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50, base=11)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    L0 = idx.search_lists(q, qt, qo, depth=depth)
+    assert _gate(ctx) == 0.0
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN_COPY)
+    try:
+        L1 = idx.search_lists(q, qt, qo, depth=depth)
+        assert _gate(ctx) == 0.0
+        L2 = idx.search_lists(q, qt, qo, depth=depth)            # second call: the copy already exists
+    finally:
+        ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    for L in (L1, L2):
+        assert np.array_equal(L.cos_counts, L0.cos_counts) and np.array_equal(L.cos_docs, L0.cos_docs)
+        assert np.array_equal(L.cos_scores.view(np.uint32), L0.cos_scores.view(np.uint32))
+    for b in range(0, B, 7):
+        _check(L1, b, O.dot_scores(rows, q[b]), depth, n, base=11)
+    idx.close()
+
+
+def test_screen_copy_mode_on_the_tie_rounding_adversary(ctx, O):
+    from openintel_amd import _lib, synth
+    rng = np.random.default_rng(4)
+    dim, B, n, depth, n_comp = 768, 16, 20_000, 100, 150
+    rows = (synth.embeddings_np(n, dim, seed=40) * np.float32(0.3)).astype(np.float32)
+    q = synth.embeddings_np(B, dim, seed=41)
+    q[0, :384], q[0, 384:] = _tie(2), _tie(1)
+    planted = 777
+    comp = np.sort(rng.choice(np.setdiff1d(np.arange(n), [planted]), size=n_comp, replace=False))
+    rows[planted, :384], rows[planted, 384:] = _tie(2), 0.0
+    rows[comp, :384], rows[comp, 384:] = 0.0, _tie(3)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
+    Le = idx.search_lists(q, qt, qo, depth=depth)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN_COPY)
+    try:
+        L = idx.search_lists(q, qt, qo, depth=depth)
+    finally:
+        ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    assert int(L.cos_docs[0][0]) == planted
+    assert np.array_equal(L.cos_docs[0], Le.cos_docs[0])
+    assert np.array_equal(L.cos_scores[0].view(np.uint32), Le.cos_scores[0].view(np.uint32))
+    for b in range(B):
+        _check(L, b, O.dot_scores(rows, q[b]), depth, n)
+    idx.close()
