@@ -95,6 +95,7 @@ def main():
                          "(default: the exact scorer's lists, HBM-bound), exact f32 MFMA for every row, or split-precision "
                          "products (six bf16 MFMAs)")
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: do not overlap exchange + fusion with the next batch's lists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-screen-copy", action="store_true", help="skip the opt-in screen-copy side measurement")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
@@ -177,6 +178,12 @@ def main():
                           torch.zeros((args.batch,), dtype=torch.int32, device=dev))
 
     step_no = [0]
+    # N > 1: throughput mode -- the exchange + fusion of batch i overlap the lists of batch i + 1 (sharded.ShardedPipeline;
+    # independent batches, one all-gather each, same results); the latency loop below runs the batches one at a time.
+    pipe = None
+    if world > 1 and not args.no_pipeline:
+        fuse_ctx = oi.HipContext(local_rank)
+        pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k)
 
     def step():
         qv, qt, qo = batches[step_no[0] % NB]
@@ -184,13 +191,20 @@ def main():
         if world == 1:
             idx.search(qv, qt, qo, k=args.k, depth=args.depth, out=out)   # one C-ABI call: the whole query
             return out.docs
+        if pipe is not None and pipelined[0]:
+            return pipe.results[pipe.submit(qv, qt, qo)].docs
         return sr.search(qv, qt, qo, args.k, args.depth, check=False)[1]  # overflow flag checked after the loops
 
+    pipelined = [False]
+
     def fence():
+        if pipe is not None:
+            pipe.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipelined[0] = True
     for _ in range(args.warmup):
         step()
     fence()
@@ -211,6 +225,7 @@ def main():
     cos_ms, cos_launches = ctx.profile_read("cosine")
     ctx.profile_reset(False)
     ctx.synchronize()   # outside the timed region: a pool overflow in any of the K steps is an error, not a number
+    pipelined[0] = False   # everything below (isolated kernel times, exact scorer, latency) runs batch by batch
     # The BM25 leg runs beside the cosine leg on a side stream, so the live cosine duration above includes
     # the CUs it lends to BM25 workgroups.  A few untimed steps with the legs one after the other give the
     # kernel's own duration as well (reported next to the live figure, never instead of it).
@@ -358,7 +373,8 @@ def main():
                                          "exact": "f32 MFMA for every row", "split": "bf16x3 split products",
                                          "screen-copy": "bf16 screen over a bf16 COPY of the rows (opt-in) + exact f32 rescoring"}[args.cosine]
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
-                       "parallelism": "row-shard x%d + all-gather of per-shard lists" % world},
+                       "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
+                                      ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "")},
             "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
             "roofline": roof,
             "other_kernels_ms_per_step": dict({t: v[0] / iso_steps for t, v in other.items()},

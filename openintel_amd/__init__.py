@@ -13,7 +13,7 @@ from .dip import HeadlineScanner, company_name_forms
 from .domain import (Alignment, AnalyzerMismatch, Confidence, DomainError, EngineConfig, MarketSnapshot,
                      PostSignal, PostText, SocialPost, SourceFailure, SourceKind, Ticker)
 from .engine import SpeculationEngine
-from .sharded import ShardedAnalyzer, ShardedRetriever, make_hip_sharded, make_hip_sharded_analyzer, shard_bounds
+from .sharded import ShardedAnalyzer, ShardedPipeline, ShardedRetriever, make_hip_sharded, make_hip_sharded_analyzer, shard_bounds
 from .retriever import (HybridIndex, PostRetriever, SearchResult, fuse_packed, merge_lists, pack_query_terms,
                         packed_words, rrf_fuse, unpack_lists)
 
@@ -22,6 +22,6 @@ __all__ = [
     "PostRetriever", "SearchResult", "merge_lists", "rrf_fuse", "pack_query_terms", "fuse_packed", "packed_words",
     "unpack_lists", "HeadlineScanner", "company_name_forms", "Alignment",
     "AnalyzerMismatch", "Confidence", "DomainError", "EngineConfig", "MarketSnapshot", "PostSignal", "PostText",
-    "SocialPost", "SourceFailure", "SourceKind", "Ticker", "ShardedAnalyzer", "ShardedRetriever", "make_hip_sharded",
+    "SocialPost", "SourceFailure", "SourceKind", "Ticker", "ShardedAnalyzer", "ShardedPipeline", "ShardedRetriever", "make_hip_sharded",
     "make_hip_sharded_analyzer", "shard_bounds",
 ]

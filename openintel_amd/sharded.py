@@ -113,6 +113,64 @@ class ShardedRetriever:
             ctx.synchronize()
 
 
+class ShardedPipeline:
+    """Throughput mode of the sharded query (GPU only): the exchange + fusion of batch i run on a second stream while
+    the shard's lists of batch i+1 are already being scored on the first -- independent batches, two packed buffers,
+    two result slots.  Per batch nothing changes (same calls, same results, one all-gather); only the ~0.1 ms of
+    exchange + fusion stop adding to the step time, which at 8 GPUs is 10 % of it.
+
+        pipe = ShardedPipeline(retriever, fuse_ctx, n_queries, depth, k)
+        slot = pipe.submit(qv, qt, qo)      # asynchronous; results of this batch land in pipe.results[slot]
+        ...
+        pipe.drain()                        # everything submitted so far is complete (and checked for overflow)
+
+    `fuse_ctx` is a second HipContext on the same device (its own stream and workspaces: the fusion must not queue
+    behind the next batch's kernels on the retriever's stream)."""
+
+    def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int):
+        import torch
+        from .retriever import SearchResult, fuse_packed, packed_words
+        self.r, self.fctx, self.B, self.depth, self.k = retriever, fuse_ctx, int(n_queries), int(depth), int(k)
+        self._fuse_packed = fuse_packed
+        dev = retriever.device
+        self.dev = dev
+        self.side = torch.cuda.Stream(device=dev)
+        fuse_ctx.set_stream(self.side)
+        words = packed_words(self.B, self.depth)
+        mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
+        self.packed = [mk(words, torch.int32) for _ in range(2)]
+        self.flat = [mk(words * retriever.world, torch.int32) for _ in range(2)] if retriever.world > 1 else self.packed
+        self.results = [SearchResult(torch.zeros((self.B, self.k), dtype=torch.float32, device=dev),
+                                     torch.zeros((self.B, self.k), dtype=torch.int32, device=dev),
+                                     torch.zeros((self.B,), dtype=torch.int32, device=dev)) for _ in range(2)]
+        self.lists_done = [torch.cuda.Event() for _ in range(2)]
+        self.fused = [torch.cuda.Event() for _ in range(2)]
+        self.n = 0
+
+    def submit(self, qv, qt, qo) -> int:
+        import torch
+        slot = self.n & 1
+        main = torch.cuda.current_stream(self.dev)
+        if self.n >= 2:
+            main.wait_event(self.fused[slot])          # the slot's packed buffer is free again
+        self.r.local.search_lists_packed(qv, qt, qo, depth=self.depth, out=self.packed[slot])
+        self.lists_done[slot].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.lists_done[slot])
+            if self.r.world > 1:
+                self.r.dist.all_gather_into_tensor(self.flat[slot], self.packed[slot], group=self.r.group)   # the ONE exchange
+            self._fuse_packed(self.fctx, self.flat[slot], self.r.world, self.B, self.depth, self.k, out=self.results[slot])
+            self.fused[slot].record(self.side)
+        self.n += 1
+        return slot
+
+    def drain(self) -> None:
+        import torch
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        self.fctx.synchronize()
+        self.r.check()
+
+
 class ShardedAnalyzer:
     """the lexicon path over sharded posts.
 

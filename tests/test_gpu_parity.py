@@ -700,3 +700,42 @@ def test_full_size_config3_shard_through_sharded_retriever(ctx, O):
         full = (rows @ qv[b]).cpu().numpy()
         _check_cos_list(cs[b], cd[b], depth, full, depth, doc_base=base)
     idx.close()
+
+
+def test_sharded_pipeline_overlaps_fusion_and_returns_the_same_results(ctx, O):
+    """sharded.ShardedPipeline (bench.py's throughput mode for N > 1): the fusion of batch i runs on a second stream and
+    a second ctx while batch i+1's lists are being scored; two slots.  Six different batches through the pipeline must
+    come out exactly as through the plain, one-at-a-time ShardedRetriever.search (world 1: the exchange degenerates)."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import sharded, synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k = 200_000, 384, 32, 300, 50
+    rows = synth.embeddings_torch(n, dim, dev)
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    idx = oi.HybridIndex(ctx, n, dim, 4096, doc_id_base=1000)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    ctx.use_torch_current_stream()
+    sr = sharded.make_hip_sharded(ctx, idx, dev)
+    sr.finalize()
+    batches = [synth.query_batch_torch(B, dim, dev, vocab=4096, seed=500 + i) for i in range(6)]
+    want = []
+    for qv, qt, qo in batches:
+        s, d, c = sr.search(qv, qt, qo, k, depth)
+        want.append((s.clone(), d.clone(), c.clone()))
+    fctx = oi.HipContext(0)
+    pipe = sharded.ShardedPipeline(sr, fctx, B, depth, k)
+    got = []
+    for qv, qt, qo in batches:
+        slot = pipe.submit(qv, qt, qo)
+        # a slot's result is valid until the slot is reused two submits later: copy it out behind the fusion (side stream)
+        with torch.cuda.stream(pipe.side):
+            r = pipe.results[slot]
+            got.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
+    pipe.drain()
+    torch.cuda.synchronize()
+    for (ws, wd, wc), (gs, gd, gc) in zip(want, got):
+        assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc)
+    fctx.close()
+    idx.close()
