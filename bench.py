@@ -315,6 +315,12 @@ def main():
         if args.corpus == "f32" and args.cosine == "screen-copy":
             bytes_step = 2.0 * n_local * args.dim   # what that (opt-in) mode's screen has to read once per batch
         passes = (args.batch + 63) // 64 if args.batch > 8 else 1
+        if args.corpus == "bf16" or args.cosine == "screen-copy":   # the bf16-corpus scorer's plan (cosine_bf16.hip, cb_group)
+            left, passes, solo = args.batch, 0, (32 if args.dim == 1024 else 64)
+            while left > 0:
+                g = solo if left <= solo else 96 if args.dim == 1024 else (96 if (left + 95) // 96 < (left + 63) // 64 else 64)
+                left -= min(g, left)
+                passes += 1
         cos_s = cos_ms / 1e3
         if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
