@@ -12,9 +12,10 @@
 // task belongs to ONE WAVE, 12 waves per CU walk their own task lists, and nothing in a task waits for another wave.
 // Most docs of a task occur in ONE of the query's runs (~95 % for 4-term queries): their score is that one product,
 // (+0) + idf * impact, and needs no accumulator at all.  So:
-//   load     the task's postings are cut into 64-posting chunks in query order by a scalar cursor over the runs and
-//            fetched a round of 8 chunks at a time, the next round in flight while this one is processed (the second
-//            pass reads them again: L2 hits);
+//   load     the task's postings are cut, run by run in query order, into groups of up to 256 (four per lane); lane g
+//            holds group g's descriptor, built by one scalar loop over the TERMS; the first six groups (1536
+//            postings: the whole task in the common case) are loaded together, up front, and stay in registers for
+//            both passes; further groups stream one ahead;
 //   pass A   every posting ORs its doc's bit into a wave-private 32768-bit map (ds_or returning the old word); a bit
 //            that was already set -- the doc was in an earlier run -- is ORed into a second map, "multi".  All the
 //            chunks' atomics are issued before the first result is waited for (a wave's LDS operations execute in
@@ -41,7 +42,7 @@
 #define BW_WAVES 4                // waves per workgroup
 #define BW_STAGE_TERMS 256u       // query terms of a pass staged in LDS (more: read from global memory)
 #define BW_MAX_Q 128u             // queries per pass (term offsets, weights and order staged in LDS)
-#define BW_ROUND 4                 // 64-posting chunks fetched and processed together
+#define BW_KEEP 6                  // groups of 256 postings loaded up front and kept in registers for both passes
 #define BW_WAVE_LDS (BW_WORDS * 4 * 2 + BW_HASH * 8)   // bytes: seen map | multi map | multi table
 
 struct BwPosting {
@@ -164,98 +165,122 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
         const uint32_t doc0 = doc_id_base + (block0 + blk) * BW_R;
         uint64_t *seg = pools + (uint64_t)q * pool_stride + carry_cap + (uint64_t)(block0 + blk) * seg_cap;
 
-        // ---- the task's postings as 64-posting chunks IN QUERY ORDER (a cursor over the runs of the first 64 terms: a
-        // run of n postings is ceil(n / 64) chunks, a chunk never spans two runs), fetched a ROUND of chunks at a
-        // time, the next round in flight while this one is processed
+        // ---- the task's postings as GROUPS of up to 256 (four per lane) IN QUERY ORDER; a group never spans two runs.
+        // Lane g holds the descriptor of group g (run start of the group, run end, term): built by one uniform loop over the
+        // terms -- scalar work per TERM, not per chunk (the first form walked a scalar cursor per 64 postings: ~1500 SALU
+        // instructions per task, as many as the vector work; PMC in DESIGN.md 4.3).
         const uint32_t ntf = nt < 64u ? nt : 64u;
-        struct Cursor { uint32_t j, i, e; };
-        auto cursor_term = [&](Cursor &c, uint32_t j) {
-            c.i = (uint32_t)__builtin_amdgcn_readlane((int)my_s, (int)j);
-            c.e = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
-        };
-        auto cursor_skip_empty = [&](Cursor &c) { // uniform: stops at a run with postings left, or at j == ntf with i = e = 0
-            while (c.j < ntf && c.i >= c.e) {
-                ++c.j;
-                if (c.j < ntf) cursor_term(c, c.j);
-                else { c.e = 0; c.i = 0; }
+        uint32_t d_i0 = 0, d_e = 0, d_j = 0; // this lane's group (page 0: groups 0..63)
+        uint32_t ng = 0;                      // groups of the first 64 terms (uniform)
+        {
+            const uint32_t n_mine = (my_e - my_s + 255u) >> 8; // groups of the term this lane holds the bounds of
+            for (uint32_t j = 0; j < ntf; ++j) {
+                const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n_mine, (int)j);
+                if (nj == 0u) continue; // uniform
+                const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)my_s, (int)j);
+                const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
+                const bool mine = lane >= ng && lane < ng + nj;
+                d_i0 = mine ? sj + ((lane - ng) << 8) : d_i0;
+                d_e = mine ? ej : d_e;
+                d_j = mine ? j : d_j;
+                ng += nj;
             }
+        }
+        struct Group {
+            BwPosting p[4];
+            uint32_t n; // postings in the group (uniform, 0..256)
+            float w;    // idf of its term (uniform)
         };
-        auto cursor_begin = [&]() {
-            Cursor c{0u, 0u, 0u};
-            if (ntf) cursor_term(c, 0);
-            cursor_skip_empty(c);
-            return c;
-        };
-        struct Round {
-            BwPosting p[BW_ROUND];
-            uint32_t meta[BW_ROUND / 2]; // uniform, two chunks per word: postings in the chunk (0: none) | term index << 7
-        };
-        auto load_round = [&](Cursor &c) { // unconditional loads (an exhausted cursor reads postings[0], n = 0)
-            Round r;
+        // group g of the first page, g uniform (a compile-time constant for the kept groups); past the end: n = 0
+        auto load_group = [&](uint32_t g) {
+            Group G;
+            const bool have = g < ng && g < 64u;
+            const uint32_t gl = have ? g : 0u;
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)d_i0, (int)gl);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)d_e, (int)gl);
+            const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)d_j, (int)gl);
+            G.n = have ? (e - i0 < 256u ? e - i0 : 256u) : 0u;
+            G.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), (int)tj));
+            const uint32_t safe = have ? e - 1u : 0u; // unpredicated loads: a lane past the group re-reads its run's last posting
 #pragma unroll
-            for (int k = 0; k < BW_ROUND / 2; ++k) r.meta[k] = 0u;
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + 64u * u + lane;
+                G.p[u] = postings[have && i < e ? i : safe];
+            }
+            return G;
+        };
+        // the first BW_KEEP groups: all their loads in flight together, kept in registers for BOTH passes
+        Group keep[BW_KEEP];
 #pragma unroll
-            for (int k = 0; k < BW_ROUND; ++k) {
-                const bool live = c.i < c.e; // (an exhausted cursor stays at i = e = 0: it must not advance)
-                const uint32_t left = live ? c.e - c.i : 0u;
-                const uint32_t n = left < 64u ? left : 64u;
-                r.meta[k >> 1] |= __builtin_amdgcn_readfirstlane(n | ((c.j & 63u) << 7)) << (16 * (k & 1));
-                r.p[k] = postings[lane < n ? c.i + lane : (live ? c.e - 1u : 0u)];
-                c.i = live ? c.i + 64u : c.i;
-                cursor_skip_empty(c);
-            }
-            return r;
-        };
-        auto chunk_n = [&](const Round &r, int k) -> uint32_t { return (r.meta[k >> 1] >> (16 * (k & 1))) & 127u; };
-        auto chunk_w = [&](const Round &r, int k) -> float { // the idf of the chunk's term: lane (term index) of my_w
-            const uint32_t tj = __builtin_amdgcn_readfirstlane((r.meta[k >> 1] >> (16 * (k & 1) + 7)) & 63u);
-            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), (int)tj));
-        };
-        // One instantiation of f per pass (the code of a task is executed once per task: every kilobyte of it is a cold
-        // instruction fetch for the wave's first task -- a 40 KB build of this kernel took 50 us for ONE task).  The next
-        // round is requested before this one is processed; the copy at the end of the body is where it is waited for.
-        auto for_each_round = [&](auto &&f) {
-            Cursor c = cursor_begin();
-            Round ra = load_round(c);
-            while (chunk_n(ra, 0) != 0u) {
-                const Round rb = load_round(c);
-                f(ra);
-                ra = rb;
-            }
-        };
+        for (int g = 0; g < BW_KEEP; ++g) keep[g] = load_group((uint32_t)g);
         fetch_bounds(t + G, 0, nx_s, nx_e, nx_w, nx_ok); // the next task's bounds: in flight while this one is processed
         if (DBG == 1 || DBG == 2) {
             uint32_t x = my_s + my_e;
             if (DBG == 2)
-                for_each_round([&](const Round &r) {
-                    for (int k = 0; k < BW_ROUND; ++k) x += (r.p[k].dib ^ __float_as_uint(r.p[k].impact)) + chunk_n(r, k);
-                });
+                for (int g = 0; g < BW_KEEP; ++g)
+                    for (int u = 0; u < 4; ++u) x += (keep[g].p[u].dib ^ __float_as_uint(keep[g].p[u].impact)) + keep[g].n;
             if (lane == 0 || x == 0xDEADBEEFu) seg_cnt[(uint64_t)q * seg_cnt_stride + block0 + blk] = x == 0xDEADBEEFu ? 1u : 0u;
             continue;
         }
-
-        // Terms beyond the 64 a wave holds bounds for (long queries), in query order, one chunk at a time (not pipelined):
-        // f(posting of this lane, lane holds one, idf weight)
-        auto for_each_late_chunk = [&](auto &&f) {
-            for (uint32_t g0 = 64; g0 < nt; g0 += 64) {
+        // Every group of the task in query order: f(group).  Kept groups come out of registers; the rest of the first page
+        // is loaded one group ahead; tasks of more than 64 groups (16K postings) and terms beyond the 64th take the slow
+        // forms below.
+        const bool one_page = ng <= 64u;
+        auto for_each_group = [&](auto &&f) {
+#pragma unroll
+            for (int g = 0; g < BW_KEEP; ++g) {
+                // The kept postings are made opaque before each use: otherwise everything pass A derives from them (word
+                // address, bit, window test, product -- ~40 registers per group) is kept alive for pass B instead of being
+                // recomputed (+45 VGPRs per kept group: spills at four groups).
+#pragma unroll
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(keep[g].p[u].dib), "+v"(keep[g].p[u].impact));
+                if ((uint32_t)g < ng) f(keep[g]); // uniform
+            }
+            if (ng > BW_KEEP && one_page) {
+                Group ga = load_group(BW_KEEP);
+                for (uint32_t g = BW_KEEP; g < ng; ++g) {
+                    const Group gb = load_group(g + 1u);
+                    f(ga);
+                    ga = gb;
+                }
+            }
+        };
+        // slow forms: f(posting of this lane, lane holds one, idf weight), one 64-posting chunk at a time
+        auto for_each_slow_chunk = [&](auto &&f) {
+            auto run = [&](uint32_t s, uint32_t e, float wt) {
+                for (uint32_t i0 = s; i0 < e; i0 += 64u) f(postings[i0 + lane < e ? i0 + lane : e - 1u], i0 + lane < e, wt);
+            };
+            if (!one_page) { // a task of more than 64 groups: everything past the kept groups, term by term
+                uint32_t seen_groups = 0;
+                for (uint32_t j = 0; j < ntf; ++j) {
+                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)my_s, (int)j);
+                    const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
+                    const uint32_t nj = (ej - sj + 255u) >> 8;
+                    // groups [seen_groups, seen_groups + nj) belong to this term; the first BW_KEEP groups overall are kept
+                    const uint32_t skip = seen_groups >= BW_KEEP ? 0u : (BW_KEEP - seen_groups < nj ? BW_KEEP - seen_groups : nj);
+                    const uint32_t from = sj + (skip << 8);
+                    run(from < ej ? from : ej, ej, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), (int)j)));
+                    seen_groups += nj;
+                }
+            }
+            for (uint32_t g0 = 64; g0 < nt; g0 += 64) { // terms beyond the 64 a wave holds bounds for
                 uint32_t gs, ge, okm;
                 float gw;
                 fetch_bounds(t, g0, gs, ge, gw, okm);
                 gs = okm ? gs : 0u; ge = okm ? ge : 0u; gw = okm ? gw : 0.f;
                 const uint32_t gn = nt - g0 < 64u ? nt - g0 : 64u;
-                for (uint32_t j = 0; j < gn; ++j) {
-                    const uint32_t s = (uint32_t)__shfl((int)gs, (int)j, OI_WAVE), e = (uint32_t)__shfl((int)ge, (int)j, OI_WAVE);
-                    const float wt = __shfl(gw, (int)j, OI_WAVE);
-                    for (uint32_t i0 = s; i0 < e; i0 += 64u) f(postings[i0 + lane < e ? i0 + lane : e - 1u], i0 + lane < e, wt);
-                }
+                for (uint32_t j = 0; j < gn; ++j)
+                    run((uint32_t)__shfl((int)gs, (int)j, OI_WAVE), (uint32_t)__shfl((int)ge, (int)j, OI_WAVE), __shfl(gw, (int)j, OI_WAVE));
             }
         };
+        // NOTE on order when !one_page: the kept groups (the first BW_KEEP groups of the task) come first, then the
+        // rest term by term -- still query order, because the kept groups are a prefix of it.
 
         uint32_t out_cnt = 0;
-        auto emit = [&](bool keep, float v, uint32_t dib) { // all lanes call; appends the kept scores to the segment
-            const unsigned long long m = __ballot(keep);
+        auto emit = [&](bool keepit, float v, uint32_t dib) { // all lanes call; appends the kept scores to the segment
+            const unsigned long long m = __ballot(keepit);
             if (m) {
-                if (keep) {
+                if (keepit) {
                     const uint32_t pos = out_cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (pos < seg_cap) seg[pos] = oi_rank_key(v, doc0 + dib);
                 }
@@ -267,35 +292,42 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
         while (lo < BW_R) {
             const uint32_t hi = lo + width;
             const unsigned long long t_a0 = stamp();
-            // ---- pass A: seen / multi maps.  A round's eight atomics are issued, THEN their results are used.
+            // ---- pass A: seen / multi maps.  A group's four atomics are issued, THEN their results are used; one ballot
+            // per group decides whether anything of it was seen before (rare)
             uint32_t n_multi = 0;
-            auto mark = [&](bool inw, uint32_t d, uint32_t oldword) { // all lanes call
-                const uint32_t bit = 1u << (d & 31u);
-                const bool again = inw && (oldword & bit);
+            for_each_group([&](const Group &g) {
+                uint32_t oldw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t d = g.p[u].dib;
+                    const bool inw = 64u * u + lane < g.n && d >= lo && d < hi;
+                    oldw[u] = 0u;
+                    if (inw) oldw[u] = atomicOr(&seen[d >> 5], 1u << (d & 31u));
+                }
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) any = any || ((oldw[u] >> (g.p[u].dib & 31u)) & 1u); // (not in window: oldw = 0)
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t d = g.p[u].dib;
+                        const bool again = (oldw[u] >> (d & 31u)) & 1u;
+                        if (again) atomicOr(&multi[d >> 5], 1u << (d & 31u));
+                        n_multi += (uint32_t)__popcll(__ballot(again));
+                    }
+                }
+            });
+            for_each_slow_chunk([&](const BwPosting &p, bool have, float) {
+                const uint32_t d = p.dib, bit = 1u << (d & 31u);
+                const bool inw = have && d >= lo && d < hi;
+                uint32_t o = 0u;
+                if (inw) o = atomicOr(&seen[d >> 5], bit);
+                const bool again = (o & bit) != 0u;
                 const unsigned long long m = __ballot(again);
-                if (m) { // uniform: rare
+                if (m) {
                     if (again) atomicOr(&multi[d >> 5], bit);
                     n_multi += (uint32_t)__popcll(m);
                 }
-            };
-            for_each_round([&](const Round &r) {
-                uint32_t oldw[BW_ROUND];
-#pragma unroll
-                for (int k = 0; k < BW_ROUND; ++k) {
-                    const uint32_t d = r.p[k].dib;
-                    const bool inw = lane < chunk_n(r, k) && d >= lo && d < hi;
-                    oldw[k] = 0u;
-                    if (inw) oldw[k] = atomicOr(&seen[d >> 5], 1u << (d & 31u));
-                }
-#pragma unroll
-                for (int k = 0; k < BW_ROUND; ++k) mark(oldw[k] != 0u, r.p[k].dib, oldw[k]); // (outside window / chunk: oldw = 0)
-            });
-            for_each_late_chunk([&](const BwPosting &p, bool have, float) {
-                const uint32_t d = p.dib;
-                const bool inw = have && d >= lo && d < hi;
-                uint32_t o = 0u;
-                if (inw) o = atomicOr(&seen[d >> 5], 1u << (d & 31u));
-                mark(inw, d, o);
             });
             if (TIMING) t_acc[3] += stamp() - t_a0; // pass A
             if (DBG == 3) { clear_maps(); lo = hi; continue; }
@@ -324,27 +356,64 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                     }
                 }
             };
-            auto score = [&](bool inw, uint32_t d, uint32_t mword, float x) { // all lanes call
-                const bool mul = inw && ((mword >> (d & 31u)) & 1u);
-                emit(inw && !mul && x > 0.0f && oi_f32_key(x) >= tau, x, d); // (BM25 lists hold scores > 0 only)
-                if (__ballot(mul)) accumulate(mul, d, x);
-            };
-            for_each_round([&](const Round &r) {
-                uint32_t mw[BW_ROUND];
+            for_each_group([&](const Group &g) {
+                uint32_t mw[4];
 #pragma unroll
-                for (int k = 0; k < BW_ROUND; ++k) mw[k] = multi[lane < chunk_n(r, k) ? r.p[k].dib >> 5 : 0u]; // reads in flight together
+                for (int u = 0; u < 4; ++u) mw[u] = multi[64u * u + lane < g.n ? g.p[u].dib >> 5 : 0u]; // reads in flight together
+                bool mul[4], kp[4], anym = false, anyk = false;
+                float x[4];
 #pragma unroll
-                for (int k = 0; k < BW_ROUND; ++k) {
-                    if (chunk_n(r, k)) { // uniform
-                        const uint32_t d = r.p[k].dib;
-                        score(lane < chunk_n(r, k) && d >= lo && d < hi, d, mw[k], __fmul_rn(chunk_w(r, k), r.p[k].impact));
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t d = g.p[u].dib;
+                    const bool inw = 64u * u + lane < g.n && d >= lo && d < hi;
+                    mul[u] = inw && ((mw[u] >> (d & 31u)) & 1u);
+                    x[u] = __fmul_rn(g.w, g.p[u].impact);
+                    kp[u] = inw && !mul[u] && x[u] > 0.0f && oi_f32_key(x[u]) >= tau; // (BM25 lists hold scores > 0 only)
+                    anym = anym || mul[u];
+                    anyk = anyk || kp[u];
+                }
+                if (__ballot(anyk)) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) emit(kp[u], x[u], g.p[u].dib);
+                }
+                if (DBG != 4 && __ballot(anym)) {
+                    // the four chunks of a group are one run: their docs are distinct, so their table updates are independent --
+                    // all four compare-and-swaps are in flight together, only stragglers (slot taken by another doc) loop
+                    bool pend[4];
+                    uint32_t slot[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pend[u] = mul[u]; slot[u] = (g.p[u].dib * 0x9E3779B1u) >> 23; }
+                    for (;;) {
+                        unsigned long long prev[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            prev[u] = 0ull;
+                            if (pend[u]) prev[u] = atomicCAS(&tab[slot[u]], 0ull, ((unsigned long long)__float_as_uint(x[u]) << 32) | (g.p[u].dib + 1u));
+                        }
+                        bool more = false;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (pend[u]) {
+                                const uint32_t tag = g.p[u].dib + 1u;
+                                if (prev[u] == 0ull) pend[u] = false; // first run of this doc: (+0) + x
+                                else if ((uint32_t)prev[u] == tag) {   // seen in an earlier run: add in query order, plain store
+                                    const float v = __fadd_rn(__uint_as_float((uint32_t)(prev[u] >> 32)), x[u]);
+                                    tab[slot[u]] = ((unsigned long long)__float_as_uint(v) << 32) | tag;
+                                    pend[u] = false;
+                                } else { slot[u] = (slot[u] + 1u) & (BW_HASH - 1u); more = true; }
+                            }
+                        if (!__ballot(more)) break;
                     }
                 }
             });
-            for_each_late_chunk([&](const BwPosting &p, bool have, float wt) {
+            for_each_slow_chunk([&](const BwPosting &p, bool have, float wt) {
                 const uint32_t d = p.dib;
                 const bool inw = have && d >= lo && d < hi;
-                score(inw, d, multi[inw ? d >> 5 : 0u], __fmul_rn(wt, p.impact));
+                const uint32_t mword = multi[inw ? d >> 5 : 0u];
+                const bool mul = inw && ((mword >> (d & 31u)) & 1u);
+                const float x = __fmul_rn(wt, p.impact);
+                emit(inw && !mul && x > 0.0f && oi_f32_key(x) >= tau, x, d);
+                if (__ballot(mul)) accumulate(mul, d, x);
             });
             if (TIMING) t_acc[4] += stamp() - t_b0; // pass B
             const unsigned long long t_em0 = stamp();
