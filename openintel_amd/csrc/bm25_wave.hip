@@ -26,8 +26,9 @@
 //            to add to; a run lists a doc once, so no two lanes ever update one entry) and emitted at the end;
 //   emit     straight into the task's OWN pool segment of capacity BM_R (a block cannot touch more docs than it
 //            has): no overflow path, no in-kernel selection; with a threshold only scores >= tau are written.
-// A task with more multi-doc postings than the table takes (384) is cut into doc-id windows (halved until they fit):
-// exact for any data, one window in the common case.  (Two earlier forms, both measured: an open-addressing table for
+// A task with more multi-doc postings than the table takes (384) is cut into doc-id windows (halved until they fit, down
+// to 2048 docs; below that the window's docs get dense accumulators instead -- at most 16 windows per task whatever the
+// query repeats): exact for any data, one window in the common case.  (Two earlier forms, both measured: an open-addressing table for
 // ALL docs -- a wave ran as slow as its longest probe chain, 26K cycles per task -- and a bitmap + rank perfect hash
 // with a dense accumulator array -- 65K cycles per task, instruction-bound on 32 fixed register slots per lane, the
 // rank sweep and a read-modify-write per posting.  DESIGN.md 4.3 has the ladders.)  HBM-bound by construction (8 B
@@ -39,6 +40,7 @@
 #define BW_WORDS (BW_R / 32)      // 1024 words per bitmap
 #define BW_HASH 512u              // entries {tag = doc-in-block + 1, f32 score bits} of the multi-doc table
 #define BW_MULTI_CAP 384u         // multi-doc postings a window may hold (load factor <= 0.75)
+#define BW_DENSE_W 2048u          // docs per window in dense mode (2048 f32 accumulators = the two maps' 8 KiB)
 #define BW_WAVES 4                // waves per workgroup
 #define BW_STAGE_TERMS 256u       // query terms of a pass staged in LDS (more: read from global memory)
 #define BW_MAX_Q 128u             // queries per pass (term offsets, weights and order staged in LDS)
@@ -170,32 +172,37 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
         // terms -- scalar work per TERM, not per chunk (the first form walked a scalar cursor per 64 postings: ~1500 SALU
         // instructions per task, as many as the vector work; PMC in DESIGN.md 4.3).
         const uint32_t ntf = nt < 64u ? nt : 64u;
-        uint32_t d_i0 = 0, d_e = 0, d_j = 0; // this lane's group (page 0: groups 0..63)
+        uint32_t d_i0 = 0, d_e = 0, d_j = 0; // this lane's group of the current PAGE (page p: groups 64 p .. 64 p + 63)
         uint32_t ng = 0;                      // groups of the first 64 terms (uniform)
-        {
-            const uint32_t n_mine = (my_e - my_s + 255u) >> 8; // groups of the term this lane holds the bounds of
+        const uint32_t n_mine = (my_e - my_s + 255u) >> 8; // groups of the term this lane holds the bounds of
+        auto build_page = [&](uint32_t page) {
+            d_i0 = 0; d_e = 0; d_j = 0;
+            const uint32_t gl = 64u * page + lane; // the group this lane describes
+            uint32_t acc = 0;
             for (uint32_t j = 0; j < ntf; ++j) {
                 const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)n_mine, (int)j);
                 if (nj == 0u) continue; // uniform
                 const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)my_s, (int)j);
                 const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
-                const bool mine = lane >= ng && lane < ng + nj;
-                d_i0 = mine ? sj + ((lane - ng) << 8) : d_i0;
+                const bool mine = gl >= acc && gl < acc + nj;
+                d_i0 = mine ? sj + ((gl - acc) << 8) : d_i0;
                 d_e = mine ? ej : d_e;
                 d_j = mine ? j : d_j;
-                ng += nj;
+                acc += nj;
             }
-        }
+            ng = acc;
+        };
+        build_page(0);
         struct Group {
             BwPosting p[4];
             uint32_t n; // postings in the group (uniform, 0..256)
             float w;    // idf of its term (uniform)
         };
-        // group g of the first page, g uniform (a compile-time constant for the kept groups); past the end: n = 0
-        auto load_group = [&](uint32_t g) {
+        // group `l` of the current page (l uniform; a compile-time constant for the kept groups of page 0); past the end: n = 0
+        auto load_group = [&](uint32_t page, uint32_t l) {
             Group G;
-            const bool have = g < ng && g < 64u;
-            const uint32_t gl = have ? g : 0u;
+            const bool have = l < 64u && 64u * page + l < ng;
+            const uint32_t gl = have ? l : 0u;
             const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane((int)d_i0, (int)gl);
             const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)d_e, (int)gl);
             const uint32_t tj = (uint32_t)__builtin_amdgcn_readlane((int)d_j, (int)gl);
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
         // the first BW_KEEP groups: all their loads in flight together, kept in registers for BOTH passes
         Group keep[BW_KEEP];
 #pragma unroll
-        for (int g = 0; g < BW_KEEP; ++g) keep[g] = load_group((uint32_t)g);
+        for (int g = 0; g < BW_KEEP; ++g) keep[g] = load_group(0u, (uint32_t)g);
         fetch_bounds(t + G, 0, nx_s, nx_e, nx_w, nx_ok); // the next task's bounds: in flight while this one is processed
         if (DBG == 1 || DBG == 2) {
             uint32_t x = my_s + my_e;
@@ -222,11 +229,11 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
             if (lane == 0 || x == 0xDEADBEEFu) seg_cnt[(uint64_t)q * seg_cnt_stride + block0 + blk] = x == 0xDEADBEEFu ? 1u : 0u;
             continue;
         }
-        // Every group of the task in query order: f(group).  Kept groups come out of registers; the rest of the first page
-        // is loaded one group ahead; tasks of more than 64 groups (16K postings) and terms beyond the 64th take the slow
-        // forms below.
-        const bool one_page = ng <= 64u;
-        auto for_each_group = [&](auto &&f) {
+        // Every group of the first 64 terms in query order: f(group).  Kept groups come out of registers; the rest streams one
+        // group ahead, page by page (a task of more than 64 groups -- 16K postings -- rebuilds the lanes' descriptors per
+        // page).  `stop()`: uniform predicate checked between groups -- pass A gives up as soon as the window has failed.
+        const uint32_t n_pages = (ng + 63u) >> 6;
+        auto for_each_group = [&](auto &&f, auto &&stop) {
 #pragma unroll
             for (int g = 0; g < BW_KEEP; ++g) {
                 // The kept postings are made opaque before each use: otherwise everything pass A derives from them (word
@@ -236,33 +243,26 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                 for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(keep[g].p[u].dib), "+v"(keep[g].p[u].impact));
                 if ((uint32_t)g < ng) f(keep[g]); // uniform
             }
-            if (ng > BW_KEEP && one_page) {
-                Group ga = load_group(BW_KEEP);
-                for (uint32_t g = BW_KEEP; g < ng; ++g) {
-                    const Group gb = load_group(g + 1u);
+            if (ng <= BW_KEEP) return;
+            for (uint32_t page = 0; page < n_pages; ++page) {
+                if (n_pages > 1u) build_page(page);
+                const uint32_t l0 = page == 0u ? BW_KEEP : 0u;
+                const uint32_t l1 = ng - 64u * page < 64u ? ng - 64u * page : 64u;
+                Group ga = load_group(page, l0);
+                for (uint32_t l = l0; l < l1; ++l) {
+                    if (stop()) { if (n_pages > 1u) build_page(0); return; }
+                    const Group gb = load_group(page, l + 1u);
                     f(ga);
                     ga = gb;
                 }
             }
+            if (n_pages > 1u) build_page(0);
         };
-        // slow forms: f(posting of this lane, lane holds one, idf weight), one 64-posting chunk at a time
-        auto for_each_slow_chunk = [&](auto &&f) {
+        // slow form (terms beyond the 64th of a long query): f(posting of this lane, lane holds one, idf weight), one chunk at a time
+        auto for_each_slow_chunk = [&](auto &&f, auto &&stop) {
             auto run = [&](uint32_t s, uint32_t e, float wt) {
-                for (uint32_t i0 = s; i0 < e; i0 += 64u) f(postings[i0 + lane < e ? i0 + lane : e - 1u], i0 + lane < e, wt);
+                for (uint32_t i0 = s; i0 < e && !stop(); i0 += 64u) f(postings[i0 + lane < e ? i0 + lane : e - 1u], i0 + lane < e, wt);
             };
-            if (!one_page) { // a task of more than 64 groups: everything past the kept groups, term by term
-                uint32_t seen_groups = 0;
-                for (uint32_t j = 0; j < ntf; ++j) {
-                    const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)my_s, (int)j);
-                    const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)my_e, (int)j);
-                    const uint32_t nj = (ej - sj + 255u) >> 8;
-                    // groups [seen_groups, seen_groups + nj) belong to this term; the first BW_KEEP groups overall are kept
-                    const uint32_t skip = seen_groups >= BW_KEEP ? 0u : (BW_KEEP - seen_groups < nj ? BW_KEEP - seen_groups : nj);
-                    const uint32_t from = sj + (skip << 8);
-                    run(from < ej ? from : ej, ej, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), (int)j)));
-                    seen_groups += nj;
-                }
-            }
             for (uint32_t g0 = 64; g0 < nt; g0 += 64) { // terms beyond the 64 a wave holds bounds for
                 uint32_t gs, ge, okm;
                 float gw;
@@ -273,9 +273,6 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                     run((uint32_t)__shfl((int)gs, (int)j, OI_WAVE), (uint32_t)__shfl((int)ge, (int)j, OI_WAVE), __shfl(gw, (int)j, OI_WAVE));
             }
         };
-        // NOTE on order when !one_page: the kept groups (the first BW_KEEP groups of the task) come first, then the
-        // rest term by term -- still query order, because the kept groups are a prefix of it.
-
         uint32_t out_cnt = 0;
         auto emit = [&](bool keepit, float v, uint32_t dib) { // all lanes call; appends the kept scores to the segment
             const unsigned long long m = __ballot(keepit);
@@ -288,6 +285,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
             }
         };
 
+        auto never = []() { return false; };
         uint32_t width = BW_R, lo = 0;
         while (lo < BW_R) {
             const uint32_t hi = lo + width;
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                         n_multi += (uint32_t)__popcll(__ballot(again));
                     }
                 }
-            });
+            }, [&]() { return n_multi > BW_MULTI_CAP; });
             for_each_slow_chunk([&](const BwPosting &p, bool have, float) {
                 const uint32_t d = p.dib, bit = 1u << (d & 31u);
                 const bool inw = have && d >= lo && d < hi;
@@ -328,13 +326,45 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                     if (again) atomicOr(&multi[d >> 5], bit);
                     n_multi += (uint32_t)__popcll(m);
                 }
-            });
+            }, [&]() { return n_multi > BW_MULTI_CAP; });
             if (TIMING) t_acc[3] += stamp() - t_a0; // pass A
             if (DBG == 3) { clear_maps(); lo = hi; continue; }
             if (n_multi > BW_MULTI_CAP) { // too many multi-doc postings for the table: clear, halve the window, again
                 clear_maps();
-                if (width > 1u) width >>= 1;
-                else { *overflow = 1u; lo = hi; } // cannot happen (a doc has <= 1024 postings here); never loop forever
+                if (width > BW_DENSE_W) { width >>= 1; continue; }
+                // Still too many at 2048 docs per window (a query that repeats a frequent term many times makes every
+                // doc of it "multi"): halving further would re-scan the task's runs once per handful of docs.  DENSE mode
+                // instead, bounded at 16 windows per task: the map region becomes 2048 f32 accumulators indexed by
+                // (doc - lo); every in-window posting is added in query order (a group is one run: distinct docs, so a
+                // group's four read-modify-writes are independent; a wave's LDS operations execute in program order).
+                float *dacc = reinterpret_cast<float *>(seen); // 8 KiB = both maps, all zero here (+0.0f)
+                auto dense_add = [&](bool inw, uint32_t d, float x) {
+                    const uint32_t a = inw ? d - lo : 0u;
+                    const float v = dacc[a];
+                    if (inw) dacc[a] = __fadd_rn(v, x);
+                };
+                for_each_group([&](const Group &g) {
+                    float v[4];
+                    bool inw[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t d = g.p[u].dib;
+                        inw[u] = 64u * u + lane < g.n && d >= lo && d < hi;
+                        v[u] = dacc[inw[u] ? d - lo : 0u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (inw[u]) dacc[g.p[u].dib - lo] = __fadd_rn(v[u], __fmul_rn(g.w, g.p[u].impact));
+                }, never);
+                for_each_slow_chunk([&](const BwPosting &p, bool have, float wt) {
+                    dense_add(have && p.dib >= lo && p.dib < hi, p.dib, __fmul_rn(wt, p.impact));
+                }, never);
+                for (uint32_t i = lane; i < BW_DENSE_W; i += 64) {
+                    const float v = dacc[i];
+                    emit(v > 0.0f && oi_f32_key(v) >= tau, v, lo + i);
+                }
+                clear_maps();
+                lo = hi;
                 continue;
             }
             const unsigned long long t_b0 = stamp();
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                         if (!__ballot(more)) break;
                     }
                 }
-            });
+            }, never);
             for_each_slow_chunk([&](const BwPosting &p, bool have, float wt) {
                 const uint32_t d = p.dib;
                 const bool inw = have && d >= lo && d < hi;
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                 const float x = __fmul_rn(wt, p.impact);
                 emit(inw && !mul && x > 0.0f && oi_f32_key(x) >= tau, x, d);
                 if (__ballot(mul)) accumulate(mul, d, x);
-            });
+            }, never);
             if (TIMING) t_acc[4] += stamp() - t_b0; // pass B
             const unsigned long long t_em0 = stamp();
             // ---- the multi docs' sums out of the table; clear it and the maps

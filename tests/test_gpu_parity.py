@@ -739,3 +739,76 @@ def test_sharded_pipeline_overlaps_fusion_and_returns_the_same_results(ctx, O):
         assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc)
     fctx.close()
     idx.close()
+
+
+def test_fuzz_small_shapes_bit_exact(ctx, O):
+    """Thirty random small configurations through the whole C-ABI path (oi_search_lists + oi_search), every BM25 kernel
+    on each: odd corpus sizes around the 32768-doc block boundary, 1..70 queries, 0..70 terms per query with repeats and
+    out-of-vocabulary ids (vocab 1 or 2: every doc holds the term and the query repeats it -- the wave kernel's dense
+    windows), depth and k from 1 to 1024, the batch scorers' dims plus odd ones, a nonzero doc_id_base.  Small-integer
+    embeddings: every dot product is exact in any order, so cosine, BM25 and fused lists must equal the oracle's bit
+    for bit.  (Progress goes to gpurun_out/fuzz_progress.log when that directory exists.)"""
+    import os
+    import time
+    import openintel_amd as oi
+    rng = np.random.default_rng(20261004)
+    log = None
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        log = open(os.path.join(out_dir, "fuzz_progress.log"), "w")
+    for case in range(30):
+        n = int(rng.choice([1, 2, 63, 64, 65, 1000, 32767, 32768, 32769, 40_000]))
+        dim = int(rng.choice([4, 8, 100, 384, 768, 1024]))
+        vocab = int(rng.choice([1, 2, 7, 50, 3000]))
+        B = int(rng.choice([1, 2, 8, 9, 33, 64, 70]))
+        depth = int(rng.choice([1, 2, 10, 100, 1000, 1024]))
+        k = int(rng.choice([1, 3, 10, 100, 1024]))
+        base = int(rng.choice([0, 5, 4_000_000_000 - 80_000]))
+        if n * dim * B > 150_000_000:      # keep the oracle's share of the test in seconds
+            dim = 8
+        t0 = time.perf_counter()
+        rows = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)
+        lens = rng.integers(0, 9, size=n)                          # empty docs allowed
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        terms = rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32)
+        queries = []
+        for b in range(B):
+            nt = int(rng.choice([0, 1, 2, 4, 4, 4, 9, 70]))
+            t = rng.integers(0, vocab + (2 if b % 4 == 0 else 0), size=nt).tolist()   # some ids >= vocab
+            queries.append(t)
+        qt, qo = oi.pack_query_terms(queries)
+        q = rng.integers(-3, 4, size=(B, dim)).astype(np.float32)
+        idx = oi.HybridIndex(ctx, n, dim, vocab, doc_id_base=base)
+        idx.set_embeddings(rows, normalize=False)
+        idx.set_forward(terms, offs)
+        idx.finalize()
+        idx.set_max_query_terms(128)
+        ref = []
+        for b in range(B):
+            cs, cd = O.topk(O.dot_scores(rows, q[b]), depth, False, base)
+            tv = np.array([t for t in queries[b] if t < vocab], np.uint32)
+            bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, base)
+            fs, fd = O.rrf_fuse(cd, bd, k)
+            ref.append((cs, cd, bs, bd, fs, fd))
+        t1 = time.perf_counter()
+        for mode in (idx.BM25_WAVE, idx.BM25_TAAT, idx.BM25_SCAN):
+            idx.set_bm25_mode(mode)
+            L = idx.search_lists(q, qt, qo, depth=depth)
+            R = idx.search(q, qt, qo, k=k, depth=depth)
+            for b in range(B):
+                cs, cd, bs, bd, fs, fd = ref[b]
+                tag = (case, n, dim, vocab, B, depth, k, base, mode, b)
+                assert int(L.cos_counts[b]) == cd.size and np.array_equal(L.cos_docs[b][:cd.size], cd), tag
+                assert np.array_equal(L.cos_scores[b][:cd.size], cs), tag
+                assert int(L.bm25_counts[b]) == bd.size and np.array_equal(L.bm25_docs[b][:bd.size], bd), tag
+                assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), tag
+                assert int(R.counts[b]) == fd.size and np.array_equal(R.docs[b][:fd.size], fd), tag
+                assert np.array_equal(R.scores[b][:fd.size].view(np.uint32), fs.view(np.uint32)), tag
+        idx.close()
+        if log:
+            log.write("case %d n=%d dim=%d vocab=%d B=%d depth=%d k=%d: oracle %.1fs gpu %.1fs\n" % (
+                case, n, dim, vocab, B, depth, k, t1 - t0, time.perf_counter() - t1))
+            log.flush()
+    if log:
+        log.close()
