@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             x0[c] = x1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((uint32_t)c < ncol) { x0[c] = row0[vidx[c]]; x1[c] = row1[vidx[c]]; } // (uniform condition)
+            if ((uint32_t)c < ncol) { x0[c] = oi_load_stream(row0 + vidx[c]); x1[c] = oi_load_stream(row1 + vidx[c]); } // (uniform condition)
         }
         score_row(x0, r);
         score_row(x1, r + n_waves);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             x0[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((uint32_t)c < ncol) x0[c] = row0[vidx[c]];
+            if ((uint32_t)c < ncol) x0[c] = oi_load_stream(row0 + vidx[c]);
         }
         score_row(x0, r);
     }

@@ -92,7 +92,7 @@ __device__ __forceinline__ void ks_issue_piece(const u32x4 &srd, uint32_t voff, 
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %4\n\t"
         "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen " OI_DMA_NT "lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(voff), "s"(srd), "s"(so), "s"(d)

@@ -7,6 +7,26 @@
 
 #define OI_WAVE 64
 
+// Cache policy of the corpus stream (LDS-DMA `buffer_load ... lds` in the cosine kernels): the rows are read once per
+// batch and are far larger than every cache, so they are loaded NON-TEMPORAL (MI355X_MICROARCH.md, row nt-weights:
+// "set nt on streamed bytes that one CU reads once").  Measured on the screen kernel at 10M x 768: 5.2-5.4 -> 4.7 ms per
+// batch, 72-74 % -> 82 % of the HBM spec.  -DOI_NO_NT (the ablation build) restores the default policy for A/B runs.
+#ifdef OI_NO_NT
+#define OI_DMA_NT ""
+#else
+#define OI_DMA_NT "nt "
+#endif
+// The same policy for a register load of a once-read stream (the batch-1 GEMV scorer's corpus rows).
+__device__ __forceinline__ float4 oi_load_stream(const float4 *p) {
+#ifdef OI_NO_NT
+    return *p;
+#else
+    typedef float oi_f32x4_t __attribute__((ext_vector_type(4)));
+    const oi_f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const oi_f32x4_t *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#endif
+}
+
 // Order-preserving map f32 -> u32 (ascending).  -0.0 is folded into +0.0 first so
 // that equal scores compare equal; NaN must be rejected by the caller.
 __device__ __forceinline__ uint32_t oi_f32_key(float s) {
