@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
             const float4 yv = qv[v];
             float4 xv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) xv[u] = x[u][v];
+            for (int u = 0; u < 4; ++u) xv[u] = oi_load_stream(x[u] + v); // (each survivor row is read once)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 a[u] = fmaf(xv[u].x, yv.x, a[u]); a[u] = fmaf(xv[u].y, yv.y, a[u]);

@@ -16,6 +16,24 @@
 #else
 #define OI_DMA_NT "nt "
 #endif
+__device__ __forceinline__ uint4 oi_load_stream(const uint4 *p) {
+#ifdef OI_NO_NT
+    return *p;
+#else
+    typedef uint32_t oi_u32x4_t __attribute__((ext_vector_type(4)));
+    const oi_u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const oi_u32x4_t *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+#endif
+}
+__device__ __forceinline__ uint2 oi_load_stream(const uint2 *p) {
+#ifdef OI_NO_NT
+    return *p;
+#else
+    typedef uint32_t oi_u32x2_t __attribute__((ext_vector_type(2)));
+    const oi_u32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const oi_u32x2_t *>(p));
+    return make_uint2(v[0], v[1]);
+#endif
+}
 // The same policy for a register load of a once-read stream (the batch-1 GEMV scorer's corpus rows).
 __device__ __forceinline__ float4 oi_load_stream(const float4 *p) {
 #ifdef OI_NO_NT
