@@ -30,6 +30,7 @@
 // each becomes a node in a per-title list, folded at the end into the keyword mask and the
 // first-occurrence order the reference's Vec has.  Tiles that do not fit the window, or that hold
 // more hits than nodes, are done one lane per title (hl_scan_title), which is also kernel v1.
+#include "oi_device.h"
 #include "oi_internal.h"
 
 #define HL_THREADS 256
@@ -207,17 +208,6 @@ struct HlShared {
     uint32_t n_nodes;
 };
 static_assert(sizeof(HlShared) <= 40 * 1024, "four workgroups per CU");
-
-__device__ static inline uint32_t hl_alnum4(uint32_t w) { // one bit per byte
-    const uint32_t hi = w & 0x80808080u;
-    const uint32_t w7 = w & 0x7F7F7F7Fu;
-    const uint32_t ge_a = (w7 | 0x20202020u) + (0x80u - 'a') * 0x01010101u;
-    const uint32_t gt_z = (w7 | 0x20202020u) + (0x7Fu - 'z') * 0x01010101u;
-    const uint32_t ge_0 = w7 + (0x80u - '0') * 0x01010101u;
-    const uint32_t gt_9 = w7 + (0x7Fu - '9') * 0x01010101u;
-    const uint32_t f = ((ge_a & ~gt_z) | (ge_0 & ~gt_9)) & ~hi & 0x80808080u;
-    return (((f >> 7) & 0x01010101u) * 0x00204081u >> 21) & 0xFu;
-}
 
 __device__ static inline uint32_t hl_title_of(const HlShared &s, uint32_t nt, uint32_t pos) {
     // largest j < nt with off[j] <= pos (empty titles share an offset; the last of them owns the byte):
@@ -406,8 +396,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
         const uint32_t i = tid + k * HL_THREADS;
         if (i < n16) {
             reinterpret_cast<uint4 *>(s.text)[i] = v[k];
-            s.am[1 + i] = (uint16_t)(hl_alnum4(v[k].x) | (hl_alnum4(v[k].y) << 4) | (hl_alnum4(v[k].z) << 8) |
-                                     (hl_alnum4(v[k].w) << 12));
+            s.am[1 + i] = (uint16_t)oi_alnum16(v[k]);
         }
     }
     __syncthreads();

@@ -313,7 +313,8 @@ __device__ __forceinline__ uint32_t lex_bloom_slot(uint32_t two_chars_folded) {
     return (two_chars_folded * 0x9E3779B1u) >> 24; // 8 bits
 }
 
-__device__ __forceinline__ void lex2_hit(Lex2Shared &s, uint32_t mult, uint32_t k0, uint32_t k1, uint32_t c8,
+template <class Sh>
+__device__ __forceinline__ void lex2_hit(Sh &s, uint32_t mult, uint32_t k0, uint32_t k1, uint32_t c8,
                                          uint32_t len, uint32_t post) {
     const uint32_t c8_len = c8 | (len << 8);
     const LexEntry e = s.table[lex_hash(k0, k1, c8_len, mult)];
@@ -325,7 +326,8 @@ __device__ __forceinline__ void lex2_hit(Lex2Shared &s, uint32_t mult, uint32_t 
 }
 
 // Exact per-char path (possible U+212A / U+0130 nearby); positions relative to the tile's first byte.
-__device__ void lex2_slow_chunk(const uint8_t *tb, uint32_t lo, uint32_t hi, uint32_t j, Lex2Shared &s,
+template <class Sh>
+__device__ void lex2_slow_chunk(const uint8_t *tb, uint32_t lo, uint32_t hi, uint32_t j, Sh &s,
                                 uint32_t mult) {
     for (uint32_t pos = lo; pos < hi; ++pos) {
         while (pos >= s.off[j + 1]) ++j;
@@ -414,6 +416,9 @@ struct SumPartial {
 // has a fixed shape -- per tile: thread t adds its posts (t, t + 256), then the wave tree; a wave adds its tiles in
 // order; then the four waves in order -- so it is bitwise reproducible for a given grid.
 // (launch bound 4 waves per SIMD = 128 VGPRs: the kernel sat at exactly 128 before the fused epilogue)
+// DBG (ablation builds only): 1 staging only, 2 + windows and alnum masks, 3 + token starts / post boundaries,
+// 4 + the token loop up to the length screen, 5 + Bloom screen and queue (no look-ups); 0 = the product.
+template <int DBG>
 __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *blob, const uint64_t *offsets,
                                                               uint64_t n, uint64_t blob_bytes,
                                                               const LexEntry *table, const uint32_t *bloom,
@@ -480,6 +485,7 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
             }
             if (lane == 0) s.q_cnt[wv] = 0;
             __syncthreads();
+            if (DBG == 1) { if (s.text[tid] == 0xDEADBEEFu) s.bull[0] = 1; __syncthreads(); continue; }
 
             // lane chunk: tile-relative positions [c0, c0+64); may start before 0 in the first sub-tile
             const int64_t c0s = (int64_t)sb - head + (int64_t)tid * LX_CH;
@@ -526,6 +532,7 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                                          ((uint64_t)lex2_alnum4(W[22]) << 8);
                     const uint64_t prevbit = (lex2_alnum4(W[3]) >> 3) & 1u;
                     uint64_t starts = cand & ~((cand << 1) | prevbit);
+                    if (DBG == 2) { if ((starts ^ ext) == 0xDEADBEEFull) s.bull[0] = 1; goto lane_done; }
                     // a post's first byte starts a token whatever precedes it
                     {
                         uint32_t jj = j;
@@ -542,6 +549,7 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                     if (lb) starts &= ~((1ull << lb) - 1ull);
                     if (hb < 64) starts &= (1ull << hb) - 1ull;
                     uint32_t pend = s.off[j + 1]; // end of the current post, kept in a register
+                    if (DBG == 3) { if ((starts ^ pend) == 0xDEADBEEFull) s.bull[0] = 1; goto lane_done; }
                     while (starts) {
                         const uint32_t b = __builtin_ctzll(starts);
                         starts &= starts - 1;
@@ -554,6 +562,7 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                         const uint32_t room = pend - pos;
                         if (len > room) len = room;
                         if (len < 2 || len > 9) continue; // lexicon words are 2..9 chars
+                        if (DBG == 4) { if ((len ^ pos) == 0xDEADBEEFu) s.bull[0] = 1; continue; }
                         // first two chars, case-folded, against the Bloom filter (the only LDS access here)
                         const uint32_t ti = tbase + b, wi = ti >> 2;
                         const uint32_t y0 = s.text[lx_phys(wi)], y1 = s.text[lx_phys(wi + 1)];
@@ -569,9 +578,10 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                         else lex2_lookup(s, mult, ti, len, j); // queue full: look it up in place
                     }
                 }
+            lane_done:;
             }
             // ---- dense pass over this wave's queue (LDS ops of one wave complete in order)
-            {
+            if (DBG != 5) {
                 uint32_t nq = s.q_cnt[wv];
                 if (nq > LX_QCAP) nq = LX_QCAP;
                 for (uint32_t c = lane; c < nq; c += 64) {
@@ -580,6 +590,308 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                 }
             }
             __syncthreads(); // LDS text is restaged next iteration
+        }
+        // ---- one PostSignal per post (lexicon.rs:62-72; Polarity::new is the identity on [-1,1])
+        uint32_t a_src1 = 0, a_bull = 0, a_bear = 0, a_neu = 0, a_spec = 0; // this thread's posts of THIS tile
+        double a_psum = 0.0;
+        for (uint32_t i = tid; i < np; i += LEX_THREADS) {
+            const double bh = (double)s.bull[i], rh = (double)s.bear[i];
+            const double p = (bh + rh == 0.0) ? 0.0 : (bh - rh) / (bh + rh);
+            const bool sp = s.spec[i] != 0;
+            if (pol_out) pol_out[p0 + i] = p;
+            if (spec_out) spec_out[p0 + i] = (uint8_t)sp;
+            if (partials) { // speculation_engine.rs:81-97, on the signal just computed
+                a_psum += p;
+                if (p > tau) ++a_bull; else if (p < -tau) ++a_bear; else ++a_neu;
+                a_spec += sp ? 1u : 0u;
+                if (sources) a_src1 += sources[p0 + i] != 0;
+            }
+        }
+        if (partials) { // fold the tile into the wave's running sums (fixed order: tiles in sequence)
+            uint32_t v5[5] = {a_src1, a_bull, a_bear, a_neu, a_spec};
+#pragma unroll
+            for (int k5 = 0; k5 < 5; ++k5) { const uint32_t r = oi_wave_sum(v5[k5]); if (lane == 0) r_u[k5][wv] += r; }
+            const double d = oi_wave_sum(a_psum);
+            if (lane == 0) r_d[wv] += d;
+        }
+    }
+    if (partials) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t[5] = {0, 0, 0, 0, 0};
+            double ds = 0.0;
+            for (int ww = 0; ww < LEX_THREADS / 64; ++ww) {
+                for (int k5 = 0; k5 < 5; ++k5) t[k5] += r_u[k5][ww];
+                ds += r_d[ww];
+            }
+            SumPartial o;
+            o.src1 = t[0]; o.bull = t[1]; o.bear = t[2]; o.neu = t[3]; o.spec = t[4];
+            o.src0 = sources ? (t[1] + t[2] + t[3]) - t[0] : 0; // posts of this workgroup not from source 1
+            o.psum = ds; o.pad = 0.0;
+            partials[blockIdx.x] = o;
+        }
+    }
+}
+
+// ---- third generation ---------------------------------------------------------------------------------
+// The v2 scan was VALU-issue-bound (PMC, 10M posts: 1574 VALU wave-instructions per 4 KiB wave chunk, 82 % of the issue
+// slots; ladder: staging 0.34 ms, alnum windows +0.20, token loop +0.63, look-ups +0.12).  v3 removes instructions:
+//  (1) every 16-byte unit is classified ONCE, by the lane that stages it (v2 re-classified a 20-byte halo per lane and
+//      read a 24-dword window back from LDS): four range tests folded into one XOR chain, the per-byte flags gathered
+//      with two v_dot4_u32_u8 per 8 bytes instead of a multiply-shift movemask per dword; the 16 alnum bits go to a
+//      bitmap in LDS next to the (now unpadded, ds_write_b128) text;
+//  (2) post starts are a second bitmap (one LDS atomic per post and sub-tile): "a post's first byte starts a token and
+//      its end cuts one" become mask operations -- no binary search and no post walk in the token loop; the post of a
+//      token is looked up only for the few that are lexicon words;
+//  (3) the token loop works on 32-bit masks (ffbl, alignbit) instead of 64-bit ones, reads the two Bloom chars as
+//      bytes, takes the Bloom word from LDS (v2: a 7-select chain over 8 registers), and compacts candidates with a
+//      ballot (no LDS atomic with return).
+#define L3_SUB 16384u
+#define L3_UNITS (L3_SUB / 16u + 2u)       // halo units of 16 bytes: [g0-16, g0+L3_SUB+16)
+#define L3_BITW 516u                       // u32 words of a bit-per-byte map: unit v is u16 number 3 + v
+#define L3_BLOOM_MUL 0x9E3779u             // 24-bit: v_mul_u32_u24 is full rate
+#define L3_SLOTS 4u                        // candidates a lane can park per sub-tile (more: looked up in place)
+
+struct Lex3Shared {
+    LexEntry table[LEX_SLOTS];
+    uint32_t off[LX_PPT + 1];
+    uint32_t bull[LX_PPT], bear[LX_PPT], spec[LX_PPT];
+    uint4 text[L3_UNITS];                  // bytes [g0-16, g0+L3_SUB+16), unit v at text[v]
+    uint32_t abits[L3_BITW];               // 1 = ASCII alphanumeric byte
+    uint32_t tbits[2][L3_BITW];            // 1 = first byte of a post (or the tile's end); double buffered
+    uint32_t spchunk[2][LEX_THREADS / 32]; // lane chunk needs the exact per-char path
+    uint32_t bloom[8];
+    uint32_t jchunk[LEX_THREADS];          // post holding the first byte of lane chunk c
+    uint32_t cand[LEX_THREADS / 64][L3_SLOTS][64]; // per wave: lane l's k-th candidate, then the same region compacted
+};
+
+__device__ __forceinline__ uint32_t lex3_bloom_hash(uint32_t two_folded) { return __umul24(two_folded, L3_BLOOM_MUL); } // slot = bits 24..31
+
+// Look one candidate up: `len` alnum chars at LDS text byte `ti`; pos = its tile-relative byte position.
+__device__ __forceinline__ void lex3_lookup(Lex3Shared &s, uint32_t mult, uint32_t ti, uint32_t len, uint32_t pos) {
+    const uint32_t *t32 = reinterpret_cast<const uint32_t *>(s.text);
+    const uint32_t wi = ti >> 2, sh = ti & 3u;
+    const uint32_t x0 = t32[wi], x1 = t32[wi + 1], x2 = t32[wi + 2], x3 = t32[wi + 3];
+    const uint32_t t0 = __builtin_amdgcn_alignbyte(x1, x0, sh) | 0x20202020u;
+    const uint32_t t1 = __builtin_amdgcn_alignbyte(x2, x1, sh) | 0x20202020u;
+    const uint32_t t2 = __builtin_amdgcn_alignbyte(x3, x2, sh) | 0x20202020u;
+    const uint32_t k0 = t0 & byte_mask(len);
+    const uint32_t k1 = len > 4 ? (t1 & byte_mask(len - 4)) : 0u;
+    const uint32_t c8_len = (len == 9 ? (t2 & 0xFFu) : 0u) | (len << 8);
+    const LexEntry e = s.table[lex_hash(k0, k1, c8_len, mult)];
+    if (e.flags != 0 && e.k0 == k0 && e.k1 == k1 && e.c8_len == c8_len) {
+        // the post holding pos: largest j with off[j] <= pos (empty posts share an offset); from its chunk's first post
+        uint32_t jl = s.jchunk[(ti - 16u) >> 6];
+        while (s.off[jl + 1] <= pos) ++jl; // off[np] = the tile's end > pos
+        if (e.flags & 1u) atomicAdd(&s.bull[jl], 1u);
+        if (e.flags & 2u) atomicAdd(&s.bear[jl], 1u);
+        if (e.flags & 4u) atomicOr(&s.spec[jl], 1u);
+    }
+}
+
+// DBG (ablation builds only): 1 staging + classification only, 2 + masks and token starts, 3 + token loops (no look-ups).
+template <int DBG>
+__global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_scan_kernel(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                                                                   uint64_t blob_bytes, const LexEntry *table,
+                                                                   const uint32_t *bloom, uint32_t mult, double *pol_out,
+                                                                   uint8_t *spec_out, const uint8_t *sources, double tau,
+                                                                   SumPartial *partials) {
+    __shared__ __attribute__((aligned(16))) Lex3Shared s;
+    __shared__ uint32_t r_u[5][LEX_THREADS / 64]; // the summary's running sums, one set per wave (see lexicon_kernel)
+    __shared__ double r_d[LEX_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 5 * (LEX_THREADS / 64)) (&r_u[0][0])[tid] = 0u;
+    if (tid < LEX_THREADS / 64) r_d[tid] = 0.0;
+    reinterpret_cast<uint4 *>(s.table)[tid] = reinterpret_cast<const uint4 *>(table)[tid];
+    if (tid < 8) s.bloom[tid] = bloom[tid];
+    uint16_t *ab16 = reinterpret_cast<uint16_t *>(s.abits);
+    const uint8_t *text8 = reinterpret_cast<const uint8_t *>(s.text);
+
+    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p0 = tile * LX_PPT;
+        const uint32_t np = (uint32_t)((n - p0) < LX_PPT ? (n - p0) : LX_PPT);
+        __syncthreads(); // previous tile fully written out
+        const uint64_t byte_begin = offsets[p0];
+        // this thread's post starts (tile-relative; the tile's end counts as one), kept for every sub-tile's bitmap
+        uint32_t myoff[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t i = tid + (uint32_t)k * LEX_THREADS;
+            myoff[k] = 0xFFFFFFFFu;
+            if (i <= np) { myoff[k] = (uint32_t)(offsets[p0 + i] - byte_begin); s.off[i] = myoff[k]; }
+        }
+        for (uint32_t i = tid; i < LX_PPT; i += LEX_THREADS) { s.bull[i] = 0; s.bear[i] = 0; s.spec[i] = 0; }
+        for (uint32_t i = tid; i < 2 * L3_BITW; i += LEX_THREADS) (&s.tbits[0][0])[i] = 0;
+        if (tid < 2 * (LEX_THREADS / 32)) (&s.spchunk[0][0])[tid] = 0;
+        __syncthreads();
+        const uint32_t n_bytes = s.off[np];
+        const uint8_t *tb = blob + byte_begin;
+        const uint32_t head = (uint32_t)(byte_begin & 15u); // sub-tiles start 16-byte aligned in the blob
+        // A sub-tile's loads are issued one sub-tile ahead and stay in flight across the token loops.  They are not
+        // predicated (a unit outside the blob reads the blob's first 16 bytes and is zeroed by fixup): a lane's loads
+        // go out together instead of each waiting at the end of its own branch.
+        constexpr uint32_t kSteps = (L3_UNITS + LEX_THREADS - 1) / LEX_THREADS;
+        uint4 xs[kSteps];
+        auto issue = [&](const uint64_t g0_) {
+            if (g0_ >= 16 && g0_ + L3_SUB + 16 <= blob_bytes) { // the whole window lies inside the blob
+                const uint4 *src = reinterpret_cast<const uint4 *>(blob + (g0_ - 16));
+#pragma unroll
+                for (uint32_t k = 0; k < kSteps; ++k) {
+                    const uint32_t v = tid + k * LEX_THREADS;
+                    xs[k] = src[v < L3_UNITS ? v : 0u];
+                }
+            } else if (blob_bytes >= 16) {
+#pragma unroll
+                for (uint32_t k = 0; k < kSteps; ++k) {
+                    const uint64_t a = g0_ + (uint64_t)(tid + k * LEX_THREADS) * 16; // unit v covers [a-16, a)
+                    const bool whole = a >= 16 && a <= blob_bytes;
+                    xs[k] = *reinterpret_cast<const uint4 *>(blob + (whole ? a - 16 : 0));
+                }
+            }
+        };
+        auto fixup = [&](const uint64_t g0_, uint4 (&x)[kSteps]) {
+            if (g0_ >= 16 && g0_ + L3_SUB + 16 <= blob_bytes) return;
+#pragma unroll
+            for (uint32_t k = 0; k < kSteps; ++k) {
+                const uint64_t a = g0_ + (uint64_t)(tid + k * LEX_THREADS) * 16;
+                uint4 z = make_uint4(0, 0, 0, 0);
+                if (a >= 16) {
+                    const uint64_t src = a - 16;
+                    if (src + 16 <= blob_bytes) z = x[k];
+                    else if (src < blob_bytes) z = lex_load_tail(blob, src, blob_bytes); // the piece the blob ends in
+                }
+                x[k] = z;
+            }
+        };
+        issue(byte_begin - head);
+        uint32_t it = 0;
+        for (uint32_t sb = 0; sb < n_bytes + head; sb += L3_SUB, ++it) {
+            const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+            const uint64_t g0 = byte_begin - head + sb; // absolute, 16-byte aligned; tile-relative position sb - head
+            // ---- stage [g0-16, g0+L3_SUB+16): the loads were issued a sub-tile ago (or before the loop)
+            fixup(g0, xs);
+            // post-start bits of this sub-tile (bit 48 + r for the byte r past g0-16); the other buffer is cleared for the next
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t r = myoff[k] + 16u + head - sb; // wraps far out of range for posts before the window
+                if (myoff[k] != 0xFFFFFFFFu && r < L3_SUB + 32u) atomicOr(&s.tbits[cur][(48u + r) >> 5], 1u << ((48u + r) & 31u));
+            }
+            for (uint32_t i = tid; i < L3_BITW; i += LEX_THREADS) s.tbits[nxt][i] = 0;
+            if (tid < LEX_THREADS / 32) s.spchunk[nxt][tid] = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < kSteps; ++k) {
+                const uint32_t v = tid + k * LEX_THREADS;
+                if (v >= L3_UNITS) continue;
+                const uint4 x = xs[k];
+                s.text[v] = x;
+                ab16[3u + v] = (uint16_t)oi_alnum16(x);
+                if ((x.x | x.y | x.z | x.w) & 0x80808080u) { // a 0xAA / 0xB0 byte may be part of U+212A / U+0130
+                    bool sp = false;
+                    const uint32_t w4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sp = sp || swar_has_byte(w4[i], 0xAAu) || swar_has_byte(w4[i], 0xB0u);
+                    if (sp) { // lane chunk c looks at units 4c .. 4c+5 (16 bytes either side of its own four)
+                        const uint32_t c_hi = v >> 2, c_lo = v >= 5 ? (v - 2) >> 2 : 0u;
+                        for (uint32_t c = c_lo; c <= c_hi && c < LEX_THREADS; ++c) atomicOr(&s.spchunk[cur][c >> 5], 1u << (c & 31u));
+                    }
+                }
+            }
+            if (sb + L3_SUB < n_bytes + head) issue(g0 + L3_SUB); // the next sub-tile's window
+            __syncthreads();
+            if (DBG == 1) { if (s.abits[tid] == 0xDEADBEEFu) s.bull[0] = 1; __syncthreads(); continue; }
+
+            // ---- lane chunk: tile-relative positions [c0s, c0s+64) (negative in front of the tile's first byte)
+            const int64_t c0s = (int64_t)sb - head + (int64_t)tid * 64;
+            const int64_t lo_s = c0s > 0 ? c0s : 0;
+            const int64_t hi_s = (c0s + 64) < (int64_t)n_bytes ? (c0s + 64) : (int64_t)n_bytes;
+            uint32_t S0 = 0, S1 = 0, E0 = 0, E1 = 0, En = 0; // token starts / token ends (non-alnum or a post's first byte)
+            if (lo_s < hi_s) {
+                const uint32_t lo = (uint32_t)lo_s, hi = (uint32_t)hi_s;
+                uint32_t jl = 0, jr = np; // post containing lo: largest j with off[j] <= lo
+                while (jr - jl > 1) {
+                    const uint32_t mid = (jl + jr) >> 1;
+                    if (s.off[mid] <= lo) jl = mid; else jr = mid;
+                }
+                s.jchunk[tid] = jl; // read by this wave's look-ups only
+                if ((s.spchunk[cur][tid >> 5] >> (tid & 31u)) & 1u) {
+                    lex2_slow_chunk(tb, lo, hi, jl, s, mult);
+                } else {
+                    const uint16_t *tb16 = reinterpret_cast<const uint16_t *>(s.tbits[cur]);
+                    const uint2 a = *reinterpret_cast<const uint2 *>(ab16 + 4u * tid + 4u);
+                    const uint2 t = *reinterpret_cast<const uint2 *>(tb16 + 4u * tid + 4u);
+                    const uint32_t a_prev = ab16[4u * tid + 3u], a_next = ab16[4u * tid + 8u], t_next = tb16[4u * tid + 8u];
+                    E0 = ~a.x | t.x;
+                    E1 = ~a.y | t.y;
+                    En = ~a_next | t_next | 0xFFFF0000u; // 16 bytes of look-ahead: enough to see that a token is longer than 9
+                    S0 = a.x & (~((a.x << 1) | (a_prev >> 15)) | t.x);
+                    S1 = a.y & (~((a.y << 1) | (a.x >> 31)) | t.y);
+                    const uint32_t lb = (uint32_t)(lo_s - c0s), hb = (uint32_t)(hi_s - c0s); // keep [lo, hi)
+                    const uint64_t keep = (hb < 64 ? (1ull << hb) - 1ull : ~0ull) & ~((1ull << lb) - 1ull);
+                    S0 &= (uint32_t)keep;
+                    S1 &= (uint32_t)(keep >> 32);
+                }
+            }
+            if (DBG == 2) { if ((S0 ^ S1 ^ E0 ^ E1 ^ En) == 0xDEADBEEFu) s.bull[0] = 1; __syncthreads(); continue; }
+            // ---- token loops, one per 32-byte half; every lane of the wave stays in them (qn is wave-uniform)
+            const uint32_t pos_base = sb - head - 16u; // tile-relative position of text byte 0 (mod 2^32)
+            // one token of a 32-byte half: its length from the end markers, the length screen, the Bloom screen
+            auto token = [&](uint32_t &S, const uint32_t Ecur, const uint32_t Enext, const uint32_t tbase, bool &pass, uint32_t &ent) {
+                pass = false;
+                ent = 0;
+                if (S) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(S);
+                    S &= S - 1u;
+                    const uint32_t y = __builtin_amdgcn_alignbit(Enext, Ecur, b) >> 1; // end markers after the first char
+                    const uint32_t len = (uint32_t)__ffs((int)y);                      // chars up to the first end; 0: none in sight
+                    if (len - 2u < 8u) { // lexicon words are 2..9 chars
+                        const uint32_t ti = tbase + b;
+                        const uint32_t two = ((uint32_t)text8[ti] | ((uint32_t)text8[ti + 1] << 8)) | 0x2020u;
+                        const uint32_t h = lex3_bloom_hash(two);
+                        pass = (s.bloom[h >> 29] >> ((h >> 24) & 31u)) & 1u;
+                        ent = ti | (len << 16);
+                    }
+                }
+            };
+            // a candidate is parked in the lane's own column (no ballot, no atomic in the loop)
+            uint32_t cnt = 0;
+            auto push = [&](bool pass, uint32_t ent) {
+                if (pass) {
+                    if (cnt < L3_SLOTS) s.cand[wv][cnt][lane] = ent;
+                    else if (DBG == 0) lex3_lookup(s, mult, ent & 0xFFFFu, ent >> 16, pos_base + (ent & 0xFFFFu)); // column full
+                    ++cnt;
+                }
+            };
+            // both halves in one loop: the trip count is the longer half's, and the two LDS chains overlap
+            while (__any((S0 | S1) != 0u)) {
+                bool pa, pb;
+                uint32_t ea, eb;
+                token(S0, E0, E1, 16u + tid * 64u, pa, ea);
+                token(S1, E1, En, 48u + tid * 64u, pb, eb);
+                push(pa, ea);
+                push(pb, eb);
+            }
+            // ---- compact the columns (prefix sum of the 0..4 counts from three ballots), then look the candidates up with
+            // all lanes busy (LDS ops of one wave complete in order; the entries pass through registers)
+            if (DBG == 0) {
+                cnt = cnt < L3_SLOTS ? cnt : L3_SLOTS;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+                const uint32_t base = (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+                const uint32_t nq = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+                uint32_t mine[L3_SLOTS];
+#pragma unroll
+                for (uint32_t k = 0; k < L3_SLOTS; ++k) mine[k] = s.cand[wv][k][lane];
+                uint32_t *flat = &s.cand[wv][0][0];
+#pragma unroll
+                for (uint32_t k = 0; k < L3_SLOTS; ++k)
+                    if (k < cnt) flat[base + k] = mine[k];
+                for (uint32_t c = lane; c < nq; c += 64) {
+                    const uint32_t ent = flat[c];
+                    lex3_lookup(s, mult, ent & 0xFFFFu, ent >> 16, pos_base + (ent & 0xFFFFu));
+                }
+            } else if (cnt == 0xDEADBEEFu) s.bull[0] = 1;
+            __syncthreads(); // text and bitmaps are restaged next iteration
         }
         // ---- one PostSignal per post (lexicon.rs:62-72; Polarity::new is the identity on [-1,1])
         uint32_t a_src1 = 0, a_bull = 0, a_bear = 0, a_neu = 0, a_spec = 0; // this thread's posts of THIS tile
@@ -662,6 +974,8 @@ static bool build_lex_table(LexEntry *table, uint32_t *mult_out, uint32_t *bloom
     for (auto &w : words) { // first two chars (already lowercase; |0x20 is the kernel's case fold)
         const uint32_t slot = (((w.k0 & 0xFFFFu) | 0x2020u) * 0x9E3779B1u) >> 24;
         bloom[slot >> 5] |= 1u << (slot & 31u);
+        const uint32_t h3 = (uint32_t)((uint64_t)((w.k0 & 0xFFFFu) | 0x2020u) * L3_BLOOM_MUL); // lex3_bloom_hash
+        bloom[8 + (h3 >> 29)] |= 1u << ((h3 >> 24) & 31u);                                      // v3's filter: words 8..15
     }
     // smallest odd multiplier that makes the hash perfect over the 39 distinct words
     for (uint32_t mult = 1; mult < (1u << 24); mult += 2) {
@@ -698,7 +1012,9 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     }
     const LexEntry *d_table = tb.as<LexEntry>();
     const uint32_t *d_bloom = reinterpret_cast<const uint32_t *>(d_table + LEX_SLOTS);
-    static const bool v1 = oi_ablation_env("OI_LEXICON_V1") != nullptr; // A/B switch: the first-generation scan
+    static const bool v1 = oi_ablation_env("OI_LEXICON_V1") != nullptr; // A/B switches: the first / second generation scans
+    static const bool v2 = oi_ablation_env("OI_LEXICON_V2") != nullptr;
+    (void)v2;
     const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
     const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
     const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
@@ -716,8 +1032,21 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
             hipLaunchKernelGGL(lexicon_kernel_v1, dim3(grid1), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
                                blob_bytes, d_table, h_mult, d_pol, d_spec);
         } else {
-            hipLaunchKernelGGL(lexicon_kernel, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                               blob_bytes, d_table, d_bloom, h_mult, d_pol, d_spec, d_sources, tau, d_partials);
+#ifdef OI_ABLATION
+            static const char *dbg_s = oi_ablation_env("OI_LEX_DBG");
+            const int dbg = dbg_s ? atoi(dbg_s) : 0;
+#define LEX_GO(K, D, BL) hipLaunchKernelGGL(K<D>, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n, \
+                                            blob_bytes, d_table, BL, h_mult, d_pol, d_spec, d_sources, tau, d_partials)
+            if (v2) switch (dbg) { case 1: LEX_GO(lexicon_kernel, 1, d_bloom); break; case 2: LEX_GO(lexicon_kernel, 2, d_bloom); break;
+                                   case 3: LEX_GO(lexicon_kernel, 3, d_bloom); break; case 4: LEX_GO(lexicon_kernel, 4, d_bloom); break;
+                                   case 5: LEX_GO(lexicon_kernel, 5, d_bloom); break; default: LEX_GO(lexicon_kernel, 0, d_bloom); }
+            else switch (dbg) { case 1: LEX_GO(lexicon_scan_kernel, 1, d_bloom + 8); break; case 2: LEX_GO(lexicon_scan_kernel, 2, d_bloom + 8); break;
+                                case 3: LEX_GO(lexicon_scan_kernel, 3, d_bloom + 8); break; default: LEX_GO(lexicon_scan_kernel, 0, d_bloom + 8); }
+#undef LEX_GO
+#else
+            hipLaunchKernelGGL(lexicon_scan_kernel<0>, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
+                               blob_bytes, d_table, d_bloom + 8, h_mult, d_pol, d_spec, d_sources, tau, d_partials);
+#endif
         }
         OI_HIP_CHECK(hipGetLastError());
     }

@@ -86,3 +86,22 @@ __device__ __forceinline__ void oi_pool_append(uint64_t *pool, uint32_t *count, 
     if (pos < cap) pool[pos] = key;
     else *overflow = 1u;
 }
+
+// ---- byte classification for the text scans (lexicon.hip, headline.hip) -------------------------------
+// 0x80 in every byte of w that is [0-9A-Za-z].  Per range: bit 7 of (x + 0x80 - lo) is x >= lo and bit 7 of
+// (x + 0x7F - hi) is x > hi (x < 0x80: no carries); "above hi" implies "at least lo", so their XOR is "in range",
+// and the two ranges are disjoint, so the XOR of all four is "in either".  Letters are tested case-folded (|0x20 maps
+// A-Z onto a-z and nothing else into that range), digits unfolded (0x10..0x19 fold onto the digits).
+__device__ __forceinline__ uint32_t oi_alnum_flags(uint32_t w) {
+    const uint32_t w7 = w & 0x7F7F7F7Fu, fold = w7 | 0x20202020u;
+    const uint32_t r = (fold + 0x1F1F1F1Fu) ^ (fold + 0x05050505u) ^ (w7 + 0x50505050u) ^ (w7 + 0x46464646u);
+    return r & ~w & 0x80808080u;
+}
+// 16 bytes -> 16 bits (bit i = byte i is alnum); each flagged byte is 128, the dot products weigh byte k by 2^k
+__device__ __forceinline__ uint32_t oi_alnum16(uint4 x) {
+    const uint32_t lo = __builtin_amdgcn_udot4(oi_alnum_flags(x.y), 0x80402010u,
+                                               __builtin_amdgcn_udot4(oi_alnum_flags(x.x), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(oi_alnum_flags(x.w), 0x80402010u,
+                                               __builtin_amdgcn_udot4(oi_alnum_flags(x.z), 0x08040201u, 0u, false), false);
+    return (lo >> 7) | (hi << 1);
+}
