@@ -1016,7 +1016,9 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     static const bool v2 = oi_ablation_env("OI_LEXICON_V2") != nullptr;
     (void)v2;
     const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
-    const uint32_t max_grid = (uint32_t)ctx->num_cus * 8u;
+    // (4 workgroups are resident per CU; 16 per CU over the tile loop balance the tail: 1.042 / 1.023 / 1.009 ms at 4 / 8 / 16)
+    static const char *grid_s = oi_ablation_env("OI_LEX_GRID"); // A/B switch: workgroups per CU
+    const uint32_t max_grid = (uint32_t)ctx->num_cus * (grid_s ? (uint32_t)atoi(grid_s) : 16u);
     const uint32_t grid = (uint32_t)(n_tiles < max_grid ? n_tiles : max_grid);
     SumPartial *d_partials = nullptr;
     if (summary) {
