@@ -106,6 +106,27 @@ def test_lexicon_unicode_and_edge_cases(ctx, O):
     _check_lexicon(ctx, O, texts)
 
 
+def test_lexicon_chunk_half_and_subtile_phases(ctx, O):
+    """The third-generation scan's own seams: 32-byte halves, 64-byte lane chunks, 16-byte units, 16 KiB sub-tiles,
+    the per-lane candidate columns (more than four candidates in one chunk) and the exact-path window around
+    U+212A / U+0130 -- every phase of each, plus posts that begin or end exactly on them."""
+    texts = []
+    for pad in range(0, 72):      # lexicon words sliding over a half / chunk seam, preceded and followed by separators
+        texts.append("#" * pad + "squeeze bagholder up iv 0dte contracts" + "#" * 7)
+        texts.append("x" * pad + " up")                              # a 2-char word whose second char opens the next chunk
+        texts.append("." * pad + "pumK rocKet tanK caKlls İv moonİ up İ striKe")   # exact-path bytes at every unit / chunk offset
+    for pad in range(0, 40):      # ... and over a 16 KiB sub-tile seam
+        texts.append("q" * (16384 - 20 + pad - 1) + " rocket drilling theta")
+        texts.append("e" * (16384 + pad - 3) + " " + "K" + "pump pumK")
+    texts.append("up " * 3000)                                       # 21 candidates per chunk: the columns overflow
+    texts.append("iv.up,0dte;itm otm" * 1500)
+    texts.append(" ".join(["bull", "bears", "bear", "bulls", "red", "reds", "tank", "tanks"] * 1200))  # Bloom false positives
+    # posts that start / end exactly on a chunk, a half, a sub-tile (the packed blob has no separators between posts)
+    texts += ["m" * 64, "oon moon", "c" * 31 + " ", "up", "", "", "s" * 16383, "ell sell", "", "y" * 16384, "olo yolo"]
+    texts += ["gamma"] * 700 + [""] * 300 + ["delta vega"] * 300       # many posts per chunk, runs of empty posts
+    _check_lexicon(ctx, O, texts)
+
+
 def test_lexicon_many_tiny_posts_and_random_corpus(ctx, O):
     from openintel_amd import synth
     rng = np.random.default_rng(5)
