@@ -96,6 +96,9 @@ def main():
                          "products (six bf16 MFMAs)")
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: do not overlap exchange + fusion with the next batch's lists")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="N > 1, pipelined: batches whose lists are scored at once, each through its own view of the shard "
+                         "(own stream and workspaces; sharded.ShardedPipeline); 1 = one at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-screen-copy", action="store_true", help="skip the opt-in screen-copy side measurement")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
@@ -181,14 +184,18 @@ def main():
     # N > 1: throughput mode -- the exchange + fusion of batch i overlap the lists of batch i + 1 (sharded.ShardedPipeline;
     # independent batches, one all-gather each, same results); the latency loop below runs the batches one at a time.
     pipe = None
-    if world > 1 and not args.no_pipeline:
+    lane_ctxs = []
+    if (world > 1 or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment)
         fuse_ctx = oi.HipContext(local_rank)
-        pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k)
+        lane_ctxs = [oi.HipContext(local_rank) for _ in range(max(1, args.lanes) - 1)]
+        for c in lane_ctxs:
+            c.set_cosine_mode(MODES[args.cosine])
+        pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k, lane_ctxs=lane_ctxs)
 
     def step():
         qv, qt, qo = batches[step_no[0] % NB]
         step_no[0] += 1
-        if world == 1:
+        if world == 1 and not (pipe is not None and pipelined[0]):
             idx.search(qv, qt, qo, k=args.k, depth=args.depth, out=out)   # one C-ABI call: the whole query
             return out.docs
         if pipe is not None and pipelined[0]:
@@ -211,7 +218,8 @@ def main():
     ctx.synchronize()   # also surfaces a pool overflow as an error
 
     # ---------------------------------------------------------------- timed region: exactly K steps
-    ctx.profile_reset(2)   # HIP events around the dominant kernel's launches only (each pair costs stream time)
+    for c in [ctx] + lane_ctxs:
+        c.profile_reset(2)   # HIP events around the dominant kernel's launches only (each pair costs stream time)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -222,9 +230,12 @@ def main():
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed = float(tm.item())
-    cos_ms, cos_launches = ctx.profile_read("cosine")
-    ctx.profile_reset(False)
-    ctx.synchronize()   # outside the timed region: a pool overflow in any of the K steps is an error, not a number
+    cos_ms, cos_launches = 0.0, 0
+    for c in [ctx] + lane_ctxs:   # (with lanes the launches of two batches overlap: their durations are summed as measured)
+        m, l = c.profile_read("cosine")
+        cos_ms, cos_launches = cos_ms + m, cos_launches + l
+        c.profile_reset(False)
+        c.synchronize()   # outside the timed region: a pool overflow in any of the K steps is an error, not a number
     pipelined[0] = False   # everything below (isolated kernel times, exact scorer, latency) runs batch by batch
     # The BM25 leg runs beside the cosine leg on a side stream, so the live cosine duration above includes
     # the CUs it lends to BM25 workgroups.  A few untimed steps with the legs one after the other give the
@@ -380,7 +391,9 @@ def main():
                                          "screen-copy": "bf16 screen over a bf16 COPY of the rows (opt-in) + exact f32 rescoring"}[args.cosine]
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
-                                      ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "")},
+                                      ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
+                                      ("; %d batches' lists in flight per rank, each through its own view of the shard" % (1 + len(lane_ctxs))
+                                       if lane_ctxs else "")},
             "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
             "roofline": roof,
             "other_kernels_ms_per_step": dict({t: v[0] / iso_steps for t, v in other.items()},

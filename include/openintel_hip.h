@@ -196,6 +196,14 @@ int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint32_t vocab,
                     uint32_t doc_id_base, oi_index **out);
 void oi_index_destroy(oi_index *idx);
 
+/* A second handle on a FINALIZED index, bound to another context of the same device (its own stream and workspaces), so
+ * that two searches over the same shard can be in flight at once -- e.g. batch i+1 scored while the selects and the
+ * rescoring of batch i drain.  The view borrows every buffer of `src`: it is read-only (the set_* /
+ * finalize calls return OI_ERR_STATE), costs no HBM, must be destroyed before `src`, and is searched with the ordinary
+ * oi_search* calls.  Thread-safety is per context as everywhere else: the two handles may be driven from two host threads.
+ * (No reference counterpart: the reference's port is synchronous, src/domain/ports/post_analyzer.rs:7-11 is its model.) */
+int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out);
+
 /* rows: n_docs x dim f32, row-major.  normalize != 0: L2-normalise each row (in
  * place when OI_DEVICE).  OI_DEVICE borrows the pointer; OI_HOST copies to HBM. */
 int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize);

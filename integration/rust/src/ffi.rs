@@ -69,6 +69,7 @@ extern "C" {
     pub fn oi_index_create(ctx: *mut OiCtx, n_docs: u64, dim: u32, vocab: u32, doc_id_base: u32,
                            out: *mut *mut OiIndex) -> c_int;
     pub fn oi_index_destroy(idx: *mut OiIndex);
+    pub fn oi_index_view(src: *mut OiIndex, ctx: *mut OiCtx, out: *mut *mut OiIndex) -> c_int;
     pub fn oi_index_set_embeddings(idx: *mut OiIndex, rows: *mut f32, location: c_int, normalize: c_int) -> c_int;
     pub fn oi_index_set_embeddings_bf16(idx: *mut OiIndex, rows: *const u16, location: c_int) -> c_int;
     pub fn oi_index_set_forward(idx: *mut OiIndex, term_ids: *const u32, doc_offsets: *const u64, location: c_int) -> c_int;

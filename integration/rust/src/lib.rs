@@ -110,6 +110,7 @@ pub struct HipIndex {
     ctx: Arc<HipCtx>,
     idx: *mut ffi::OiIndex,
     dim: usize,
+    source: Option<Arc<HipIndex>>, // a view keeps the index it borrows from alive (oi_index_view)
 }
 unsafe impl Send for HipIndex {}
 unsafe impl Sync for HipIndex {}
@@ -128,13 +129,20 @@ impl HipIndex {
         let n_docs = (rows.len() / dim) as u64;
         let mut idx = std::ptr::null_mut();
         check(unsafe { ffi::oi_index_create(ctx.raw(), n_docs, dim as u32, vocab, 0, &mut idx) })?;
-        let me = HipIndex { ctx, idx, dim };
+        let me = HipIndex { ctx, idx, dim, source: None };
         check(unsafe { ffi::oi_index_set_embeddings(me.idx, rows.as_mut_ptr(), ffi::OI_HOST, 1) })?;
         check(unsafe { ffi::oi_index_set_forward(me.idx, terms.as_ptr(), offsets.as_ptr(), ffi::OI_HOST) })?;
         let mut tokens = 0u64;
         check(unsafe { ffi::oi_index_local_stats(me.idx, &mut tokens, std::ptr::null_mut()) })?;
         check(unsafe { ffi::oi_index_finalize(me.idx, n_docs, tokens, std::ptr::null()) })?;
         Ok(me)
+    }
+    /// A second, read-only handle on this shard bound to `ctx` (a context of its own: another stream, other workspaces),
+    /// so that two searches can be in flight at once; costs no HBM.
+    pub fn view(self: &Arc<Self>, ctx: Arc<HipCtx>) -> Result<HipIndex, HipError> {
+        let mut idx = std::ptr::null_mut();
+        check(unsafe { ffi::oi_index_view(self.idx, ctx.raw(), &mut idx) })?;
+        Ok(HipIndex { ctx, idx, dim: self.dim, source: Some(Arc::clone(self)) })
     }
     /// Hybrid BM25 + cosine + RRF: one ranked list (<= k) per query, in query order.
     pub fn search(&self, query_vecs: &[f32], query_terms: &[Vec<u32>], k: usize, depth: usize) -> Result<Vec<Vec<RankedPost>>, HipError> {
@@ -154,7 +162,7 @@ impl HipIndex {
             ffi::oi_search(self.idx, query_vecs.as_ptr(), flat.as_ptr(), offs.as_ptr(), b as u32, depth as u32, k as u32,
                            ffi::OI_HOST, s.as_mut_ptr(), d.as_mut_ptr(), c.as_mut_ptr())
         })?;
-        let _ = &self.ctx;
+        let _ = (&self.ctx, &self.source);
         Ok((0..b)
             .map(|q| (0..c[q] as usize).map(|i| RankedPost { doc_id: d[q * k + i], score: s[q * k + i] }).collect())
             .collect())

@@ -70,6 +70,7 @@ SIGNATURES = {
     "oi_social_summary": (_I, [_P, _P, _U64, _P, _P, _U64, C.c_double, _I, C.POINTER(SocialCounters)]),
     "oi_index_create": (_I, [_P, _U64, _U32, _U32, _U32, C.POINTER(_P)]),
     "oi_index_destroy": (None, [_P]),
+    "oi_index_view": (_I, [_P, _P, C.POINTER(_P)]),
     "oi_index_set_embeddings": (_I, [_P, _P, _I, _I]),
     "oi_index_set_embeddings_bf16": (_I, [_P, _P, _I]),
     "oi_index_set_forward": (_I, [_P, _P, _P, _I]),

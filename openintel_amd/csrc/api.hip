@@ -34,6 +34,7 @@ int oi_dyn_lds(oi_ctx *ctx, const void *kernel, size_t bytes) {
 // ---------------------------------------------------------------- buffers
 int DevBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return OI_OK;
+    if (borrowed) { oi_set_error("internal: a borrowed buffer cannot grow"); return OI_ERR_STATE; }
     if (p) {
         (void)hipFree(p);
         p = nullptr;
@@ -46,9 +47,10 @@ int DevBuf::ensure(size_t bytes) {
     return OI_OK;
 }
 void DevBuf::release() {
-    if (p) (void)hipFree(p);
+    if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    borrowed = false;
 }
 
 // ---------------------------------------------------------------- profiling hooks
@@ -344,6 +346,33 @@ extern "C" int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint3
     return OI_OK;
 }
 
+// A second handle on a finalized index, bound to another context (its own stream and workspaces) of the same device:
+// searches through the two handles can be in flight at the same time.  The view borrows every buffer.
+extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
+    if (!src || !ctx || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    OI_REQUIRE(ctx != src->ctx, "index view: give it a context of its own (the point is a second stream and second workspaces)");
+    OI_REQUIRE(ctx->device == src->ctx->device, "index view: context on device %d, index on device %d", ctx->device, src->ctx->device);
+    std::lock_guard<std::mutex> g(src->ctx->mu); // the source is not being built or searched while it is aliased
+    if (!src->finalized || (!src->rows && !src->rows_bf16)) { oi_set_error("index view: the source must have rows and be finalized"); return OI_ERR_STATE; }
+    oi_index *v = new oi_index();
+    v->ctx = ctx;
+    v->is_view = true;
+    v->n_docs = src->n_docs; v->dim = src->dim; v->vocab = src->vocab; v->doc_id_base = src->doc_id_base;
+    v->rows = src->rows; v->rows_bf16 = src->rows_bf16; // rows_owned / rows_bf16_owned stay false
+    v->screen_ok = src->screen_ok;
+    v->forward_set = src->forward_set; v->finalized = true;
+    v->total_tokens = src->total_tokens; v->n_postings = src->n_postings; v->n_blocks = src->n_blocks;
+    v->avgdl = src->avgdl; v->max_query_terms = src->max_query_terms; v->bm25_mode = src->bm25_mode;
+    auto alias = [](DevBuf &dst, const DevBuf &from) { dst.p = from.p; dst.cap = from.cap; dst.borrowed = from.p != nullptr; };
+    alias(v->max_row_norm, src->max_row_norm); alias(v->screen_copy, src->screen_copy);
+    alias(v->uniq_keys, src->uniq_keys); alias(v->tf, src->tf); alias(v->doc_len, src->doc_len); alias(v->df_local, src->df_local);
+    alias(v->postings, src->postings); alias(v->cell_start, src->cell_start); alias(v->idf, src->idf);
+    alias(v->fwd_terms, src->fwd_terms); alias(v->fwd_offsets, src->fwd_offsets);
+    *out = v;
+    return OI_OK;
+}
+
 extern "C" void oi_index_destroy(oi_index *idx) {
     if (!idx) return;
     {
@@ -361,6 +390,7 @@ extern "C" void oi_index_destroy(oi_index *idx) {
 
 extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize) {
     if (!idx || !rows) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
@@ -395,6 +425,7 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
 
 extern "C" int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows, int location) {
     if (!idx || !rows) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
@@ -421,6 +452,7 @@ extern "C" int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows,
 extern "C" int oi_index_set_forward(oi_index *idx, const uint32_t *term_ids, const uint64_t *doc_offsets,
                                     int location) {
     if (!idx || !doc_offsets) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
@@ -457,6 +489,7 @@ extern "C" int oi_index_set_bm25_mode(oi_index *idx, int mode) {
 
 extern "C" int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df_out_host) {
     if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }
@@ -473,6 +506,7 @@ extern "C" int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, u
 extern "C" int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                                  const uint32_t *global_df_host) {
     if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }

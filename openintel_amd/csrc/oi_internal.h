@@ -64,6 +64,7 @@ inline const char *oi_ablation_env(const char *) { return nullptr; }
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool borrowed = false; // a view's alias of another index's buffer (oi_index_view): never freed, never resized here
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -151,6 +152,7 @@ struct oi_index {
     uint32_t max_query_terms = 16; // contract for the batch-scan path (oi_index_set_max_query_terms)
     int bm25_mode = 0;             // 0 default (= 3 unless OI_BM25_MODE says otherwise), 1 term-at-a-time per workgroup (bm25.hip),
                                    // 2 scan of the forward index (bm25_scan.hip), 3 term-at-a-time per wave (bm25_wave.hip)
+    bool is_view = false;          // oi_index_view: the data belongs to another index; this handle only searches
 };
 
 // ---------------------------------------------------------------- kernels (host launchers)

@@ -224,6 +224,19 @@ class HybridIndex(PostRetriever):
                                             _lib.ptr(eps)))
         return st, eps
 
+    def view(self, ctx: HipContext) -> "HybridIndex":
+        """A second handle on this (finalized) shard, bound to `ctx` -- another HipContext of the same device, with its
+        own stream and workspaces -- so that two searches can be in flight at once (oi_index_view).  Borrows every
+        buffer: read-only, no HBM; close it before this index."""
+        v = HybridIndex.__new__(HybridIndex)
+        v.ctx, v.lib = ctx, ctx.lib
+        v.n_docs, v.dim, v.vocab, v.doc_id_base = self.n_docs, self.dim, self.vocab, self.doc_id_base
+        h = C.c_void_p()
+        _lib.check(self.lib.oi_index_view(self.handle, ctx.handle, C.byref(h)))
+        v.handle = h
+        v._keep = [self]  # the source outlives the view
+        return v
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.oi_index_destroy(self.handle)

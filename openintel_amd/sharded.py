@@ -114,20 +114,25 @@ class ShardedRetriever:
 
 
 class ShardedPipeline:
-    """Throughput mode of the sharded query (GPU only): the exchange + fusion of batch i run on a second stream while
-    the shard's lists of batch i+1 are already being scored on the first -- independent batches, two packed buffers,
-    two result slots.  Per batch nothing changes (same calls, same results, one all-gather); only the ~0.1 ms of
-    exchange + fusion stop adding to the step time, which at 8 GPUs is 10 % of it.
+    """Throughput mode of the sharded query (GPU only).  Batches are independent, so
+      * the exchange + fusion of batch i run on a second stream (`fuse_ctx`) while the shard's lists of batch i+1 are
+        already being scored -- per batch nothing changes (same calls, same results, ONE all-gather); the ~0.1 ms of
+        exchange + fusion stop adding to the step time, which at 8 GPUs is 10 % of it;
+      * with `lane_ctxs` (further HipContexts of the same device) the lists of consecutive batches are scored through
+        VIEWS of the shard (HybridIndex.view: same buffers, own stream and workspaces), one batch per lane in flight: the
+        next batch's screen fills the CUs that the selects and the rescoring of the previous one leave idle
+        (0.874 -> 0.813 ms per batch at 1.25M rows, tools/dual_stream_probe.py).
 
-        pipe = ShardedPipeline(retriever, fuse_ctx, n_queries, depth, k)
+        pipe = ShardedPipeline(retriever, fuse_ctx, n_queries, depth, k, lane_ctxs=[HipContext(dev)])
         slot = pipe.submit(qv, qt, qo)      # asynchronous; results of this batch land in pipe.results[slot]
         ...
         pipe.drain()                        # everything submitted so far is complete (and checked for overflow)
 
-    `fuse_ctx` is a second HipContext on the same device (its own stream and workspaces: the fusion must not queue
-    behind the next batch's kernels on the retriever's stream)."""
+    `fuse_ctx` is a HipContext of its own on the same device (the fusion must not queue behind the next batch's kernels
+    on a scoring stream).  The collectives are issued from the host in submission order on ONE stream, so every rank
+    runs them in the same order whatever the lanes do."""
 
-    def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int):
+    def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int, lane_ctxs=()):
         import torch
         from .retriever import SearchResult, fuse_packed, packed_words
         self.r, self.fctx, self.B, self.depth, self.k = retriever, fuse_ctx, int(n_queries), int(depth), int(k)
@@ -136,25 +141,38 @@ class ShardedPipeline:
         self.dev = dev
         self.side = torch.cuda.Stream(device=dev)
         fuse_ctx.set_stream(self.side)
+        # lane 0 = the retriever's own index on the caller's stream; lane j > 0 = a view on a stream of its own
+        self.lanes = [(retriever.local, None)]
+        for c in lane_ctxs:
+            st = torch.cuda.Stream(device=dev)
+            c.set_stream(st)
+            self.lanes.append((retriever.local.view(c), st))
+        self.n_slots = 2 * len(self.lanes)
         words = packed_words(self.B, self.depth)
         mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
-        self.packed = [mk(words, torch.int32) for _ in range(2)]
-        self.flat = [mk(words * retriever.world, torch.int32) for _ in range(2)] if retriever.world > 1 else self.packed
+        self.packed = [mk(words, torch.int32) for _ in range(self.n_slots)]
+        self.flat = ([mk(words * retriever.world, torch.int32) for _ in range(self.n_slots)] if retriever.world > 1
+                     else self.packed)
         self.results = [SearchResult(torch.zeros((self.B, self.k), dtype=torch.float32, device=dev),
                                      torch.zeros((self.B, self.k), dtype=torch.int32, device=dev),
-                                     torch.zeros((self.B,), dtype=torch.int32, device=dev)) for _ in range(2)]
-        self.lists_done = [torch.cuda.Event() for _ in range(2)]
-        self.fused = [torch.cuda.Event() for _ in range(2)]
+                                     torch.zeros((self.B,), dtype=torch.int32, device=dev)) for _ in range(self.n_slots)]
+        self.lists_done = [torch.cuda.Event() for _ in range(self.n_slots)]
+        self.fused = [torch.cuda.Event() for _ in range(self.n_slots)]
         self.n = 0
 
     def submit(self, qv, qt, qo) -> int:
         import torch
-        slot = self.n & 1
+        slot = self.n % self.n_slots
+        index, lane_stream = self.lanes[self.n % len(self.lanes)]
         main = torch.cuda.current_stream(self.dev)
-        if self.n >= 2:
-            main.wait_event(self.fused[slot])          # the slot's packed buffer is free again
-        self.r.local.search_lists_packed(qv, qt, qo, depth=self.depth, out=self.packed[slot])
-        self.lists_done[slot].record(main)
+        st = main if lane_stream is None else lane_stream
+        if lane_stream is not None:
+            lane_stream.wait_stream(main)              # the queries were produced on the caller's stream
+        if self.n >= self.n_slots:
+            st.wait_event(self.fused[slot])            # the slot's packed buffer is free again
+        with torch.cuda.stream(st):
+            index.search_lists_packed(qv, qt, qo, depth=self.depth, out=self.packed[slot])
+            self.lists_done[slot].record(st)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.lists_done[slot])
             if self.r.world > 1:
@@ -166,9 +184,19 @@ class ShardedPipeline:
 
     def drain(self) -> None:
         import torch
-        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        main = torch.cuda.current_stream(self.dev)
+        for _, st in self.lanes[1:]:
+            main.wait_stream(st)
+        main.wait_stream(self.side)
         self.fctx.synchronize()
+        for index, _ in self.lanes[1:]:
+            index.ctx.synchronize()                    # raises if a view's engine flagged a pool overflow
         self.r.check()
+
+    def close(self) -> None:
+        for index, _ in self.lanes[1:]:
+            index.close()
+        self.lanes = self.lanes[:1]
 
 
 class ShardedAnalyzer:

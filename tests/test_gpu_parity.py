@@ -127,6 +127,29 @@ def test_lexicon_chunk_half_and_subtile_phases(ctx, O):
     _check_lexicon(ctx, O, texts)
 
 
+def test_lexicon_fuzz_against_the_oracle(ctx, O):
+    """Random posts over an alphabet that is hostile to the scan: lexicon words and their near misses, every kind of
+    separator, upper case, digits, U+212A / U+0130 and other multi-byte chars, empty posts, posts of 1 byte up to
+    several sub-tiles -- 12 seeds, each one packed blob (no separators between posts), bit for bit against the oracle."""
+    from openintel_amd import synth
+    lex = list(synth.LEXICON_WORDS)
+    near = [w[:-1] for w in lex if len(w) > 2] + [w + "s" for w in lex] + [w.upper() for w in lex] + [w.capitalize() for w in lex]
+    pieces = lex * 3 + near + ["\u212a", "\u0130", "\u00e9", "\U0001F680", "\u0430", "\u00aa", "\u00b0", "\u4e2a",
+                               "0", "7", "42", "a", "I", "x" * 9, "y" * 10, "z" * 17]
+    seps = [" ", " ", " ", "", "", ".", ",", "\n", "\t", "-", "'", "  ", "$", "\u2014", "/", "_", "\x00", "\x11"]
+    for seed in range(12):
+        rng = np.random.default_rng(1000 + seed)
+        texts = []
+        for _ in range(int(rng.integers(200, 1500))):
+            kind = rng.random()
+            n_tok = 0 if kind < 0.1 else int(rng.integers(1, 4)) if kind < 0.4 else int(rng.integers(4, 60)) if kind < 0.97 \
+                else int(rng.integers(2000, 9000))
+            ids = rng.integers(0, len(pieces), size=n_tok)
+            sp = rng.integers(0, len(seps), size=n_tok)
+            texts.append("".join(pieces[i] + seps[j] for i, j in zip(ids, sp)))
+        _check_lexicon(ctx, O, texts)
+
+
 def test_lexicon_many_tiny_posts_and_random_corpus(ctx, O):
     from openintel_amd import synth
     rng = np.random.default_rng(5)
@@ -760,6 +783,93 @@ def test_sharded_pipeline_overlaps_fusion_and_returns_the_same_results(ctx, O):
         assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc)
     fctx.close()
     idx.close()
+
+
+def test_index_view_and_pipeline_lanes(ctx, O):
+    """oi_index_view: a second handle on a finalized shard, bound to another context -- searched alone, it returns the
+    source's results bit for bit; build calls on it are refused; two handles driven from two host threads agree with
+    the serial results; ShardedPipeline with a second lane (consecutive batches scored through the index and its view at
+    once, exchange + fusion on a third stream) returns what the one-at-a-time retriever returns."""
+    import threading
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib, sharded, synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k = 150_000, 768, 64, 400, 60
+    rows = synth.embeddings_torch(n, dim, dev)
+    terms, offs = synth.forward_index_torch(n, dev, vocab=4096)
+    c0 = oi.HipContext(0)   # default scorer (bf16 screen + rescoring): the mode the lanes run in bench.py
+    idx = oi.HybridIndex(c0, n, dim, 4096, doc_id_base=77)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    c0.use_torch_current_stream()
+    c1 = oi.HipContext(0)
+    with pytest.raises(_lib.OiError):
+        idx.view(c1)                      # not finalized yet
+    sr = sharded.make_hip_sharded(c0, idx, dev)
+    sr.finalize()
+    with pytest.raises(_lib.OiError):
+        idx.view(c0)                      # a view needs a context of its own
+    view = idx.view(c1)
+    with pytest.raises(_lib.OiError):
+        view.set_embeddings(rows, normalize=False)
+    with pytest.raises(_lib.OiError):
+        view.finalize()
+    batches = [synth.query_batch_torch(B, dim, dev, vocab=4096, seed=900 + i) for i in range(8)]
+    want = []
+    for qv, qt, qo in batches:
+        r = idx.search(qv, qt, qo, k=k, depth=depth)
+        want.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
+    torch.cuda.synchronize()
+    for (qv, qt, qo), (ws, wd, wc) in zip(batches, want):       # the view alone
+        r = view.search(qv, qt, qo, k=k, depth=depth)
+        c1.synchronize()
+        assert torch.equal(r.docs, wd) and torch.equal(r.scores, ws) and torch.equal(r.counts, wc)
+    # two host threads, one handle each, at the same time
+    got = [[None] * len(batches) for _ in range(2)]
+
+    def worker(which, handle, hctx):
+        st = torch.cuda.Stream(device=dev)
+        hctx.set_stream(st)
+        with torch.cuda.stream(st):
+            for rep in range(3):
+                for i, (qv, qt, qo) in enumerate(batches):
+                    r = handle.search(qv, qt, qo, k=k, depth=depth)
+                    got[which][i] = (r.scores.clone(), r.docs.clone(), r.counts.clone())
+        hctx.synchronize()
+
+    ts = [threading.Thread(target=worker, args=(0, idx, c0)), threading.Thread(target=worker, args=(1, view, c1))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    for which in range(2):
+        for (ws, wd, wc), (gs, gd, gc) in zip(want, got[which]):
+            assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc)
+    view.close()
+    c0.use_torch_current_stream()
+    # the pipeline with a second lane
+    fctx, lctx = oi.HipContext(0), oi.HipContext(0)
+    pipe = sharded.ShardedPipeline(sr, fctx, B, depth, k, lane_ctxs=[lctx])
+    assert pipe.n_slots == 4 and len(pipe.lanes) == 2
+    outs = []
+    for rep in range(2):
+        for qv, qt, qo in batches:
+            slot = pipe.submit(qv, qt, qo)
+            with torch.cuda.stream(pipe.side):   # a slot is reused four submits later: copy out behind the fusion
+                r = pipe.results[slot]
+                outs.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
+    pipe.drain()
+    torch.cuda.synchronize()
+    for i, (gs, gd, gc) in enumerate(outs):
+        ws, wd, wc = want[i % len(batches)]
+        assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc), "batch %d" % i
+    pipe.close()
+    for c in (fctx, lctx, c1):
+        c.close()
+    idx.close()
+    c0.close()
 
 
 def test_fuzz_small_shapes_bit_exact(ctx, O):
