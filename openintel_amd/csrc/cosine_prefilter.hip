@@ -455,7 +455,14 @@ bool oi_cosine_screen_supported(uint32_t dim) { return dim == 384 || dim == 768;
 void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
     const uint64_t n_tiles = (n_rows + PF_TILE_ROWS - 1) / PF_TILE_ROWS;
     const uint64_t quads = (n_tiles + 3) / 4;
-    const uint64_t grid = quads < (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (uint64_t)ctx->num_cus;
+    // The persistent screen takes 7/8 of the CUs, one workgroup each.  It is HBM-bound: 208..224 of 256 CUs stream the corpus as
+    // fast as 256 (4.82-4.92 vs 4.97 ms per 10M-row batch), and the CUs left free run the small kernels of whatever else is in
+    // flight -- the BM25 leg on the side stream, the selects and the rescoring of another batch scored through a view of the
+    // same shard (oi_index_view): 0.817 -> 0.713 ms per batch at 1.25M rows with two batches in flight (tools/dual_stream_probe.py;
+    // 192: 0.69-0.72, 160: 0.75, and from 176 down the single-stream time grows).  OI_SCREEN_CUS: A/B switch.
+    static const char *cus_s = oi_ablation_env("OI_SCREEN_CUS");
+    const uint64_t cus = cus_s ? (uint64_t)std::max(1, atoi(cus_s)) : std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 7 / 8);
+    const uint64_t grid = quads < cus ? (quads ? quads : 1) : cus;
     *n_segs = (uint32_t)grid;
     *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * PF_TILE_ROWS;
 }
