@@ -329,7 +329,7 @@ def main():
         if args.corpus == "bf16" or args.cosine == "screen-copy":   # the bf16-corpus scorer's plan (cosine_bf16.hip, cb_group)
             left, passes, solo = args.batch, 0, (32 if args.dim == 1024 else 64)
             while left > 0:
-                g = solo if left <= solo else 96 if args.dim == 1024 else (96 if (left + 95) // 96 < (left + 63) // 64 else 64)
+                g = solo if left <= solo else (128 if left > 96 else 96) if args.dim == 1024 else (96 if (left + 95) // 96 < (left + 63) // 64 else 64)
                 left -= min(g, left)
                 passes += 1
         cos_s = cos_ms / 1e3

@@ -373,6 +373,191 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_pair(
     }
 }
 
+// ------------------------------------------------------------------ 128 queries per corpus pass
+// configs[4] is 256 queries at d = 1024: 32 per pass with the solo kernel, 96 with the pair kernel (three passes).  Here
+// the four waves of a workgroup share EVERY 32-row tile, each holding one QUARTER of K of 128 queries in registers
+// (128 x 256 bf16 = 64 KB = 256 VGPRs) and streaming its quarter of the rows through its own ring: two passes.  The four
+// partial 32 x 128 tiles meet once per tile, and the epilogue is split four ways too: wave w owns query tile w -- it parks
+// the three partial tiles it does not own in LDS, and after one barrier adds the other waves' partials of ITS tile to its
+// own (K quarters in order 0..3) and filters.  A second barrier lets the buffer be reused (the four epilogues are the
+// same size, so nobody waits long at it; the DMA ring keeps the loads of the next tile in flight across both).
+template <int D, int DBG = 0> // DBG (ablation builds): 1 = no reduction / epilogue / barriers (streaming + MFMA only), 2 = no epilogue work
+__global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
+    const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const uint16_t *__restrict__ queries, // bf16 [128][D], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int NQT = 4;
+    constexpr int KQ = D / 4;                 // K of one wave
+    constexpr int NKC = KQ / CB_SLOT_K;       // ring slots per tile and wave
+    constexpr int NBUF = NKC;
+    constexpr int P = NBUF - 1;
+    constexpr int KSTEPS = KQ / 16;
+    constexpr int RED = 16 * 64;              // floats of one parked partial query tile (32 rows x 32 queries)
+    static_assert(KQ % CB_SLOT_K == 0 && P >= 1, "unsupported D");
+    static_assert(NQT * KSTEPS * 4 <= 400, "the query block must fit the register file");
+    static_assert(NKC * 4 == 16, "the epilogue is spread over 16 MFMA groups");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                      // [4][NBUF][4 KiB]
+    float *red = reinterpret_cast<float *>(smem + 4 * NBUF * CB_SLOT_BYTES);         // [4 writers][4 query tiles][RED]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 16 * RED);               // [128]
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // K quarter, and the query tile this wave finishes
+    const uint32_t li = lane & 31, lh = lane >> 5;
+
+    cb_bf16x8 qreg[NQT][KSTEPS]; // this wave's quarter of K of every query
+#pragma unroll
+    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            qreg[t][s] = *reinterpret_cast<const cb_bf16x8 *>(queries + (uint64_t)(32 * t + li) * D + w * KQ + 16 * s + 8 * lh);
+    const uint32_t my_q = 32u * w + li;
+    const uint32_t my_tau = my_q < n_queries ? tau_keys[my_q] : 0xFFFFFFFFu;
+    // (a key of 0 = no threshold yet; -0.0 passes a +0.0 threshold here where the key order would stop it: a harmless extra
+    // candidate, the selects work on keys)
+    const float tau_f = my_tau == 0u ? -__builtin_inff() : oi_key_f32(my_tau);
+    if (tid < 32 * NQT) seg_fill[tid] = 0;
+    __syncthreads();
+
+    // ---- tiles of this WORKGROUP: blockIdx.x, + gridDim.x, ...
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
+    const uint64_t first = blockIdx.x, stride = gridDim.x;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+
+    uint32_t voff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const uint32_t prow = 8 * m + (lane >> 3);
+        voff[m] = prow * (uint32_t)(D * 2) + w * (uint32_t)(KQ * 2) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+    }
+    const uint32_t ring_w = cb_lds_addr(ring) + w * (NBUF * CB_SLOT_BYTES);
+    const unsigned char *ring_rd = ring + w * (NBUF * CB_SLOT_BYTES);
+    uint32_t frag_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
+
+    auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)CB_TILE_ROWS; };
+    auto tile_srd = [&](uint64_t ti) {
+        const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
+        return cb_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 2));
+    };
+    cb_u32x4 cur = tile_srd(0), nxt = tile_srd(1);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only: retire every load hipcc knows about, here
+    if (my_nt) {
+#pragma unroll
+        for (int kc = 0; kc < P; ++kc)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                cb_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CB_SLOT_BYTES + m * 1024, false);
+    }
+
+    // The epilogue of tile i-1 (sum of the four K quarters of this wave's query tile, filter, append) is spread over the
+    // 16 MFMA groups of tile i, one accumulator register per group: it runs in the shadow of the matrix pipe and of the
+    // DMA instead of holding both up (stand-alone it cost 65 % on top of the streaming loop).
+    uint64_t row0_prev = 0;
+    bool have_prev = false;
+    uint32_t rows_prev = 0; // rows of the previous tile inside the chunk (32 but for the last)
+    const float *red_mine = red + (w * 16) * 64 + lane; // [K quarter kq][register r] of MY query tile: + (kq * 64 + r) * 64
+    // the four partials of register r are read BEFORE the group's MFMAs and used after them: the LDS latency passes while
+    // the matrix pipe works (read and used back to back it was exposed in every group: +27 %)
+    auto epilogue_load = [&](auto r_, float (&e)[4]) {
+        constexpr int r = decltype(r_)::value;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) e[kq] = red_mine[(kq * 64 + r) * 64];
+    };
+    auto epilogue_use = [&](auto r_, const float (&e)[4]) {
+        constexpr int r = decltype(r_)::value;
+        const uint64_t row = row0_prev + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float s = ((e[0] + e[1]) + e[2]) + e[3]; // K quarters in order (every wave parks its own tile too: no branch on w)
+        if (DBG == 3) { if (s == 12345.678f) *overflow = 2u; return; } // sums only
+        // one float compare does the filter: tau_f is the threshold as a float (-inf while there is none, NaN for a padded
+        // query), false for a NaN score too; rows_prev cuts the ragged last tile
+        if ((uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * lh < rows_prev && s >= tau_f) {
+            const uint32_t pos = atomicAdd(&seg_fill[my_q], 1u); // LDS
+            if (pos < seg_cap) my_seg[(uint64_t)my_q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
+            else *overflow = 1u;
+        }
+    };
+
+    for (uint64_t ti = 0; ti < my_nt; ++ti) {
+        const bool has_next_tile = ti + 1 < my_nt;
+        cb_f32x16 acc[NQT];
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        {
+            cb_wait<4 * (P - 1)>();
+            cb_bf16x8 a_cur = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + frag_off[0]);
+            cb_static_for<0, NKC * 4>([&](auto gi_) {
+                constexpr int gi = decltype(gi_)::value;
+                constexpr int kc = gi / 4, g = gi % 4;
+                constexpr int sn = kc + P;
+                cb_bf16x8 a_nxt = a_cur;
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (DBG == 0 || DBG == 3) { // the previous tile's epilogue, register gi: its partials
+                    if (have_prev) epilogue_load(gi_, e);
+                }
+                if constexpr (g < 3)
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + (kc % NBUF) * CB_SLOT_BYTES + frag_off[g + 1]);
+#pragma unroll
+                for (int t = 0; t < NQT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+                if constexpr (sn < NKC)
+                    cb_issue_piece(cur, voff[g], sn * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024, false);
+                else
+                    cb_issue_piece(nxt, voff[g], (sn - NKC) * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024,
+                                   !has_next_tile);
+                if constexpr (DBG == 0 || DBG == 3) { // ... summed, filtered, appended
+                    if (have_prev) epilogue_use(gi_, e);
+                }
+                if constexpr (g == 3 && kc + 1 < NKC) {
+                    if (kc + P < NKC || has_next_tile) cb_wait<4 * (P - 1)>();
+                    else cb_wait<4 * (NKC - 2 - kc)>();
+                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + ((kc + 1) % NBUF) * CB_SLOT_BYTES + frag_off[0]);
+                }
+                a_cur = a_nxt;
+            });
+        }
+        if (DBG == 1) {
+            float x = 0.f;
+#pragma unroll
+            for (int t = 0; t < NQT; ++t) x += acc[t][0] + acc[t][7] + acc[t][15];
+            if (x == 12345.678f) *overflow = 2u;
+            cur = nxt;
+            nxt = tile_srd(ti + 2);
+            continue;
+        }
+        __syncthreads(); // everyone has consumed the parked partials of the previous tile
+        // ---- the four quarters meet: every wave parks its four partial query tiles, [writer w][query tile t][register r][lane]
+#pragma unroll
+        for (int t = 0; t < NQT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((w * 4 + t) * 16 + r) * 64 + lane] = acc[t][r];
+        row0_prev = tile_row0(ti);
+        rows_prev = row_end - row0_prev < 32 ? (uint32_t)(row_end - row0_prev) : 32u;
+        have_prev = true;
+        __syncthreads(); // parked: readable during the next tile's MFMA groups
+        cur = nxt;
+        nxt = tile_srd(ti + 2);
+    }
+    if (DBG == 0 && have_prev) // the last tile's epilogue has no MFMA loop to hide in
+        cb_static_for<0, 16>([&](auto r_) {
+            float e[4];
+            epilogue_load(r_, e);
+            epilogue_use(r_, e);
+        });
+    __syncthreads();
+    if (tid < 32 * NQT && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+    }
+}
+
 // ------------------------------------------------------------------ query staging: f32 -> bf16 (RNE), zero padded
 __global__ __launch_bounds__(256) void cb_stage_queries(const float *__restrict__ q, uint32_t n_queries, uint32_t n_padded,
                                                         uint32_t dim, uint16_t *__restrict__ out) {
@@ -398,7 +583,7 @@ bool oi_cosine_bf16_supported(uint32_t dim) { return dim == 384 || dim == 768 ||
 static uint32_t cb_group(uint32_t dim, uint32_t left) {
     const uint32_t solo = dim == 1024 ? 32u : 64u;
     if (left <= solo) return solo;
-    if (dim == 1024) return 96u;
+    if (dim == 1024) return left > 96u ? 128u : 96u; // 128: the quad kernel (a quarter of K per wave)
     return (left + 95u) / 96u < (left + 63u) / 64u ? 96u : 64u;
 }
 
@@ -439,6 +624,32 @@ static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
     return OI_OK;
 }
 
+template <int D>
+static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                            uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    constexpr int NKC = D / 4 / CB_SLOT_K;
+    constexpr size_t smem = 4 * NKC * CB_SLOT_BYTES + 16 * (16 * 64) * 4 + 128 * 4;
+    static_assert(smem <= 160 * 1024, "LDS");
+#ifdef OI_ABLATION
+    static const char *dbg_s = oi_ablation_env("OI_QUAD_DBG");
+    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    if (dbg >= 1 && dbg <= 3) {
+        auto kern = dbg == 1 ? cosine_bf16_quad<D, 1> : dbg == 2 ? cosine_bf16_quad<D, 2> : cosine_bf16_quad<D, 3>;
+        OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(kern), (size_t)(smem)));
+        hipLaunchKernelGGL(kern, dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq, doc_id_base, p.keys,
+                           p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap, p.overflow);
+        OI_HIP_CHECK(hipGetLastError());
+        return OI_OK;
+    }
+#endif
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_quad<D>), (size_t)(smem)));
+    hipLaunchKernelGGL((cosine_bf16_quad<D>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
+                       doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap,
+                       p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 // All queries of a batch over rows [row_begin, row_end) of a bf16 corpus.  d_queries: f32 [n_queries][dim].
 int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                 const float *d_queries, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool) {
@@ -448,6 +659,7 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
                "cosine (bf16 corpus): chunk does not fit the candidate pool");
     if (row_end <= row_begin || n_queries == 0) return OI_OK;
     static const bool solo_only = oi_ablation_env("OI_BF16_SOLO") != nullptr; // A/B: never use the pair kernel
+    static const bool no_quad = oi_ablation_env("OI_BF16_NO_QUAD") != nullptr;   // A/B: passes of at most 96 queries at d = 1024
     const uint32_t n_padded = (n_queries + 31u) & ~31u;
     DevBuf &qb = ctx->buf("q_bf16");
     OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 128) * dim));
@@ -461,7 +673,8 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
     ProfScope ps(ctx, "cosine");
     for (uint32_t q0 = 0; q0 < n_queries;) {
         const uint32_t left = n_queries - q0;
-        const uint32_t group = solo_only ? (dim == 1024 ? 32u : 64u) : cb_group(dim, left);
+        uint32_t group = solo_only ? (dim == 1024 ? 32u : 64u) : cb_group(dim, left);
+        if (no_quad && group > 96u) group = 96u;
         const uint32_t nq_here = std::min(group, left);
         const uint32_t nqt = (nq_here + 31u) / 32u; // query tiles of 32 in this launch
         PoolView p = pool;
@@ -474,7 +687,8 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
 #define CB_PAIR(DD, T) OI_CHECK((launch_bf16_pair<DD, T>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)))
         const bool pair = nq_here > (dim == 1024 ? 32u : 64u);
         if (dim == 1024) {
-            if (!pair) CB_SOLO(1024, 1);
+            if (nq_here > 96u) OI_CHECK((launch_bf16_quad<1024>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+            else if (!pair) CB_SOLO(1024, 1);
             else if (nqt == 2) CB_PAIR(1024, 2);
             else CB_PAIR(1024, 3);
         } else if (dim == 768) {

@@ -52,7 +52,8 @@ def _index(ctx, bits, terms, offs, vocab, base=0):
 @pytest.mark.parametrize("B,dim,n", [(1, 768, 5000), (9, 384, 3000), (40, 768, 9000), (64, 768, 40_000),
                                      (70, 384, 6000), (33, 1024, 5000), (64, 1024, 20_000), (3, 1024, 33),
                                      (256, 1024, 30_000),   # the batch and width of BASELINE configs[4]
-                                     (128, 768, 20_000), (100, 384, 5000), (200, 768, 3000)])  # pair kernel shapes
+                                     (128, 768, 20_000), (100, 384, 5000), (200, 768, 3000),   # pair kernel shapes
+                                     (97, 1024, 2011), (128, 1024, 9001), (225, 1024, 4000)])   # quad kernel (a quarter of K per wave)
 def test_bf16_cosine_within_tolerance(ctx, O, B, dim, n):
     from openintel_amd import synth
     bits = to_bf16_bits(synth.embeddings_np(n, dim, seed=5 + B))
@@ -78,7 +79,8 @@ def test_bf16_cosine_within_tolerance(ctx, O, B, dim, n):
 
 
 @pytest.mark.parametrize("n,dim,B,depth,k", [(70_000, 384, 9, 1000, 100), (40_000, 768, 64, 10, 10),
-                                             (300_000, 384, 3, 100, 50), (5_000, 1024, 40, 1024, 1024)])
+                                             (300_000, 384, 3, 100, 50), (5_000, 1024, 40, 1024, 1024),
+                                             (9_001, 1024, 128, 500, 100), (40_003, 1024, 250, 64, 32)])   # quad kernel
 def test_bf16_hybrid_pipeline_bit_exact(ctx, O, n, dim, B, depth, k):
     # small integers are exact in bf16 and their dot products exact in f32 in any order: the whole
     # pipeline (several cosine chunks, BM25, RRF) must match the oracle bit for bit
