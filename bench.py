@@ -187,10 +187,15 @@ def main():
     lane_ctxs = []
     if (world > 1 or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment)
         fuse_ctx = oi.HipContext(local_rank)
-        lane_ctxs = [oi.HipContext(local_rank) for _ in range(max(1, args.lanes) - 1)]
-        for c in lane_ctxs:
-            c.set_cosine_mode(MODES[args.cosine])
-        pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k, lane_ctxs=lane_ctxs)
+        pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k)
+        if args.lanes > 1:
+            # a second lane is kept only if it measurably pays on THIS rank's stream-to-queue placement (calibrate's docstring)
+            def make_lane_ctx():
+                c = oi.HipContext(local_rank)
+                c.set_cosine_mode(MODES[args.cosine])
+                return c
+            pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4)
+            lane_ctxs = [index.ctx for index, _ in pipe.lanes[1:]]
 
     def step():
         qv, qt, qo = batches[step_no[0] % NB]
@@ -401,7 +406,8 @@ def main():
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
                                       ("; %d batches' lists in flight per rank, each through its own view of the shard" % (1 + len(lane_ctxs))
-                                       if lane_ctxs else "")},
+                                       if lane_ctxs else ""),
+                       "lane_calibration_rank0": pipe.calibration if pipe is not None else None},
             "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
             "roofline": roof,
             "other_kernels_ms_per_step": dict({t: v[0] / iso_steps for t, v in other.items()},

@@ -147,7 +147,8 @@ class ShardedPipeline:
             st = torch.cuda.Stream(device=dev)
             c.set_stream(st)
             self.lanes.append((retriever.local.view(c), st))
-        self.n_slots = 2 * len(self.lanes)
+        self.n_slots = max(4, 2 * len(self.lanes))   # (4: room for a second lane added by calibrate())
+        self.calibration = None
         words = packed_words(self.B, self.depth)
         mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
         self.packed = [mk(words, torch.int32) for _ in range(self.n_slots)]
@@ -181,6 +182,56 @@ class ShardedPipeline:
             self.fused[slot].record(self.side)
         self.n += 1
         return slot
+
+    def calibrate(self, batches, make_ctx: Callable, reps: int = 16, placements: int = 4) -> dict:
+        """Choose between one lane and two EMPIRICALLY, and the second lane's stream with it.
+
+        Whether a second lane pays depends on which hardware queue its stream lands on (HIP streams share a handful of
+        queues, handed out round-robin at creation; measured at a 1.25M-row shard, same code: 0.745-0.82 ms per batch
+        when the two lanes' streams do not share a queue with each other's corpus passes, 0.88-0.92 -- no gain -- or worse
+        when they do).  So: time `reps` batches with lane 0 alone, then with each of `placements`
+        freshly created (context, stream, view) as the second lane, keep the best set-up and close the others.  Every rank
+        runs the same number of batches (the collectives stay in step); the choice itself is local to the rank.
+        `make_ctx()` returns a new HipContext of this device, configured like the retriever's."""
+        import time
+
+        import torch
+        assert len(self.lanes) == 1, "calibrate() starts from the single-lane pipeline"
+
+        def period():
+            for i in range(4):
+                self.submit(*batches[i % len(batches)])
+            self.drain()
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                self.submit(*batches[i % len(batches)])
+            self.drain()
+            torch.cuda.synchronize(self.dev)
+            return (time.perf_counter() - t0) / reps * 1e3
+
+        lane0 = self.lanes[0]
+        tried = [{"lanes": 1, "ms": period()}]
+        best_ms, best_lane = tried[0]["ms"], None
+        for p in range(max(0, placements)):
+            c = make_ctx()
+            st = torch.cuda.Stream(device=self.dev)
+            c.set_stream(st)
+            lane = (self.r.local.view(c), st)
+            self.lanes = [lane0, lane]
+            ms = period()
+            tried.append({"lanes": 2, "placement": p, "ms": ms})
+            if ms < 0.97 * best_ms:            # a second lane has to earn its keep
+                if best_lane is not None:
+                    best_lane[0].close()
+                    best_lane[0].ctx.close()
+                best_ms, best_lane = ms, lane
+            else:
+                lane[0].close()
+                c.close()
+        self.lanes = [lane0] if best_lane is None else [lane0, best_lane]
+        self.calibration = {"chosen_lanes": len(self.lanes), "period_ms": best_ms, "tried": tried}
+        return self.calibration
 
     def drain(self) -> None:
         import torch

@@ -866,6 +866,21 @@ def test_index_view_and_pipeline_lanes(ctx, O):
         ws, wd, wc = want[i % len(batches)]
         assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc), "batch %d" % i
     pipe.close()
+    # the empirical choice between one lane and two (bench.py, N > 1): whatever it keeps, the results do not change
+    pipe2 = sharded.ShardedPipeline(sr, fctx, B, depth, k)
+    cal = pipe2.calibrate(batches, lambda: oi.HipContext(0), reps=6, placements=2)
+    assert cal["chosen_lanes"] == len(pipe2.lanes) and cal["chosen_lanes"] in (1, 2) and len(cal["tried"]) == 3
+    outs = []
+    for qv, qt, qo in batches:
+        slot = pipe2.submit(qv, qt, qo)
+        with torch.cuda.stream(pipe2.side):
+            r = pipe2.results[slot]
+            outs.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
+    pipe2.drain()
+    torch.cuda.synchronize()
+    for (gs, gd, gc), (ws, wd, wc) in zip(outs, want):
+        assert torch.equal(wd, gd) and torch.equal(ws, gs) and torch.equal(wc, gc)
+    pipe2.close()
     for c in (fctx, lctx, c1):
         c.close()
     idx.close()
