@@ -101,52 +101,23 @@ class _Pipe(sharded.ShardedPipeline):
         with torch.cuda.stream(st):
             index.search_lists_packed(qv_, qt_, qo_, depth=self.depth, out=self.packed[slot])
             self.lists_done[slot].record(st)
-        if os.environ.get("OI_FUSE_ON_LANE"):   # experiment: the fusion on the lane's own stream and context
-            with torch.cuda.stream(st):
-                self._fuse_packed(index.ctx, flat, S, self.B, self.depth, self.k, out=self.results[slot])
-                self.fused[slot].record(st)
-        else:
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.lists_done[slot])
-                self._fuse_packed(self.fctx, flat, S, self.B, self.depth, self.k, out=self.results[slot])
-                self.fused[slot].record(self.side)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.lists_done[slot])
+            self._fuse_packed(self.fctx, flat, S, self.B, self.depth, self.k, out=self.results[slot])
+            self.fused[slot].record(self.side)
         self.n += 1
         return slot
 
 
 batches = [synth.query_batch_torch(B, DIM, dev, seed=synth.SEED_QUERY + 7919 * i) for i in range(4)]
-periods = {}
-if os.environ.get("OI_EXPLICIT_MAIN_STREAM"):   # experiment: lane 0 on a stream of its own instead of the default stream
-    _ms = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(_ms)
-    ctx.use_torch_current_stream()
-if os.environ.get("OI_PROFILE_IN_LOOP"):
-    ctx.profile_reset(2)
-for lanes in (1, 2):
-    fctx = oi.HipContext(0)
-    lctx = [oi.HipContext(0) for _ in range(lanes - 1)]
-    pipe = _Pipe(_OneRankOfS(), fctx, B, DEPTH, K, lane_ctxs=lctx)
-    if os.environ.get("OI_PROFILE_IN_LOOP") == "all":
-        for c in [ctx] + lctx:
-            c.profile_reset(2)
-    for i in range(8):
-        pipe.submit(*batches[i % 4])
-    pipe.drain()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(reps):
-        pipe.submit(*batches[i % 4])
-    pipe.drain()
-    torch.cuda.synchronize()
-    periods[lanes] = (time.perf_counter() - t0) / reps * 1e3
-    pipe.close()
-    for c in [fctx] + lctx:
-        c.close()
+fctx = oi.HipContext(0)
+pipe = _Pipe(_OneRankOfS(), fctx, B, DEPTH, K)
+cal = pipe.calibrate(batches, lambda: oi.HipContext(0), reps=reps, placements=4)   # one lane, then four placements of a second
 print(json.dumps({"docs_per_shard": n, "shards": S, "batch": B, "lists_ms": t_lists, "lists_kernels_ms": prof,
                   "fuse_ms": t_fuse, "fuse_kernels_ms": prof_f, "step_without_exchange_ms": t_lists + t_fuse,
                   "qps_8gpu_if_exchange_free": B / ((t_lists + t_fuse) / 1e3),
-                  "pipelined_period_ms": {"one_lane": periods[1], "two_lanes": periods[2],
-                                          "note": "batches in flight as bench.py --gpus N runs them (ShardedPipeline: fusion of "
-                                                  "batch i beside the lists of batch i+1; two lanes = two batches' lists at once "
-                                                  "through a view of the shard); four rotating query batches; no all-gather on one GPU"},
-                  "qps_8gpu_pipelined_if_exchange_hidden": B / (periods[2] / 1e3)}))
+                  "pipelined": dict(cal, note="batches in flight as bench.py --gpus N runs them (ShardedPipeline: fusion of batch i "
+                                              "beside the lists of batch i+1; a second lane = two batches' lists at once through a view "
+                                              "of the shard, kept if its stream placement pays -- ShardedPipeline.calibrate); four "
+                                              "rotating query batches; no all-gather on one GPU"),
+                  "qps_8gpu_pipelined_if_exchange_hidden": B / (cal["period_ms"] / 1e3)}))
