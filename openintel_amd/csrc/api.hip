@@ -772,8 +772,9 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             };
             static const bool shape16 = !(oi_ablation_env("OI_KS_SHAPE") && atoi(oi_ablation_env("OI_KS_SHAPE")) == 32);
             static const bool cos_v1 = oi_ablation_env("OI_COSINE_V1") != nullptr || oi_ablation_env("OI_SELECT_V1") != nullptr;
-            const bool want_copy = ctx->cosine_mode == OI_COSINE_SCREEN_COPY;
-            const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || want_copy) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
+            // (a view never makes a copy of its own: it streams the source's if that exists, the f32 rows otherwise)
+            const bool want_copy = ctx->cosine_mode == OI_COSINE_SCREEN_COPY && !(idx->is_view && !idx->screen_copy.p);
+            const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
                                 idx->screen_ok && shape16 && !cos_v1;
             if (!screen) return exact_pipeline(nullptr, nullptr);
 
