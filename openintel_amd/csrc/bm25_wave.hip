@@ -26,7 +26,7 @@
 //            to add to; a run lists a doc once, so no two lanes ever update one entry) and emitted at the end;
 //   emit     straight into the task's OWN pool segment of capacity BM_R (a block cannot touch more docs than it
 //            has): no overflow path, no in-kernel selection; with a threshold only scores >= tau are written.
-// A task with more multi-doc postings than the table takes (384) is cut into doc-id windows (halved until they fit, down
+// A task with more multi-doc postings than the table takes (BW_MULTI_CAP = 384) is cut into doc-id windows (halved until they fit, down
 // to 2048 docs; below that the window's docs get dense accumulators instead -- at most 16 windows per task whatever the
 // query repeats): exact for any data, one window in the common case.  (Two earlier forms, both measured: an open-addressing table for
 // ALL docs -- a wave ran as slow as its longest probe chain, 26K cycles per task -- and a bitmap + rank perfect hash
@@ -38,8 +38,10 @@
 
 #define BW_R OI_BM25_BLOCK_DOCS
 #define BW_WORDS (BW_R / 32)      // 1024 words per bitmap
-#define BW_HASH 512u              // entries {tag = doc-in-block + 1, f32 score bits} of the multi-doc table
-#define BW_MULTI_CAP 384u         // multi-doc postings a window may hold (load factor <= 0.75)
+#define BW_HASH_BITS 9
+#define BW_HASH (1u << BW_HASH_BITS) // entries {tag = doc-in-block + 1, f32 score bits} of the multi-doc table (a multiple of 128)
+#define BW_MULTI_CAP (BW_HASH * 3u / 4u) // multi-doc postings a window may hold (load factor <= 0.75)
+#define BW_TAB_STEPS (BW_HASH / 128u)    // 16-byte pieces of the table per lane
 #define BW_DENSE_W 2048u          // docs per window in dense mode (2048 f32 accumulators = the two maps' 8 KiB)
 #define BW_WAVES 4                // waves per workgroup
 #define BW_STAGE_TERMS 256u       // query terms of a pass staged in LDS (more: read from global memory)
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
     auto stamp = [&]() -> unsigned long long { return TIMING ? __builtin_amdgcn_s_memtime() : 0ull; };
     const unsigned long long t_kernel0 = stamp();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // [BW_WAVES][seen u32 x 1024 | multi u32 x 1024 | table u64 x 512] | q_off[MAX_Q + 1] | order[MAX_Q] | weight[MAX_Q] | terms[STAGE]
+    // [BW_WAVES][seen u32 x 1024 | multi u32 x 1024 | table u64 x BW_HASH] | q_off[MAX_Q + 1] | order[MAX_Q] | weight[MAX_Q] | terms[STAGE]
     uint32_t *s_qoff = reinterpret_cast<uint32_t *>(smem_raw + BW_WAVES * BW_WAVE_LDS);
     uint32_t *s_order = s_qoff + BW_MAX_Q + 1;
     uint32_t *s_weight = s_order + BW_MAX_Q;
@@ -87,14 +89,14 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
     uint32_t *multi = seen + BW_WORDS;
     unsigned long long *tab = reinterpret_cast<unsigned long long *>(multi + BW_WORDS);
     uint4 *maps4 = reinterpret_cast<uint4 *>(seen); // both maps: 8 KiB = 512 x 16 B
-    uint4 *tab4 = reinterpret_cast<uint4 *>(tab);   // 4 KiB = 256 x 16 B
+    uint4 *tab4 = reinterpret_cast<uint4 *>(tab);   // BW_HASH x 8 B = BW_TAB_STEPS x 64 x 16 B
     auto clear_maps = [&]() {
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) maps4[k * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     };
     auto clear_table = [&]() {
 #pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) tab4[k * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t k = 0; k < BW_TAB_STEPS; ++k) tab4[k * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     };
 
     // ---- stage the pass's query terms (offsets relative to the pass's first term), weigh and rank the queries
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
             auto accumulate = [&](bool mul, uint32_t d, float x) { // lanes with mul: table[d] += x, in call order
                 if (DBG == 4) return;
                 bool pend = mul;
-                uint32_t slot = (d * 0x9E3779B1u) >> 23; // 9 bits
+                uint32_t slot = (d * 0x9E3779B1u) >> (32 - BW_HASH_BITS);
                 const uint32_t tag = d + 1u;
                 while (__ballot(pend)) {
                     if (pend) {
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
                     bool pend[4];
                     uint32_t slot[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { pend[u] = mul[u]; slot[u] = (g.p[u].dib * 0x9E3779B1u) >> 23; }
+                    for (int u = 0; u < 4; ++u) { pend[u] = mul[u]; slot[u] = (g.p[u].dib * 0x9E3779B1u) >> (32 - BW_HASH_BITS); }
                     for (;;) {
                         unsigned long long prev[4];
 #pragma unroll
@@ -449,12 +451,12 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
             const unsigned long long t_em0 = stamp();
             // ---- the multi docs' sums out of the table; clear it and the maps
             if (n_multi) { // uniform
-                uint4 ent[4];
+                uint4 ent[BW_TAB_STEPS];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) ent[k] = tab4[k * 64 + lane];
+                for (uint32_t k = 0; k < BW_TAB_STEPS; ++k) ent[k] = tab4[k * 64 + lane];
                 clear_table();
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
+                for (uint32_t k = 0; k < BW_TAB_STEPS; ++k) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const uint32_t tg = h ? ent[k].z : ent[k].x;
@@ -498,7 +500,9 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     const uint64_t n_tasks = (uint64_t)nb * nq;
     OI_REQUIRE(n_tasks < 0xFFFFFFFFull, "bm25 (wave): too many tasks");
     uint64_t wgs = (n_tasks + BW_WAVES - 1) / BW_WAVES;
-    const uint64_t max_wgs = 3ull * (uint64_t)ctx->num_cus; // three resident workgroups per CU (LDS: 3 x 52 KiB)
+    // three resident workgroups per CU (LDS: 3 x 52 KiB).  A 128-entry table (39 KiB: four per CU) was measured and is slower,
+    // 0.209 vs 0.137 ms per batch: tasks with more than 96 multi-doc postings are common and each costs a rescan of a halved window
+    const uint64_t max_wgs = 3ull * (uint64_t)ctx->num_cus;
     if (wgs > max_wgs) wgs = max_wgs;
 #ifdef OI_ABLATION
     if (oi_ablation_env("OI_BM25_WAVE_TIMING")) { // diagnostic: per-section cycle sums (the stamps and forced waits cost time)
