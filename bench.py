@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
     args = ap.parse_args()
 
+    # RCCL / device-tensor sharing across processes needs dmabuf IPC on this driver (the image exports it; keep it if a
+    # launcher dropped the environment)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
