@@ -263,13 +263,15 @@ __device__ static bool hl_match_rest(const HlShared &s, uint32_t p, uint32_t q, 
     return true;
 }
 
-__device__ static void hl_verify(HlShared &s, const HlParams *prm, uint32_t nt, uint32_t e) {
+// dbg (ablation builds): 3 = token packing only, 4 = no keyword bookkeeping (node lists), 5 = no company patterns
+__device__ static void hl_verify(HlShared &s, const HlParams *prm, uint32_t nt, uint32_t e, int dbg = 0) {
     const uint32_t pos = e & 0xFFFFu, lc = e >> 16;
     uint64_t lo, hi;
     hl_pack_token(s, pos, lc, lo, hi); // exact for lc < HL_LONG; longer tokens are never compared packed
     const uint32_t fc = s.ctab[(uint32_t)lo & 0xFFu]; // lowercased first byte: same class
     uint32_t j = ~0u;
-    if ((fc >> lc) & 1u) { // keyword: lc is the exact length, 3..13
+    if (dbg == 3) { if ((lo ^ hi) == 0xDEADBEEFull) s.n_nodes = 0; return; }
+    if (((fc >> lc) & 1u) && dbg != 4) { // keyword: lc is the exact length, 3..13
         const uint32_t sl = hl_kw_slot(lo, s.hot.kw_mult);
         if (s.hot.kw_lo[sl] == lo && s.hot.kw_hi[sl] == hi) {
             const uint32_t k = s.hot.kw_id[sl];
@@ -285,7 +287,7 @@ __device__ static void hl_verify(HlShared &s, const HlParams *prm, uint32_t nt, 
             }
         }
     }
-    if ((fc >> (16u + lc)) & 1u) { // company pattern: words by packed compare, long words by the byte walker
+    if (((fc >> (16u + lc)) & 1u) && dbg != 5) { // company pattern: words by packed compare, long words by the byte walker
         const uint32_t np = s.hot.n_patterns;
         for (uint32_t p = 0; p < np; ++p) {
             if (s.hot.pat_first_len[p] != lc) continue;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
                 }
                 tail += (uint32_t)__popcll(m);
                 if (tail - head >= 64u && dbg != 2) { // a wave's LDS operations complete in order
-                    hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)]);
+                    hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)], dbg);
                     head += 64u;
                 }
             }
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
         if (TM) tk[3] = clock64();
         if (dbg != 2) {
             while (head < tail) {
-                if (head + lane < tail) hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)]);
+                if (head + lane < tail) hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)], dbg);
                 head += 64u;
             }
         }
