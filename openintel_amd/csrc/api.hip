@@ -567,6 +567,14 @@ static uint64_t oi_chunk_growth(uint32_t B) {
     return g ? g : (B <= 8 ? 16 : 8);
 }
 
+// End of the corpus chunk that starts at row r: `chunk` rows, but a tail shorter than a quarter of the chunk is taken along
+// (a 2.5M-row shard: 32K, 256K, 2.2M rows instead of 32K, 256K, 2M and a fourth launch + select for 0.2M).
+static uint64_t oi_chunk_end(uint64_t r, uint64_t chunk, uint64_t n, uint64_t max_chunk) {
+    uint64_t e = std::min(n, r + chunk);
+    if (e < n && (n - e) * 4 <= (e - r) && n - r <= max_chunk) e = n;
+    return e;
+}
+
 // Device-side ranked lists for a batch; all pointers device.
 int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, const uint32_t *d_qo, uint32_t B,
                         uint32_t depth, float *cos_s, uint32_t *cos_d, uint32_t *cos_c, float *bm_s,
@@ -725,7 +733,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > max_chunk) chunk = max_chunk;
-                const uint64_t e = std::min(n, r + chunk);
+                const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk);
                 OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->rows_bf16, r, e, idx->dim, d_qv, B, idx->doc_id_base, P.cos));
                 const bool last = e == n;
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
@@ -760,7 +768,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 uint64_t r = 0;
                 while (r < n) {
                     if (chunk > max_chunk) chunk = max_chunk;
-                    const uint64_t e = std::min(n, r + chunk);
+                    const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk);
                     OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, X));
                     const bool last = e == n;
                     OI_CHECK(oi_launch_select(ctx, X, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
@@ -815,7 +823,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
-                const uint64_t e = std::min(n, r + chunk);
+                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk);
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
                 if (want_copy) OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, d_qv, B, idx->doc_id_base, PF));
