@@ -11,8 +11,20 @@
 // batch and are far larger than every cache, so they are loaded NON-TEMPORAL (MI355X_MICROARCH.md, row nt-weights:
 // "set nt on streamed bytes that one CU reads once").  Measured on the screen kernel at 10M x 768: 5.2-5.4 -> 4.7 ms per
 // batch, 72-74 % -> 82 % of the HBM spec.  -DOI_NO_NT (the ablation build) restores the default policy for A/B runs.
-#ifdef OI_NO_NT
+#if defined(OI_NO_NT)
 #define OI_DMA_NT ""
+#elif defined(OI_DMA_VARIANT) // A/B builds of the other cache-policy bit combinations (tools/build_ablation.sh, OI_ABL_EXTRA)
+#if OI_DMA_VARIANT == 1
+#define OI_DMA_NT "nt sc1 "
+#elif OI_DMA_VARIANT == 2
+#define OI_DMA_NT "sc0 nt sc1 "
+#elif OI_DMA_VARIANT == 3
+#define OI_DMA_NT "sc0 nt "
+#elif OI_DMA_VARIANT == 4
+#define OI_DMA_NT "sc1 "
+#else
+#define OI_DMA_NT "sc0 sc1 "
+#endif
 #else
 #define OI_DMA_NT "nt "
 #endif
