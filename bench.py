@@ -7,8 +7,13 @@
 Workload (BASELINE.json configs[2]): 10M posts x 768-d f32 synthetic corpus,
 batches of 64 queries (embedding + 4 BM25 terms), per-list depth k'=1000, RRF top-100.
 A step = one batch through the whole hot path with corpus, index and queries resident in HBM.
-With N > 1 the SAME 10M-row corpus is row-sharded over the N ranks (strong scaling) and the
-per-shard lists are exchanged with one RCCL all-gather per batch.
+With N > 1 a 10M-row corpus of the same distribution is row-sharded over the N ranks (strong scaling: the TOTAL
+row count is fixed; every rank generates its own rows from seed + rank, so the rows differ from the N=1 corpus but
+their number, shape and statistics do not) and the per-shard lists are exchanged with one RCCL all-gather per batch.
+
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run --nproc-per-node N ... bench.py ...`) BEFORE anything touches the GPU, relays
+rank 0's JSON line and exits with the child's code; under torch.distributed.run it is a rank.
 
 Prints ONE JSON line on rank 0 (see README/DESIGN.md for every field).
 """
@@ -75,6 +80,39 @@ def cpu_baseline(n_total, dim, vocab, depth, k, sample_docs, sample_queries):
     }
 
 
+def launcher_command(argv, n_gpus, port, python=None):
+    """argv/env of the child that runs the N ranks (tests/test_bench_launcher.py).  `argv` = this script's own
+    arguments, passed through unchanged so that every rank parses what the user typed."""
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+           "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.join(ROOT, "bench.py")] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL / device-tensor sharing across processes
+    env.setdefault("OMP_NUM_THREADS", "1")                # torch.distributed.run would set (and warn about) it otherwise
+    env["MASTER_ADDR"] = "127.0.0.1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)                                  # the child launcher sets its ranks' own
+    return cmd, env
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(argv, n_gpus):
+    """Parent of an N-rank run: never imports torch, never touches the GPU (a process that has initialised the GPU must
+    not exec or be replaced); starts the ranks as a CHILD, relays their output line by line and returns their exit code."""
+    import subprocess
+    cmd, env = launcher_command(argv, n_gpus, free_port())
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in p.stdout:               # rank 0 prints the ONE JSON line; anything else the ranks print is passed on too
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +141,12 @@ def main():
     ap.add_argument("--no-screen-copy", action="store_true", help="skip the opt-in screen-copy side measurement")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
+    ap.add_argument("--latency-batches", type=int, default=200, help="timed batches of the latency loops (SURVEY 8d: >= 200)")
+    ap.add_argument("--latency-warmup", type=int, default=20, help="untimed batches before each latency loop (SURVEY 8d: 20)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     # RCCL / device-tensor sharing across processes needs dmabuf IPC on this driver (the image exports it; keep it if a
     # launcher dropped the environment)
@@ -116,9 +159,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world   # under a launcher the launcher's world size is the truth
     # Rehearsal switches for a 1-GPU box (not for reported numbers): OI_BENCH_BACKEND=gloo lets two
     # ranks share cuda:0 (RCCL refuses duplicate devices) so the sharded path runs end to end.
     backend = os.environ.get("OI_BENCH_BACKEND", "nccl")
@@ -126,7 +167,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # OI_BENCH_FORCE_DIST=1 (rehearsal on a one-GPU box): a process group of ONE rank, so that the real RCCL calls -- init
+    # with device_id, the df all-reduce, all_gather_into_tensor on the side stream, calibrate, drain -- run at --gpus 1
+    force_dist = world == 1 and bool(os.environ.get("OI_BENCH_FORCE_DIST"))
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -162,6 +208,8 @@ def main():
     del terms, offs
     torch.cuda.empty_cache()
     sr = sharded.make_hip_sharded(ctx, idx, dev)
+    if force_dist:
+        sr.exchange = True
     sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
     _, df_local = idx.local_stats()                    # for the BM25 leg's algorithmic bytes (rank 0 reports)
     # Distinct query batches rotated through the steps (step i uses batch i mod NB): no step can profit from the
@@ -188,7 +236,7 @@ def main():
     # independent batches, one all-gather each, same results); the latency loop below runs the batches one at a time.
     pipe = None
     lane_ctxs = []
-    if (world > 1 or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment)
+    if (world > 1 or force_dist or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment)
         fuse_ctx = oi.HipContext(local_rank)
         pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k)
         if args.lanes > 1:
@@ -203,7 +251,7 @@ def main():
     def step():
         qv, qt, qo = batches[step_no[0] % NB]
         step_no[0] += 1
-        if world == 1 and not (pipe is not None and pipelined[0]):
+        if world == 1 and not force_dist and not (pipe is not None and pipelined[0]):
             idx.search(qv, qt, qo, k=args.k, depth=args.depth, out=out)   # one C-ABI call: the whole query
             return out.docs
         if pipe is not None and pipelined[0]:
@@ -234,10 +282,19 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    tm_own = elapsed
     tm = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed = float(tm.item())
+    # every rank's own set-up and clock (rank 0 prints them all: a scaling number can be tied to the lanes that produced it)
+    mine = {"rank": rank, "docs_per_gpu": n_local, "doc_id_base": lo, "own_elapsed_ms_per_step": float(tm_own) / args.steps * 1e3,
+            "lane_calibration": pipe.calibration if pipe is not None else None,
+            "lanes": (len(pipe.lanes) if pipe is not None else 1)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     cos_ms, cos_launches = 0.0, 0
     for c in [ctx] + lane_ctxs:   # (with lanes the launches of two batches overlap: their durations are summed as measured)
         m, l = c.profile_read("cosine")
@@ -308,15 +365,56 @@ def main():
                          "note": "OPT-IN mode oi_set_cosine_mode(OI_COSINE_SCREEN_COPY), not the headline: same bound, same exact f32 rescoring, "
                                  "identical lists (tests/test_gpu_prefilter.py); the screen streams a bf16 copy (+50 % corpus memory)"}
 
-    # per-batch latency (p50/p95), measured separately with a host sync after every batch
-    lat = []
-    for _ in range(max(10, min(args.steps, 50))):
-        fence()
-        t1 = time.perf_counter()
+    # ---------------------------------------------------------------- latency: >= 200 timed batches after 20 warm-ups,
+    # whatever --steps says.  (a) device-resident: HIP events on the launch stream around ONE batch at a time (queries and
+    # results in HBM), plus the host's wall clock around the same batch (call + sync); (b) host-inclusive: the OI_HOST entry
+    # point -- H2D of the queries (196 KB of vectors + terms at B=64), the whole query, D2H of the top-k -- wall clock.
+    NL, NW = max(1, args.latency_batches), max(0, args.latency_warmup)
+
+    def pct(v, p):
+        v = sorted(v)
+        return v[min(len(v) - 1, max(0, int(round(p * (len(v) - 1)))))]
+
+    for _ in range(NW):
         step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(NL)]
+    lat_wall = []
+    for a, b in ev:
+        if world > 1:
+            dist.barrier()          # ranks enter every batch together (a collective inside would wait for the slowest anyway)
         torch.cuda.synchronize()
-        lat.append((time.perf_counter() - t1) * 1e3)
-    lat.sort()
+        t1 = time.perf_counter()
+        a.record()
+        step()
+        b.record()
+        torch.cuda.synchronize()
+        lat_wall.append((time.perf_counter() - t1) * 1e3)
+    lat = [a.elapsed_time(b) for a, b in ev]
+
+    host_batches = [tuple(x.cpu().numpy() for x in b) for b in batches]
+    host_batches = [(qv, qt.view(np.uint32) if qt.dtype != np.uint32 else qt, qo.view(np.uint32) if qo.dtype != np.uint32 else qo)
+                    for qv, qt, qo in host_batches]
+
+    def host_step(i):
+        qv, qt, qo = host_batches[i % NB]
+        if world == 1 and not force_dist:
+            return idx.search(qv, qt, qo, k=args.k, depth=args.depth).docs     # OI_HOST: numpy in, numpy out, synchronous
+        d = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) for x in (qv, qt, qo)]
+        return sr.search(d[0], d[1], d[2], args.k, args.depth, check=False)[1].cpu().numpy()
+
+    for i in range(NW):
+        host_step(i)
+    fence()
+    lat_host = []
+    for i in range(NL):
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        host_step(i)
+        lat_host.append((time.perf_counter() - t1) * 1e3)
+    fence()
+    ctx.synchronize()
 
     # a result sanity check outside the timed region: every row full, ids in range
     docs = step().cpu().numpy()
@@ -373,14 +471,14 @@ def main():
         roof["kernel_ms_per_step"] = cos_ms / max(1, args.steps)
         roof["hbm_GBs_algorithmic"] = bytes_step * args.steps / cos_s / 1e9
         roof["legs"] = "BM25 leg overlapped on a side stream during the timed region (oi_set_overlap)"
+        roof["step_level"] = {"achieved": bytes_step * passes * args.steps / elapsed / 1e9, "unit": "GB/s",
+                              "frac": bytes_step * passes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS,
+                              "note": "this rank's corpus bytes streamed / the whole timed region (everything else included)"}
         if lane_ctxs and pipe is not None:
             # two batches' screens share the chip: each launch's duration includes the time it ran beside the other lane's,
             # so the per-launch figure above understates the rate the corpus is streamed at; the step-level figure does not
             roof["overlapped_launches"] = ("%d batches in flight per rank: launch durations overlap and are summed as measured "
                                            "(frac understates the kernel); see step_level and isolated" % (1 + len(lane_ctxs)))
-            roof["step_level"] = {"achieved": bytes_step * passes * args.steps / elapsed / 1e9, "unit": "GB/s",
-                                  "frac": bytes_step * passes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS,
-                                  "note": "this rank's corpus bytes / the whole timed region (everything else included)"}
         roof["isolated"] = {"avg_launch_ms": iso_ms / max(1, iso_launches),
                             "frac": (flops_step if roof["bound"] == "mfma" else bytes_step) * iso_steps / (iso_ms / 1e3)
                             / (1e12 if roof["bound"] == "mfma" else 1e9) / roof["peak"],
@@ -410,8 +508,20 @@ def main():
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
                                       ("; %d batches' lists in flight per rank, each through its own view of the shard" % (1 + len(lane_ctxs))
                                        if lane_ctxs else ""),
-                       "lane_calibration_rank0": pipe.calibration if pipe is not None else None},
-            "p50_ms": lat[len(lat) // 2], "p95_ms": lat[int(len(lat) * 0.95) - 1],
+                       "backend": (backend if (world > 1 or force_dist) else None),
+                       "forced_process_group_of_one": force_dist,
+                       "per_rank": per_rank},
+            "p50_ms": pct(lat, 0.5), "p95_ms": pct(lat, 0.95),
+            "p50_host_ms": pct(lat_host, 0.5), "p95_host_ms": pct(lat_host, 0.95),
+            "latency": {"batches": NL, "warmup": NW,
+                        "device": {"p50_ms": pct(lat, 0.5), "p95_ms": pct(lat, 0.95), "min_ms": min(lat), "max_ms": max(lat),
+                                   "clock": "HIP events on the launch stream around one batch; queries and results resident in HBM"},
+                        "device_wall": {"p50_ms": pct(lat_wall, 0.5), "p95_ms": pct(lat_wall, 0.95),
+                                        "clock": "host perf_counter around the same batch: call + stream sync"},
+                        "host_inclusive": {"p50_ms": pct(lat_host, 0.5), "p95_ms": pct(lat_host, 0.95), "min_ms": min(lat_host), "max_ms": max(lat_host),
+                                           "clock": "host perf_counter around the OI_HOST entry point: H2D of %d query bytes, the query, D2H of %d result bytes"
+                                                    % (sum(int(x.nbytes) for x in host_batches[0]), args.batch * args.k * 8 + args.batch * 4)},
+                        "note": "rank 0's clocks; one batch in flight at a time (the timed throughput region above pipelines batches when N > 1)"},
             "roofline": roof,
             "other_kernels_ms_per_step": dict({t: v[0] / iso_steps for t, v in other.items()},
                                               note="from the %d serialised steps, not the timed region" % iso_steps),
@@ -440,8 +550,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)
+        line["library"] = os.path.relpath(_oil.LIB_PATH, ROOT)   # what was measured (the package loader has no override)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pipe is not None:
+        pipe.close()
+        fuse_ctx.close()
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -72,6 +72,13 @@ int oi_abi_version(void);
 const char *oi_last_error(void);
 
 int oi_create(int device_ordinal, oi_ctx **out);
+/* Lifetime: handles are reference-counted inside the library, so destruction is safe in ANY order.  oi_destroy gives up
+ * the caller's handle (which must not be used again); if indexes created on -- or viewed through -- the ctx are still
+ * alive, its stream, workspaces and mutex stay until the last of them is destroyed (those indexes remain fully usable
+ * and from then on run on the device's default stream: oi_destroy forgets the stream given to oi_set_stream, which may
+ * not outlive the caller).  Likewise oi_index_destroy of an index that still has views keeps its buffers until the
+ * last view is destroyed.  (The reference shares its long-lived adapters the same way -- `Arc<...>` fields of the MCP
+ * server, src/mcp/server.rs:17-20: the last owner frees.) */
 void oi_destroy(oi_ctx *ctx);
 /* `hip_stream` is a hipStream_t (NULL = the default stream). */
 int oi_set_stream(oi_ctx *ctx, void *hip_stream);
@@ -128,7 +135,7 @@ int oi_lexicon_analyze_device(oi_ctx *ctx, const uint8_t *d_text_blob, const uin
 /* Raw sums of SpeculationEngine::social_summary (speculation_engine.rs:76-97).
  * Integer fields are exact.  polarity_sum is a fixed-shape tree sum (bitwise
  * reproducible run to run) and differs from the reference's input-order sum by
- * at most n * 2^-53 * max|partial sum|; see DESIGN.md. */
+ * at most n * 2^-52 * max|partial sum| (the bound tests/ assert). */
 typedef struct {
     uint64_t total;
     uint64_t by_source[2]; /* [reddit, bluesky]  source_kind.rs:5-8 */
@@ -199,7 +206,9 @@ void oi_index_destroy(oi_index *idx);
 /* A second handle on a FINALIZED index, bound to another context of the same device (its own stream and workspaces), so
  * that two searches over the same shard can be in flight at once -- e.g. batch i+1 scored while the selects and the
  * rescoring of batch i drain.  The view borrows every buffer of `src`: it is read-only (the set_* /
- * finalize calls return OI_ERR_STATE), costs no HBM, must be destroyed before `src`, and is searched with the ordinary
+ * finalize calls return OI_ERR_STATE), costs no HBM for the index (its ctx allocates its own search workspaces on
+ * first use, see oi_search_lists), may be destroyed before or after `src` (the buffers live until the last handle on them
+ * is gone), and is searched with the ordinary
  * oi_search* calls.  Thread-safety is per context as everywhere else: the two handles may be driven from two host threads.
  * (No reference counterpart: the reference's port is synchronous, src/domain/ports/post_analyzer.rs:7-11 is its model.) */
 int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out);

@@ -10,8 +10,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libopenintel_hip.so")
-if os.environ.get("OI_LIB", "").startswith("ablation"):   # tools/ only: the -DOI_ABLATION build (tools/build_ablation.sh),
-    LIB_PATH = os.path.join(HERE, "libopenintel_hip_%s.so" % os.environ["OI_LIB"])   # or a renamed copy of one (ablation_<tag>)
+# (No environment override here: tests/ and bench.py always load THIS file.  The tools that time -DOI_ABLATION builds set
+# LIB_PATH explicitly before first use -- tools/_ablation.py.)
 
 OI_HOST, OI_DEVICE = 0, 1
 OI_MAX_DEPTH = 1024

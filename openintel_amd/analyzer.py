@@ -12,6 +12,7 @@ Contract (post_analyzer.rs:9): one PostSignal per input post, aligned to input o
 from __future__ import annotations
 
 import abc
+import ctypes as C
 from typing import List, Sequence
 
 import numpy as np
@@ -75,18 +76,6 @@ class HipLexiconAnalyzer(PostAnalyzer):
     def summary_device(self, d_blob, d_offsets, d_sources=None, tau: float = 0.2, d_polarity=None, d_speculative=None):
         """The scan and the social_summary reduction in one pass (oi_lexicon_summary_device): returns the raw sums
         (_lib.SocialCounters); the per-post outputs are written only if their tensors are given."""
-        import ctypes as C
-        n = d_offsets.numel() - 1
-        out = _lib.SocialCounters()
-        _lib.check(self.ctx.lib.oi_lexicon_summary_device(
-            self.ctx.handle, _lib.ptr(d_blob), _lib.ptr(d_offsets), n, d_blob.numel(), _lib.ptr(d_sources), float(tau),
-            _lib.ptr(d_polarity), _lib.ptr(d_speculative), C.byref(out)))
-        return out
-
-    def summary_device(self, d_blob, d_offsets, d_sources=None, tau: float = 0.2, d_polarity=None, d_speculative=None):
-        """The scan and the social_summary reduction in one pass (oi_lexicon_summary_device): returns the raw sums
-        (_lib.SocialCounters); the per-post outputs are written only if their tensors are given."""
-        import ctypes as C
         n = d_offsets.numel() - 1
         out = _lib.SocialCounters()
         _lib.check(self.ctx.lib.oi_lexicon_summary_device(

@@ -142,16 +142,29 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     return OI_OK;
 }
 
-extern "C" void oi_destroy(oi_ctx *ctx) {
-    if (!ctx) return;
+// The teardown proper: runs when the last reference goes (the caller's handle, or the last index that outlived it).
+static void ctx_release(oi_ctx *ctx) {
+    if (ctx->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     oi_profile_reset(ctx, 0);
     for (auto &kv : ctx->ws) kv.second.release();
     delete ctx;
+}
+
+extern "C" void oi_destroy(oi_ctx *ctx) {
+    if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        // With indexes still alive the object stays (they search, and are destroyed, through it): from here on it runs
+        // on the default stream -- the caller's stream may not outlive the caller's handle.
+        if (ctx->refs.load() > 1) ctx->stream = nullptr;
+    }
+    ctx_release(ctx);
 }
 
 extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
@@ -338,6 +351,7 @@ extern "C" int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint3
     OI_REQUIRE(vocab > 0, "index: vocab must be > 0");
     oi_index *idx = new oi_index();
     idx->ctx = ctx;
+    ctx->refs.fetch_add(1);
     idx->n_docs = n_docs;
     idx->dim = dim;
     idx->vocab = vocab;
@@ -357,6 +371,9 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     if (!src->finalized || (!src->rows && !src->rows_bf16)) { oi_set_error("index view: the source must have rows and be finalized"); return OI_ERR_STATE; }
     oi_index *v = new oi_index();
     v->ctx = ctx;
+    ctx->refs.fetch_add(1);
+    v->src = src;
+    src->refs.fetch_add(1); // the buffers it borrows live until the last handle on them is gone
     v->is_view = true;
     v->n_docs = src->n_docs; v->dim = src->dim; v->vocab = src->vocab; v->doc_id_base = src->doc_id_base;
     v->rows = src->rows; v->rows_bf16 = src->rows_bf16; // rows_owned / rows_bf16_owned stay false
@@ -373,12 +390,16 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     return OI_OK;
 }
 
-extern "C" void oi_index_destroy(oi_index *idx) {
-    if (!idx) return;
+// Drops one reference; the last one frees the buffers (a source index with live views stays until they are gone),
+// then lets go of the source (a view) and of the ctx.
+static void index_release(oi_index *idx) {
+    if (idx->refs.fetch_sub(1) != 1) return;
+    oi_ctx *ctx = idx->ctx;
+    oi_index *src = idx->src;
     {
-        std::lock_guard<std::mutex> g(idx->ctx->mu);
-        (void)hipSetDevice(idx->ctx->device);
-        (void)hipStreamSynchronize(idx->ctx->stream);
+        std::lock_guard<std::mutex> g(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
         if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
         if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
@@ -386,6 +407,19 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         idx->fwd_terms.release(); idx->fwd_offsets.release(); idx->max_row_norm.release(); idx->screen_copy.release();
     }
     delete idx;
+    if (src) index_release(src);
+    ctx_release(ctx);
+}
+
+extern "C" void oi_index_destroy(oi_index *idx) {
+    if (!idx) return;
+    {   // nothing of this handle's work stays in flight behind the call, whoever frees the buffers in the end
+        std::lock_guard<std::mutex> g(idx->ctx->mu);
+        (void)hipSetDevice(idx->ctx->device);
+        (void)hipStreamSynchronize(idx->ctx->stream);
+        if (idx->ctx->side_stream) (void)hipStreamSynchronize(idx->ctx->side_stream);
+    }
+    index_release(idx);
 }
 
 extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize) {

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -79,6 +80,10 @@ struct ProfSpan {
 };
 
 struct oi_ctx {
+    // Lifetime: the caller's handle holds one reference and every oi_index created on / viewed through the ctx one more;
+    // oi_destroy drops the caller's, the teardown runs when the last one goes (api.hip: ctx_release).  An index can
+    // therefore always be destroyed, whatever became of its ctx handle.
+    std::atomic<int> refs{1};
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
@@ -117,7 +122,9 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- index
 struct oi_index {
-    oi_ctx *ctx = nullptr;
+    std::atomic<int> refs{1}; // the caller's handle + one per live view (a view borrows this index's buffers)
+    oi_index *src = nullptr;  // a view: the index whose buffers it borrows (holds a reference on it)
+    oi_ctx *ctx = nullptr;    // holds a reference
     uint64_t n_docs = 0;
     uint32_t dim = 0, vocab = 0, doc_id_base = 0;
 

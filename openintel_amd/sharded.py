@@ -49,6 +49,9 @@ class ShardedRetriever:
         self.dist = dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # the collectives are skipped at world 1 -- unless a caller with an initialised process group of ONE rank sets this
+        # (bench.py OI_BENCH_FORCE_DIST=1, tests/test_gpu_rccl.py: the real RCCL calls on a one-GPU box)
+        self.exchange = self.world > 1
 
     # ---- build: global collection statistics
     def finalize(self) -> None:
@@ -56,7 +59,7 @@ class ShardedRetriever:
         tokens, df = self.local.local_stats()
         stats = torch.tensor([self.local.n_docs, tokens], dtype=torch.int64, device=self.device)
         gdf = torch.from_numpy(df.astype(np.int64)).to(self.device)
-        if self.world > 1:
+        if self.exchange:
             self.dist.all_reduce(stats, group=self.group)
             self.dist.all_reduce(gdf, group=self.group)
         n_global, tok_global = (int(x) for x in stats.cpu())
@@ -75,7 +78,7 @@ class ShardedRetriever:
         if self.fuse_packed is not None:
             B = int(qv.shape[0])
             packed = self.local.search_lists_packed(qv, qt, qo, depth=depth)
-            if self.world > 1:
+            if self.exchange:
                 flat = torch.empty(self.world * packed.numel(), dtype=packed.dtype, device=packed.device)
                 self.dist.all_gather_into_tensor(flat, packed, group=self.group)   # the ONE exchange per batch
             else:
@@ -129,8 +132,18 @@ class ShardedPipeline:
         pipe.drain()                        # everything submitted so far is complete (and checked for overflow)
 
     `fuse_ctx` is a HipContext of its own on the same device (the fusion must not queue behind the next batch's kernels
-    on a scoring stream).  The collectives are issued from the host in submission order on ONE stream, so every rank
-    runs them in the same order whatever the lanes do."""
+    on a scoring stream); the caller owns it (and the retriever's own ctx) -- close() closes only what the pipeline made
+    or was handed as a lane.  The collectives are issued from the host in submission order on ONE stream, so every rank
+    runs them in the same order whatever the lanes do.
+
+    Ownership of a batch's tensors (all asynchronous):
+      * inputs: `qv, qt, qo` must stay ALIVE AND UNMODIFIED until the batch's lists are scored.  A lane stream that is not
+        the caller's gets `record_stream()` on them, so that dropping the tensors right after submit() is safe (the caching
+        allocator will not hand the memory out while the lane still reads it); OVERWRITING them in place is only safe
+        after `wait(slot)` (or drain()).
+      * outputs: `results[slot]` is valid on the caller's stream after `wait(slot)`; the slot is written again
+        `n_slots` submits later -- submit() orders that write after everything the caller's stream had queued by then, so
+        a consumer that was enqueued on the caller's stream before the reuse is safe."""
 
     def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int, lane_ctxs=()):
         import torch
@@ -152,7 +165,7 @@ class ShardedPipeline:
         words = packed_words(self.B, self.depth)
         mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
         self.packed = [mk(words, torch.int32) for _ in range(self.n_slots)]
-        self.flat = ([mk(words * retriever.world, torch.int32) for _ in range(self.n_slots)] if retriever.world > 1
+        self.flat = ([mk(words * retriever.world, torch.int32) for _ in range(self.n_slots)] if retriever.exchange
                      else self.packed)
         self.results = [SearchResult(torch.zeros((self.B, self.k), dtype=torch.float32, device=dev),
                                      torch.zeros((self.B, self.k), dtype=torch.int32, device=dev),
@@ -169,19 +182,29 @@ class ShardedPipeline:
         st = main if lane_stream is None else lane_stream
         if lane_stream is not None:
             lane_stream.wait_stream(main)              # the queries were produced on the caller's stream
+            for t in (qv, qt, qo):                     # ... and are read on the lane's: the allocator must know
+                if hasattr(t, "record_stream"):
+                    t.record_stream(lane_stream)
         if self.n >= self.n_slots:
             st.wait_event(self.fused[slot])            # the slot's packed buffer is free again
+            self.side.wait_stream(main)                # readers of results[slot] queued on the caller's stream go first
         with torch.cuda.stream(st):
             index.search_lists_packed(qv, qt, qo, depth=self.depth, out=self.packed[slot])
             self.lists_done[slot].record(st)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.lists_done[slot])
-            if self.r.world > 1:
+            if self.r.exchange:
                 self.r.dist.all_gather_into_tensor(self.flat[slot], self.packed[slot], group=self.r.group)   # the ONE exchange
             self._fuse_packed(self.fctx, self.flat[slot], self.r.world, self.B, self.depth, self.k, out=self.results[slot])
             self.fused[slot].record(self.side)
         self.n += 1
         return slot
+
+    def wait(self, slot: int) -> None:
+        """Order the caller's current stream after the fusion of the batch in `slot`: results[slot] may be read (and the
+        batch's input tensors overwritten) by work queued on that stream afterwards.  No host synchronisation."""
+        import torch
+        torch.cuda.current_stream(self.dev).wait_event(self.fused[slot])
 
     def calibrate(self, batches, make_ctx: Callable, reps: int = 16, placements: int = 4) -> dict:
         """Choose between one lane and two EMPIRICALLY, and the second lane's stream with it.
@@ -245,8 +268,17 @@ class ShardedPipeline:
         self.r.check()
 
     def close(self) -> None:
+        """Drain, then close every lane the pipeline holds beyond the retriever's own index: the view AND its context
+        (each lane context owns a full set of search workspaces -- candidate pools, screen pool, BM25 pools: HBM that would
+        otherwise wait for the garbage collector).  `fuse_ctx` and the retriever stay the caller's."""
+        import torch
+        if self.n:
+            self.drain()
+        torch.cuda.synchronize(self.dev)
         for index, _ in self.lanes[1:]:
+            c = index.ctx
             index.close()
+            c.close()
         self.lanes = self.lanes[:1]
 
 

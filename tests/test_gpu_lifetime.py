@@ -1,0 +1,88 @@
+"""Handle lifetime at the C ABI (VERDICT r02 missing #5 / weak #8): ctx, index and view may be destroyed in ANY order.
+
+Round 1's `gpurun_out/pf1.log` ended in `terminate called after throwing 'std::bad_variant_access'` at interpreter exit:
+a failed test kept a HybridIndex alive past its ctx fixture, and oi_index_destroy then locked the mutex of a freed oi_ctx.
+The library now counts references (include/openintel_hip.h, oi_destroy): these tests drop the ctx FIRST."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _case(n=20000, dim=64, vocab=300, B=12, seed=5):
+    rng = np.random.default_rng(seed)
+    rows = rng.integers(-3, 4, size=(n, dim)).astype(np.float32)      # small integers: every dot product exact in any order
+    q = rng.integers(-3, 4, size=(B, dim)).astype(np.float32)
+    lens = rng.integers(1, 12, size=n)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32)
+    qo = (np.arange(B + 1) * 3).astype(np.uint32)
+    qt = rng.integers(0, vocab, size=3 * B).astype(np.uint32)
+    return rows, q, terms, offs, qt, qo
+
+
+def _index(ctx, rows, terms, offs, vocab=300):
+    import openintel_amd as oi
+    idx = oi.HybridIndex(ctx, rows.shape[0], rows.shape[1], vocab)
+    idx.set_embeddings(rows, normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    return idx
+
+
+def test_ctx_destroyed_before_its_index_and_view_before_or_after_source():
+    import openintel_amd as oi
+    rows, q, terms, offs, qt, qo = _case()
+    ctx = oi.HipContext(0)
+    idx = _index(ctx, rows, terms, offs)
+    want = idx.search(q, qt, qo, k=10, depth=100)
+    ctx2 = oi.HipContext(0)
+    view = idx.view(ctx2)
+    ctx.close()                         # oi_destroy with a live index AND a live view of it: deferred inside the library
+    got = idx.search(q, qt, qo, k=10, depth=100)          # the index stays usable (default stream from here on)
+    assert np.array_equal(got.docs, want.docs) and np.array_equal(got.scores, want.scores)
+    idx.close()                         # source destroyed before its view: the buffers live on
+    ctx2.close()                        # ... and the view's ctx handle too
+    got = view.search(q, qt, qo, k=10, depth=100)
+    assert np.array_equal(got.docs, want.docs) and np.array_equal(got.scores, want.scores)
+    view.close()                        # last handle: everything is freed here
+    # a fresh ctx works afterwards (nothing was left locked or half torn down)
+    ctx3 = oi.HipContext(0)
+    idx3 = _index(ctx3, rows, terms, offs)
+    got = idx3.search(q, qt, qo, k=10, depth=100)
+    assert np.array_equal(got.docs, want.docs)
+    idx3.close()
+    ctx3.close()
+
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+import openintel_amd as oi
+sys.path.insert(0, %r)
+from test_gpu_lifetime import _case, _index
+rows, q, terms, offs, qt, qo = _case()
+ctx = oi.HipContext(0)
+LEAKED = _index(ctx, rows, terms, offs)          # module global: alive until interpreter teardown
+LEAKED_VIEW_CTX = oi.HipContext(0)
+LEAKED_VIEW = LEAKED.view(LEAKED_VIEW_CTX)
+r = LEAKED.search(q, qt, qo, k=10, depth=100)
+ctx.close()                                        # the pf1.log order: ctx gone, index destroyed later by __del__
+del ctx
+print("ok", int(r.counts.sum()))
+"""
+
+
+def test_interpreter_exit_with_a_leaked_index_whose_ctx_was_closed_first():
+    r = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, os.path.join(ROOT, "tests"))], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "ok" in r.stdout and "terminate called" not in r.stderr and "core dumped" not in r.stderr

@@ -1,0 +1,150 @@
+"""The REAL RCCL calls of the sharded path on a one-GPU box (VERDICT r02 weak #5 / next #1b): a process group of ONE rank
+over backend "nccl" (= RCCL on ROCm; it refuses two ranks on one device, so the two-rank rehearsal is gloo,
+tests/test_gpu_two_ranks.py).  What runs: init_process_group("nccl", device_id=...), the df / N / token all-reduce of
+ShardedRetriever.finalize, ShardedPipeline.calibrate with live collectives, all_gather_into_tensor on the exchange
+stream under the lanes, drain -- and bench.py's own self-launcher in the same set-up.  Results equal the plain oi_search bit for bit."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N, DIM, VOCAB, B, DEPTH, K, NB = 60_003, 384, 300, 64, 200, 50, 5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _corpus():
+    rng = np.random.default_rng(77)
+    rows = rng.integers(-3, 4, size=(N, DIM)).astype(np.float32)
+    lens = rng.integers(1, 12, size=N)
+    offs = np.zeros(N + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(0, VOCAB, size=int(offs[-1])).astype(np.uint32)
+    batches = []
+    for _ in range(NB):
+        q = rng.integers(-3, 4, size=(B, DIM)).astype(np.float32)
+        qt = rng.integers(0, 40, size=B * 4).astype(np.uint32)
+        qo = (np.arange(B + 1) * 4).astype(np.uint32)
+        batches.append((q, qt, qo))
+    return rows, terms, offs, batches
+
+
+def _worker(rank, port, ret):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    import openintel_amd as oi
+    from openintel_amd import sharded
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    rows, terms, offs, batches = _corpus()
+    ctx = oi.HipContext(0)
+    ctx.use_torch_current_stream()
+    idx = oi.HybridIndex(ctx, N, DIM, VOCAB, doc_id_base=0)
+    idx.set_embeddings(torch.from_numpy(rows.copy()).to(dev), normalize=False)
+    idx.set_forward(terms, offs)
+    sr = sharded.make_hip_sharded(ctx, idx, dev)
+    sr.exchange = True                       # run the collectives although the group has one rank
+    sr.finalize()                            # all_reduce (RCCL) of (N, tokens) and of the df vector
+    dbatches = [tuple(torch.from_numpy(x).to(dev) for x in b) for b in batches]
+    serial = [sr.search(*b, K, DEPTH) for b in dbatches]          # all_gather_into_tensor on the current stream
+    fctx = oi.HipContext(0)
+    pipe = sharded.ShardedPipeline(sr, fctx, B, DEPTH, K)
+    cal = pipe.calibrate(dbatches, lambda: oi.HipContext(0), reps=4, placements=2)    # collectives live during the timing
+    outs = []
+    for rep in range(2):
+        for b in dbatches:
+            slot = pipe.submit(*b)
+            pipe.wait(slot)
+            r = pipe.results[slot]
+            outs.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
+    pipe.drain()
+    torch.cuda.synchronize()
+    ret["pipe"] = [(s.cpu().numpy(), d.cpu().numpy(), c.cpu().numpy()) for s, d, c in outs]
+    ret["serial"] = [(s.cpu().numpy(), d.cpu().numpy(), c.cpu().numpy()) for s, d, c in serial]
+    ret["lanes"] = cal["chosen_lanes"]
+    pipe.close()
+    fctx.close()
+    idx.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_rccl_group_of_one_runs_the_real_collectives_and_equals_oi_search():
+    import torch.multiprocessing as mp
+    import openintel_amd as oi
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    rows, terms, offs, batches = _corpus()
+    ctx = oi.HipContext(0)
+    idx = oi.HybridIndex(ctx, N, DIM, VOCAB)
+    idx.set_embeddings(rows.copy(), normalize=False)
+    idx.set_forward(terms, offs)
+    idx.finalize()
+    want = []
+    for q, qt, qo in batches:
+        r = idx.search(q, qt, qo, k=K, depth=DEPTH)
+        want.append((np.asarray(r.scores).copy(), np.asarray(r.docs).copy(), np.asarray(r.counts).copy()))
+    assert ret["lanes"] in (1, 2)
+    for name, outs in (("serial", ret["serial"]), ("pipe", ret["pipe"])):
+        for i, (s, d, c) in enumerate(outs):
+            ws, wd, wc = want[i % NB]
+            assert np.array_equal(c, wc), (name, i)
+            for b in range(B):
+                n = int(wc[b])
+                assert np.array_equal(d[b, :n], wd[b, :n].astype(d.dtype)), (name, i, b)
+                assert np.array_equal(s[b, :n].view(np.uint32), ws[b, :n].view(np.uint32)), (name, i, b)
+    idx.close()
+    ctx.close()
+
+
+def _run_bench(extra_env, argv):
+    env = dict(os.environ)
+    env.update(extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--docs", "200000", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-screen-copy", "--latency-batches", "20",
+         "--latency-warmup", "3", "--vocab", "4096"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_self_launcher_two_gloo_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` with NO launcher around it: the parent starts the two ranks itself (the driver's N > 1
+    form would otherwise die on the old SystemExit).  Rehearsal switches: gloo + both ranks on cuda:0."""
+    line = _run_bench({"OI_BENCH_BACKEND": "gloo", "OI_BENCH_SINGLE_DEVICE": "1"}, ["--gpus", "2"] + SMALL)
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    pr = line["config"]["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and sum(p["docs_per_gpu"] for p in pr) == 200000
+    assert all(p["lane_calibration"] is not None for p in pr)
+    assert line["roofline"]["step_level"]["frac"] > 0
+    assert line["latency"]["batches"] == 20 and line["p50_host_ms"] >= line["p50_ms"] * 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_with_a_forced_rccl_group_of_one():
+    line = _run_bench({"OI_BENCH_FORCE_DIST": "1"}, ["--gpus", "1"] + SMALL)
+    assert line["n_gpus"] == 1 and line["config"]["backend"] == "nccl" and line["config"]["forced_process_group_of_one"]
+    assert line["config"]["per_rank"][0]["lane_calibration"] is not None
+    assert line["value"] > 0

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 import openintel_amd as oi
+import _ablation  # noqa: F401  (OI_LIB=ablation: tools only)
 from openintel_amd import dip, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000

@@ -2,6 +2,7 @@ import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 import openintel_amd as oi
+import _ablation  # noqa: F401  (OI_LIB=ablation: tools only)
 from openintel_amd import synth, sharded
 dev = torch.device("cuda:0")
 n, B, DIM, DEPTH, K = 1_250_000, 64, 768, 1000, 100

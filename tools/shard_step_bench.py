@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 import openintel_amd as oi
+import _ablation  # noqa: F401  (OI_LIB=ablation: tools only)
 from openintel_amd import retriever, synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
