@@ -55,7 +55,8 @@ typedef enum {
     OI_ERR_STATE = -5,         /* call order violated (e.g. search before finalize) */
     OI_ERR_NO_DEVICE = -6,     /* no gfx950 device / HIP runtime unusable */
     OI_ERR_UNSUPPORTED = -7,   /* shape outside what the kernels are built for */
-    OI_ERR_OVERFLOW = -8       /* an internal candidate pool overflowed (bug guard) */
+    OI_ERR_OVERFLOW = -8,      /* an internal candidate pool overflowed (bug guard) */
+    OI_ERR_COMM = -9           /* an RCCL call failed; message has the ncclResult string */
 } oi_status;
 
 enum { OI_HOST = 0, OI_DEVICE = 1 };
@@ -67,6 +68,7 @@ enum { OI_HOST = 0, OI_DEVICE = 1 };
 
 typedef struct oi_ctx oi_ctx;
 typedef struct oi_index oi_index;
+typedef struct oi_comm oi_comm;
 
 int oi_abi_version(void);
 const char *oi_last_error(void);
@@ -297,6 +299,36 @@ int oi_rrf_fuse(oi_ctx *ctx, const uint32_t *docs_a, const uint32_t *counts_a,
 int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_terms,
               const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
               int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+
+/* ------------------------------------------------------------------------- */
+/* The row-sharded query behind the C ABI: one process per GPU, RCCL inside    */
+/* ------------------------------------------------------------------------- */
+/*
+ * A host with no collective library of its own (the Rust composition root, src/main.rs:17-39, has none -- the reference
+ * is single-process, src/domain/ports/mod.rs:1-8) gets the whole multi-GPU path from three calls.  RCCL is loaded on
+ * first use (dlopen "librccl.so.1"; OI_ERR_UNSUPPORTED if absent).  A Python host that already runs torch.distributed
+ * can keep using oi_search_lists_packed + its own all-gather + oi_fuse_packed (openintel_amd/sharded.py): same results.
+ *
+ *   rank 0:  oi_comm_unique_id(id)  -> ship the OI_COMM_ID_BYTES to every rank over the host's own channel (file, socket, env)
+ *   all:     oi_comm_create(ctx, id, rank, world, &comm)          collective: returns when every rank has called it
+ *            ... oi_index_create / set_embeddings / set_forward on the rank's row shard (doc_id_base = first global row) ...
+ *            oi_index_finalize_sharded(idx, comm)                  collective: all-reduce of (n_docs, tokens) and of the
+ *                                                                  df vector, then the impacts from the GLOBAL statistics
+ *            oi_search_sharded(idx, comm, queries..., out...)      collective, once per batch, same queries on every rank:
+ *                                                                  the shard's two lists -> ONE ncclAllGather of
+ *                                                                  OI_PACKED_WORDS words per rank -> merge to the global
+ *                                                                  top-depth per list -> RRF.  Identical output on every rank.
+ * Collectives run on the ctx stream in call order: every rank must issue them in the same order (one host thread per
+ * comm, or external ordering).  With OI_DEVICE buffers oi_search_sharded is asynchronous like oi_search.
+ */
+#define OI_COMM_ID_BYTES 128
+int oi_comm_unique_id(uint8_t id_out[OI_COMM_ID_BYTES]);
+int oi_comm_create(oi_ctx *ctx, const uint8_t id[OI_COMM_ID_BYTES], uint32_t rank, uint32_t world, oi_comm **out);
+void oi_comm_destroy(oi_comm *comm);
+int oi_index_finalize_sharded(oi_index *idx, oi_comm *comm);
+int oi_search_sharded(oi_index *idx, oi_comm *comm, const float *query_vecs, const uint32_t *query_terms,
+                      const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k, int location,
+                      float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 
 /* Diagnostics of the OI_COSINE_SCREEN mode (tests/test_gpu_prefilter.py; not on the query path).  For host
  * queries [n_queries][dim] against rows [row_begin, row_begin + n_rows) of an f32 index:

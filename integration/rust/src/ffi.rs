@@ -11,6 +11,11 @@ pub struct OiCtx {
 pub struct OiIndex {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct OiComm {
+    _p: [u8; 0],
+}
+pub const OI_COMM_ID_BYTES: usize = 128;
 
 /// `oi_social_counters`: the raw sums of SpeculationEngine::social_summary (speculation_engine.rs:76-97).
 #[repr(C)]
@@ -28,6 +33,7 @@ pub struct OiSocialCounters {
 pub const OI_OK: c_int = 0;
 pub const OI_ERR_ANALYZER_MISMATCH: c_int = -3;
 pub const OI_ERR_OVERFLOW: c_int = -8;
+pub const OI_ERR_COMM: c_int = -9;
 pub const OI_HOST: c_int = 0;
 pub const OI_DEVICE: c_int = 1;
 pub const OI_COSINE_EXACT: c_int = 0;
@@ -97,6 +103,15 @@ extern "C" {
     pub fn oi_search(idx: *mut OiIndex, query_vecs: *const f32, query_terms: *const u32, q_term_offsets: *const u32,
                      n_queries: u32, depth: u32, k: u32, location: c_int, scores_out: *mut f32, docs_out: *mut u32,
                      counts_out: *mut u32) -> c_int;
+
+    // the row-sharded query with RCCL inside the library (one process per GPU)
+    pub fn oi_comm_unique_id(id_out: *mut u8) -> c_int;
+    pub fn oi_comm_create(ctx: *mut OiCtx, id: *const u8, rank: u32, world: u32, out: *mut *mut OiComm) -> c_int;
+    pub fn oi_comm_destroy(comm: *mut OiComm);
+    pub fn oi_index_finalize_sharded(idx: *mut OiIndex, comm: *mut OiComm) -> c_int;
+    pub fn oi_search_sharded(idx: *mut OiIndex, comm: *mut OiComm, query_vecs: *const f32, query_terms: *const u32,
+                             q_term_offsets: *const u32, n_queries: u32, depth: u32, k: u32, location: c_int,
+                             scores_out: *mut f32, docs_out: *mut u32, counts_out: *mut u32) -> c_int;
 
     pub fn oi_screen_probe(idx: *mut OiIndex, query_vecs: *const f32, n_queries: u32, row_begin: u64, n_rows: u32,
                            screen_scores_out: *mut f32, eps_out: *mut f32) -> c_int;

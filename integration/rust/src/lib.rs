@@ -169,6 +169,76 @@ impl HipIndex {
     }
 }
 
+/// An RCCL communicator owned by the library (`oi_comm`): the multi-GPU exchange for a host that brings no collective
+/// library of its own -- the reference is single-process (src/domain/ports/mod.rs:1-8), its composition root
+/// (src/main.rs:17-39) would start one process per GPU and ship the 128-byte id over any channel it likes.
+pub struct HipComm {
+    ctx: Arc<HipCtx>,
+    comm: *mut ffi::OiComm,
+    pub rank: u32,
+    pub world: u32,
+}
+unsafe impl Send for HipComm {}
+impl Drop for HipComm {
+    fn drop(&mut self) {
+        unsafe { ffi::oi_comm_destroy(self.comm) }
+    }
+}
+impl HipComm {
+    /// Rank 0 only; every rank passes the same bytes to `create`.
+    pub fn unique_id() -> Result<[u8; ffi::OI_COMM_ID_BYTES], HipError> {
+        let mut id = [0u8; ffi::OI_COMM_ID_BYTES];
+        check(unsafe { ffi::oi_comm_unique_id(id.as_mut_ptr()) })?;
+        Ok(id)
+    }
+    /// Collective: returns when every rank of `world` has called it.
+    pub fn create(ctx: Arc<HipCtx>, id: &[u8; ffi::OI_COMM_ID_BYTES], rank: u32, world: u32) -> Result<Self, HipError> {
+        let mut comm = std::ptr::null_mut();
+        check(unsafe { ffi::oi_comm_create(ctx.raw(), id.as_ptr(), rank, world, &mut comm) })?;
+        Ok(HipComm { ctx, comm, rank, world })
+    }
+}
+
+impl HipIndex {
+    /// One rank's row shard of a collection split over `comm.world` GPUs: rows [doc_id_base, doc_id_base + n) of the
+    /// global collection.  Collective (the df / N / token all-reduce runs inside `oi_index_finalize_sharded`).
+    pub fn build_shard(comm: &HipComm, doc_id_base: u32, rows: &mut [f32], dim: usize, vocab: u32, terms: &[u32],
+                       offsets: &[u64]) -> Result<Self, HipError> {
+        let n_docs = (rows.len() / dim) as u64;
+        let mut idx = std::ptr::null_mut();
+        check(unsafe { ffi::oi_index_create(comm.ctx.raw(), n_docs, dim as u32, vocab, doc_id_base, &mut idx) })?;
+        let me = HipIndex { ctx: comm.ctx.clone(), idx, dim, source: None };
+        check(unsafe { ffi::oi_index_set_embeddings(me.idx, rows.as_mut_ptr(), ffi::OI_HOST, 1) })?;
+        check(unsafe { ffi::oi_index_set_forward(me.idx, terms.as_ptr(), offsets.as_ptr(), ffi::OI_HOST) })?;
+        check(unsafe { ffi::oi_index_finalize_sharded(me.idx, comm.comm) })?;
+        Ok(me)
+    }
+    /// The hybrid query over ALL shards (collective, same queries on every rank, one ncclAllGather per batch inside):
+    /// identical lists on every rank, global doc ids.
+    pub fn search_sharded(&self, comm: &HipComm, query_vecs: &[f32], query_terms: &[Vec<u32>], k: usize, depth: usize)
+                          -> Result<Vec<Vec<RankedPost>>, HipError> {
+        let b = query_terms.len();
+        assert_eq!(query_vecs.len(), b * self.dim);
+        let mut flat = Vec::new();
+        let mut offs = vec![0u32];
+        for t in query_terms {
+            flat.extend_from_slice(t);
+            offs.push(flat.len() as u32);
+        }
+        if flat.is_empty() {
+            flat.push(0);
+        }
+        let (mut s, mut d, mut c) = (vec![0f32; b * k], vec![0u32; b * k], vec![0u32; b]);
+        check(unsafe {
+            ffi::oi_search_sharded(self.idx, comm.comm, query_vecs.as_ptr(), flat.as_ptr(), offs.as_ptr(), b as u32,
+                                   depth as u32, k as u32, ffi::OI_HOST, s.as_mut_ptr(), d.as_mut_ptr(), c.as_mut_ptr())
+        })?;
+        Ok((0..b)
+            .map(|q| (0..c[q] as usize).map(|i| RankedPost { doc_id: d[q * k + i], score: s[q * k + i] }).collect())
+            .collect())
+    }
+}
+
 /// The adapter for the reference: `impl PostAnalyzer for HipLexiconAnalyzer`.
 #[cfg(feature = "reference")]
 pub mod adapter {

@@ -27,6 +27,8 @@ OI_ERR_STATE = -5
 OI_ERR_NO_DEVICE = -6
 OI_ERR_UNSUPPORTED = -7
 OI_ERR_OVERFLOW = -8
+OI_ERR_COMM = -9
+OI_COMM_ID_BYTES = 128
 
 
 class OiError(RuntimeError):
@@ -84,6 +86,11 @@ SIGNATURES = {
     "oi_merge_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_rrf_fuse": (_I, [_P, _P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_search": (_I, [_P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
+    "oi_comm_unique_id": (_I, [_P]),
+    "oi_comm_create": (_I, [_P, _P, _U32, _U32, C.POINTER(_P)]),
+    "oi_comm_destroy": (None, [_P]),
+    "oi_index_finalize_sharded": (_I, [_P, _P]),
+    "oi_search_sharded": (_I, [_P, _P, _P, _P, _P, _U32, _U32, _U32, _I, _P, _P, _P]),
     "oi_screen_probe": (_I, [_P, _P, _U32, _U64, _U32, _P, _P]),
     "oi_profile_reset": (_I, [_P, _I]),
     "oi_profile_read": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_U64)]),

@@ -1132,24 +1132,11 @@ extern "C" int oi_search_lists_packed(oi_index *idx, const float *qv, const uint
     return check_overflow_locked(ctx);
 }
 
-extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t n_shards, uint32_t B, uint32_t depth,
-                              uint32_t k, int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
-    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(packed_all && scores_out && docs_out && counts_out, "fuse_packed: null buffer");
-    OI_REQUIRE(n_shards >= 1 && n_shards <= 1024, "fuse_packed: n_shards=%u outside [1,1024]", n_shards);
-    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH && k >= 1 && k <= OI_MAX_DEPTH, "fuse_packed: depth/k out of range");
-    if (B == 0) return OI_OK;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    OI_HIP_CHECK(hipSetDevice(ctx->device));
+// All shards' packed lists (device) -> global top-depth per list -> RRF top-k into device outputs.  ctx->mu held.
+static int fuse_packed_device(oi_ctx *ctx, const uint32_t *d_in, uint32_t n_shards, uint32_t B, uint32_t depth, uint32_t k,
+                              float *o_s, uint32_t *o_d, uint32_t *o_c) {
     hipStream_t st = ctx->stream;
-    const size_t L = (size_t)B * depth, W = (size_t)OI_PACKED_WORDS(B, depth), K = (size_t)B * k;
-    const uint32_t *d_in = packed_all;
-    if (location != OI_DEVICE) {
-        DevBuf &in = ctx->buf("packed_in");
-        OI_CHECK(in.ensure(W * 4 * n_shards));
-        OI_HIP_CHECK(hipMemcpyAsync(in.p, packed_all, W * 4 * n_shards, hipMemcpyHostToDevice, st));
-        d_in = in.as<uint32_t>();
-    }
+    const size_t L = (size_t)B * depth, W = (size_t)OI_PACKED_WORDS(B, depth);
     DevBuf &flag = ctx->buf("state_flag");
     if (!flag.p) {
         OI_CHECK(flag.ensure(16));
@@ -1160,7 +1147,7 @@ extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t 
     DevBuf &pk = ctx->buf("merge_pool"), &pc = ctx->buf("merge_counts"), &ml = ctx->buf("merged_lists");
     OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)2 * B * mstride));
     OI_CHECK(pc.ensure(sizeof(uint32_t) * (size_t)2 * B * (1 + n_shards)));
-    OI_CHECK(ml.ensure((4 * L + 2 * (size_t)B) * 4 + (2 * K + B) * 4));
+    OI_CHECK(ml.ensure((4 * L + 2 * (size_t)B) * 4));
     PoolView pool{pk.as<uint64_t>(), pc.as<uint32_t>(), pc.as<uint32_t>() + 2 * (size_t)B, nullptr, mstride,
                   carry_cap, depth, n_shards, n_shards, flag.as<uint32_t>()};
     float *m_s = ml.as<float>();                       // [2][B][depth]
@@ -1171,19 +1158,136 @@ extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t 
     OI_CHECK(oi_launch_lists_to_pool(ctx, reinterpret_cast<const float *>(d_in), d_in + 2 * L, d_in + 4 * L, W, W,
                                      n_shards, 2 * B, depth, pool));
     OI_CHECK(oi_launch_select(ctx, pool, 2 * B, depth, false, m_s, m_d, m_c, depth));
-    float *o_s = scores_out;
-    uint32_t *o_d = docs_out, *o_c = counts_out;
-    if (location != OI_DEVICE) {
-        o_s = reinterpret_cast<float *>(m_c + 2 * (size_t)B);
-        o_d = reinterpret_cast<uint32_t *>(o_s + K);
-        o_c = o_d + K;
-        OI_HIP_CHECK(hipMemsetAsync(o_s, 0, (2 * K + B) * 4, st));
-    }
-    OI_CHECK(oi_launch_rrf(ctx, m_d, m_c, m_d + L, m_c + B, B, depth, k, o_s, o_d, o_c));
-    if (location == OI_DEVICE) return OI_OK;
+    return oi_launch_rrf(ctx, m_d, m_c, m_d + L, m_c + B, B, depth, k, o_s, o_d, o_c);
+}
+
+extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t n_shards, uint32_t B, uint32_t depth,
+                              uint32_t k, int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(packed_all && scores_out && docs_out && counts_out, "fuse_packed: null buffer");
+    OI_REQUIRE(n_shards >= 1 && n_shards <= 1024, "fuse_packed: n_shards=%u outside [1,1024]", n_shards);
+    OI_REQUIRE(depth >= 1 && depth <= OI_MAX_DEPTH && k >= 1 && k <= OI_MAX_DEPTH, "fuse_packed: depth/k out of range");
+    if (B == 0) return OI_OK;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (location == OI_DEVICE) return fuse_packed_device(ctx, packed_all, n_shards, B, depth, k, scores_out, docs_out, counts_out);
+    hipStream_t st = ctx->stream;
+    const size_t W = (size_t)OI_PACKED_WORDS(B, depth), K = (size_t)B * k;
+    DevBuf &in = ctx->buf("packed_in"), &fo = ctx->buf("fuse_out");
+    OI_CHECK(in.ensure(W * 4 * n_shards));
+    OI_CHECK(fo.ensure((2 * K + B) * 4 + 64));
+    OI_HIP_CHECK(hipMemcpyAsync(in.p, packed_all, W * 4 * n_shards, hipMemcpyHostToDevice, st));
+    float *o_s = fo.as<float>();
+    uint32_t *o_d = reinterpret_cast<uint32_t *>(o_s + K), *o_c = o_d + K;
+    OI_HIP_CHECK(hipMemsetAsync(o_s, 0, (2 * K + B) * 4, st));
+    OI_CHECK(fuse_packed_device(ctx, in.as<uint32_t>(), n_shards, B, depth, k, o_s, o_d, o_c));
     OI_HIP_CHECK(hipMemcpyAsync(scores_out, o_s, K * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipMemcpyAsync(docs_out, o_d, K * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipMemcpyAsync(counts_out, o_c, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));
     return OI_OK;
+}
+
+// ---------------------------------------------------------------- the sharded query with RCCL inside (comm.hip)
+extern "C" int oi_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    return oi_rccl_unique_id(id_out);
+}
+
+extern "C" int oi_comm_create(oi_ctx *ctx, const uint8_t *id, uint32_t rank, uint32_t world, oi_comm **out) {
+    if (!ctx || !id || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    OI_REQUIRE(world >= 1 && world <= 1024 && rank < world, "comm: rank %u of %u", rank, world);
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device)); // RCCL binds the communicator to the current device
+    void *nc = nullptr;
+    OI_CHECK(oi_rccl_init(&nc, world, id, rank));
+    oi_comm *c = new oi_comm();
+    c->ctx = ctx;
+    ctx->refs.fetch_add(1);
+    c->nccl = nc;
+    c->rank = rank;
+    c->world = world;
+    *out = c;
+    return OI_OK;
+}
+
+extern "C" void oi_comm_destroy(oi_comm *comm) {
+    if (!comm) return;
+    oi_ctx *ctx = comm->ctx;
+    {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        oi_rccl_destroy(comm->nccl);
+    }
+    delete comm;
+    ctx_release(ctx);
+}
+
+extern "C" int oi_index_finalize_sharded(oi_index *idx, oi_comm *comm) {
+    if (!idx || !comm) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the data on the index it was taken from)"); return OI_ERR_STATE; }
+    oi_ctx *ctx = idx->ctx;
+    OI_REQUIRE(comm->ctx == ctx, "finalize_sharded: the communicator belongs to another context");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }
+    if (idx->finalized) { oi_set_error("index: already finalized"); return OI_ERR_STATE; }
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // BM25 needs the statistics of the WHOLE collection: sum over the shards of (n_docs, tokens) and of df
+    DevBuf &ws = ctx->buf("sharded_stats");
+    OI_CHECK(ws.ensure(16 + sizeof(uint32_t) * (size_t)idx->vocab));
+    uint64_t mine[2] = {idx->n_docs, idx->total_tokens};
+    OI_HIP_CHECK(hipMemcpyAsync(ws.p, mine, 16, hipMemcpyHostToDevice, st));
+    uint32_t *d_df = reinterpret_cast<uint32_t *>(ws.as<uint8_t>() + 16);
+    OI_HIP_CHECK(hipMemcpyAsync(d_df, idx->df_local.p, sizeof(uint32_t) * (size_t)idx->vocab, hipMemcpyDeviceToDevice, st));
+    OI_CHECK(oi_rccl_all_reduce_sum(comm->nccl, ws.p, 2, /*u64=*/true, st));
+    OI_CHECK(oi_rccl_all_reduce_sum(comm->nccl, d_df, idx->vocab, /*u64=*/false, st));
+    uint64_t glob[2] = {0, 0};
+    std::vector<uint32_t> gdf(idx->vocab);
+    OI_HIP_CHECK(hipMemcpyAsync(glob, ws.p, 16, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(gdf.data(), d_df, sizeof(uint32_t) * (size_t)idx->vocab, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return oi_bm25_finalize(idx, glob[0], glob[1], gdf.data());
+}
+
+extern "C" int oi_search_sharded(oi_index *idx, oi_comm *comm, const float *qv, const uint32_t *qt, const uint32_t *qo,
+                                 uint32_t B, uint32_t depth, uint32_t k, int location, float *scores_out,
+                                 uint32_t *docs_out, uint32_t *counts_out) {
+    OI_CHECK(check_search_args(idx, qv, qt, qo, B, depth));
+    if (!comm) { oi_set_error("null communicator"); return OI_ERR_INVALID_ARG; }
+    OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH, "search: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
+    OI_REQUIRE(scores_out && docs_out && counts_out, "search: null output buffer");
+    oi_ctx *ctx = idx->ctx;
+    OI_REQUIRE(comm->ctx == ctx, "search_sharded: the communicator belongs to another context");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    QueryStage q;
+    OI_CHECK(stage_queries(idx, qv, qt, qo, B, location, &q));
+    const size_t L = (size_t)B * depth, W = (size_t)OI_PACKED_WORDS(B, depth), K = (size_t)B * k;
+    DevBuf &pk = ctx->buf("sharded_packed"), &fl = ctx->buf("sharded_flat");
+    OI_CHECK(pk.ensure(W * 4));
+    OI_CHECK(fl.ensure(W * 4 * comm->world));
+    uint32_t *d_p = pk.as<uint32_t>();
+    OI_HIP_CHECK(hipMemsetAsync(d_p + 4 * L, 0, (size_t)B * 8, st)); // counts
+    float *sc = reinterpret_cast<float *>(d_p);
+    uint32_t *dc = d_p + 2 * L, *cn = d_p + 4 * L;
+    OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, sc, dc, cn, sc + L, dc + L, cn + B));
+    // the ONE exchange per batch: every rank's packed lists to every rank (1 MB per rank at B=64, k'=1000)
+    OI_CHECK(oi_rccl_all_gather_u32(comm->nccl, d_p, fl.as<uint32_t>(), W, st));
+    if (location == OI_DEVICE)
+        return fuse_packed_device(ctx, fl.as<uint32_t>(), comm->world, B, depth, k, scores_out, docs_out, counts_out);
+    DevBuf &fo = ctx->buf("fuse_out");
+    OI_CHECK(fo.ensure((2 * K + B) * 4 + 64));
+    float *o_s = fo.as<float>();
+    uint32_t *o_d = reinterpret_cast<uint32_t *>(o_s + K), *o_c = o_d + K;
+    OI_HIP_CHECK(hipMemsetAsync(o_s, 0, (2 * K + B) * 4, st));
+    OI_CHECK(fuse_packed_device(ctx, fl.as<uint32_t>(), comm->world, B, depth, k, o_s, o_d, o_c));
+    OI_HIP_CHECK(hipMemcpyAsync(scores_out, o_s, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(docs_out, o_d, K * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipMemcpyAsync(counts_out, o_c, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return check_overflow_locked(ctx);
 }

@@ -265,3 +265,15 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
                    uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,
                    uint32_t block_end);
+
+// comm.hip: RCCL through dlopen (no link-time dependency)
+struct oi_comm {
+    oi_ctx *ctx = nullptr; // holds a reference
+    void *nccl = nullptr;  // ncclComm_t
+    uint32_t rank = 0, world = 1;
+};
+int oi_rccl_unique_id(uint8_t *id_out);
+int oi_rccl_init(void **comm_out, uint32_t world, const uint8_t *id_bytes, uint32_t rank);
+void oi_rccl_destroy(void *comm);
+int oi_rccl_all_gather_u32(void *comm, const uint32_t *send, uint32_t *recv, size_t words, hipStream_t st);
+int oi_rccl_all_reduce_sum(void *comm, void *buf, size_t count, bool u64, hipStream_t st);

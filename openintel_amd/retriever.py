@@ -212,6 +212,25 @@ class HybridIndex(PostRetriever):
                                       _lib.ptr(out.docs), _lib.ptr(out.counts)))
         return out
 
+    # ---------------------------------------------------------------- the sharded query with RCCL inside the library
+    def finalize_sharded(self, comm: "NativeComm") -> None:
+        """Collective over `comm`: all-reduce of (n_docs, tokens, df) inside the library, then the impacts from the global
+        statistics (oi_index_finalize_sharded) -- what ShardedRetriever.finalize does with torch.distributed."""
+        _lib.check(self.lib.oi_index_finalize_sharded(self.handle, comm.handle))
+
+    def search_sharded(self, comm: "NativeComm", query_vecs, query_terms, q_term_offsets, k: int = DEFAULT_K,
+                       depth: int = DEFAULT_DEPTH, out: Optional[SearchResult] = None) -> SearchResult:
+        """Collective over `comm`, same queries on every rank: this shard's lists -> ONE ncclAllGather -> global merge ->
+        RRF, in one C call (oi_search_sharded).  Identical result on every rank."""
+        dev, B, qv, qt, qo = self._queries(query_vecs, query_terms, q_term_offsets)
+        if out is None:
+            out = SearchResult(self._alloc(dev, (B, k), np.float32), self._alloc(dev, (B, k), np.uint32),
+                               self._alloc(dev, (B,), np.uint32))
+        _lib.check(self.lib.oi_search_sharded(self.handle, comm.handle, _lib.ptr(qv), _lib.ptr(qt), _lib.ptr(qo), B,
+                                              int(depth), int(k), _lib.OI_DEVICE if dev else _lib.OI_HOST,
+                                              _lib.ptr(out.scores), _lib.ptr(out.docs), _lib.ptr(out.counts)))
+        return out
+
     def screen_probe(self, query_vecs, row_begin: int = 0, n_rows: int = 0):
         """Diagnostics of the bf16 screen (oi_screen_probe): (s~ [B, n_rows] or None, eps [B]) for host queries --
         the screen's raw scores of rows [row_begin, row_begin + n_rows) and each query's proven bound."""
@@ -242,6 +261,41 @@ class HybridIndex(PostRetriever):
             self.lib.oi_index_destroy(self.handle)
             self.handle = None
             self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeComm:
+    """An RCCL communicator owned by the library (oi_comm_*): the multi-GPU exchange without torch.distributed.
+
+        id = NativeComm.unique_id()            # rank 0; ship the 128 bytes to the other ranks over any host channel
+        comm = NativeComm(ctx, id, rank, world)  # collective
+        idx.finalize_sharded(comm); idx.search_sharded(comm, qv, qt, qo, k, depth)
+
+    Collectives run on the ctx stream in call order; every rank issues them in the same order."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * _lib.OI_COMM_ID_BYTES)()
+        _lib.check(_lib.load().oi_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, ctx: HipContext, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == _lib.OI_COMM_ID_BYTES
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        buf = (C.c_uint8 * _lib.OI_COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        _lib.check(ctx.lib.oi_comm_create(ctx.handle, C.cast(buf, C.c_void_p), self.rank, self.world, C.byref(h)))
+        self.handle = h
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.ctx.lib.oi_comm_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:
