@@ -148,6 +148,13 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
+    # stdout carries ONE JSON line and nothing else: RCCL ("RCCL version : ...") and gloo ("[Gloo] Rank 0 is connected ...")
+    # print banners to fd 1 from native code, so fd 1 is pointed at stderr for the life of the rank and the line is
+    # written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # RCCL / device-tensor sharing across processes needs dmabuf IPC on this driver (the image exports it; keep it if a
     # launcher dropped the environment)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -551,7 +558,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)
         line["library"] = os.path.relpath(_oil.LIB_PATH, ROOT)   # what was measured (the package loader has no override)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if pipe is not None:
         pipe.close()
         fuse_ctx.close()

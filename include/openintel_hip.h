@@ -115,6 +115,18 @@ int oi_set_cosine_mode(oi_ctx *ctx, int mode);
  * runs beside the MFMA-bound cosine leg; enable = 0 runs them one after the other. */
 int oi_set_overlap(oi_ctx *ctx, int enable);
 
+/* One device-buffer query call is ~30 kernel launches, memsets and event operations: ~0.3 ms of host time, which at a
+ * 1.25M-row shard (one of 8 GPUs) is what limits the rate, not the GPU (0.7 ms of work that two batches in flight overlap).
+ * enable != 0: oi_search_lists_packed / oi_fuse_packed / oi_search calls with OI_DEVICE buffers are CAPTURED into a
+ * hipGraph the second time they are made with the same arguments (index, pointers, sizes, modes) on this ctx and
+ * replayed with one launch call from then on.  The launch sequence does not depend on the data (chunk schedules and
+ * pool capacities are functions of the sizes alone), so a replay does exactly what the call would have done: same
+ * kernels, same buffers, same results.  The caller's part: keep using the SAME buffers (a serving loop copies each batch
+ * into per-slot staging buffers -- openintel_amd/sharded.py does).  A call with new arguments runs eagerly once more;
+ * profiling (oi_profile_reset) and the default stream disable replay; at most 32 captured calls per ctx are kept.
+ * Default off.  (No reference counterpart: the reference makes no device calls, src/adapters/analyzer/lexicon.rs:82-87.) */
+int oi_set_graph_replay(oi_ctx *ctx, int enable);
+
 /* ------------------------------------------------------------------------- */
 /* PostAnalyzer path (reference-pinned)                                        */
 /* ------------------------------------------------------------------------- */

@@ -65,6 +65,7 @@ SIGNATURES = {
     "oi_lexicon_analyze_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P]),
     "oi_lexicon_summary_device": (_I, [_P, _P, _P, _U64, _U64, _P, C.c_double, _P, _P, C.POINTER(SocialCounters)]),
     "oi_set_overlap": (_I, [_P, _I]),
+    "oi_set_graph_replay": (_I, [_P, _I]),
     "oi_set_cosine_mode": (_I, [_P, _I]),
     "oi_catalyst_keyword": (C.c_char_p, [_U32]),
     "oi_headline_scan": (_I, [_P, _P, _P, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),

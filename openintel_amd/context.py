@@ -41,6 +41,15 @@ class HipContext:
         """BM25 leg of a hybrid query beside the cosine leg on a side stream (default) or after it."""
         _lib.check(self.lib.oi_set_overlap(self.handle, 1 if enable else 0))
 
+    def set_graph_replay(self, enable: bool) -> None:
+        """Capture repeated device-buffer query calls into hipGraphs and replay them with one launch (oi_set_graph_replay):
+        same kernels, same results, ~0.3 ms less host time per call.  The caller keeps using the same buffers."""
+        _lib.check(self.lib.oi_set_graph_replay(self.handle, 1 if enable else 0))
+
+    def graph_stats(self):
+        """(replays, captures) since the ctx was created."""
+        return self.profile_read("graph_replays")[1], self.profile_read("graph_captures")[1]
+
     # ---- HIP-event kernel timing (bench.py)
     def profile_reset(self, enable=True) -> None:
         """enable: False/0 off, True/1 every tagged launch, 2 only the cosine scorer's launches."""

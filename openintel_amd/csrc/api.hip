@@ -32,9 +32,12 @@ int oi_dyn_lds(oi_ctx *ctx, const void *kernel, size_t bytes) {
 }
 
 // ---------------------------------------------------------------- buffers
+std::atomic<uint64_t> g_oi_ws_epoch{1};
+
 int DevBuf::ensure(size_t bytes) {
     if (bytes <= cap && p) return OI_OK;
     if (borrowed) { oi_set_error("internal: a borrowed buffer cannot grow"); return OI_ERR_STATE; }
+    g_oi_ws_epoch.fetch_add(1); // captured launch sequences that hold the old pointer are stale from here on
     if (p) {
         (void)hipFree(p);
         p = nullptr;
@@ -47,6 +50,7 @@ int DevBuf::ensure(size_t bytes) {
     return OI_OK;
 }
 void DevBuf::release() {
+    if (p) g_oi_ws_epoch.fetch_add(1);
     if (p && !borrowed) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -90,6 +94,11 @@ extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *tota
         if (launches_out) *launches_out = 0;
         return OI_OK;
     }
+    if (strcmp(kernel_tag, "graph_replays") == 0 || strcmp(kernel_tag, "graph_captures") == 0) { // diagnostics of oi_set_graph_replay
+        if (total_ms_out) *total_ms_out = 0.0;
+        if (launches_out) *launches_out = kernel_tag[6] == 'r' ? ctx->graph_replays : ctx->graph_captures;
+        return OI_OK;
+    }
     if (strcmp(kernel_tag, "screen_gate") == 0) { // diagnostics: did the last screened search fall back to the exact kernel?
         uint32_t g = 0;                          // (0 no, nonzero yes; -1 when no search has used the screen)
         if (ctx->last_screen_gate) OI_HIP_CHECK(hipMemcpy(&g, ctx->last_screen_gate, 4, hipMemcpyDeviceToHost));
@@ -105,6 +114,106 @@ extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *tota
         }
     if (total_ms_out) *total_ms_out = total;
     if (launches_out) *launches_out = n;
+    return OI_OK;
+}
+
+// ---------------------------------------------------------------- captured launch sequences (hipGraph replay)
+#define OI_MAX_GRAPHS 32
+
+static void graph_free(GraphEntry &e) {
+    if (e.exec) (void)hipGraphExecDestroy(e.exec);
+    if (e.graph) (void)hipGraphDestroy(e.graph);
+    e.exec = nullptr;
+    e.graph = nullptr;
+}
+
+static void graphs_purge(oi_ctx *ctx, uint64_t index_uid) { // index_uid 0 = all
+    for (size_t i = 0; i < ctx->graphs.size();)
+        if (index_uid == 0 || ctx->graphs[i].key[0] == index_uid) {
+            graph_free(ctx->graphs[i]);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)i);
+        } else ++i;
+}
+
+// body(): the launches of one call, all on ctx->stream (and streams forked from and joined back into it), nothing that
+// synchronises.  First call with a key: eager (it also allocates the workspaces and sets the kernels' attributes);
+// second: captured, instantiated, launched; afterwards: one hipGraphLaunch.  Anything unusual -- profiling on, the default
+// stream, a workspace that moved, a capture that fails -- takes the eager path, which is always correct.
+template <class F> static int run_captured(oi_ctx *ctx, const uint64_t (&key)[10], F &&body) {
+    if (!ctx->use_graphs || ctx->prof_enabled || !ctx->stream) return body();
+    const uint64_t epoch = g_oi_ws_epoch.load();
+    GraphEntry *e = nullptr;
+    for (auto &g : ctx->graphs)
+        if (memcmp(g.key, key, sizeof(key)) == 0) { e = &g; break; }
+    if (!e) {
+        if (ctx->graphs.size() >= OI_MAX_GRAPHS) {
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->graphs.size(); ++i)
+                if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+            graph_free(ctx->graphs[lru]);
+            ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+        }
+        ctx->graphs.emplace_back();
+        e = &ctx->graphs.back();
+        memcpy(e->key, key, sizeof(key));
+        e->last_use = ++ctx->graph_clock;
+        const int rc = body();
+        e->epoch = g_oi_ws_epoch.load(); // (after the call: whatever it allocated is in place now)
+        return rc;
+    }
+    e->last_use = ++ctx->graph_clock;
+    if (e->epoch != epoch) { // a workspace moved since: start over (eager now, capture next time)
+        graph_free(*e);
+        e->state = 0;
+        const int rc = body();
+        e->epoch = g_oi_ws_epoch.load();
+        return rc;
+    }
+    if (e->state == 2) return body();
+    if (e->state == 1) {
+        OI_HIP_CHECK(hipGraphLaunch(e->exec, ctx->stream));
+        ++ctx->graph_replays;
+        return OI_OK;
+    }
+    // state 0, same epoch: capture
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        e->state = 2;
+        return body();
+    }
+    const int rc = body();
+    hipGraph_t g = nullptr;
+    const hipError_t end = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != OI_OK || end != hipSuccess || !g || g_oi_ws_epoch.load() != epoch) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        e->state = 2;
+        if (rc != OI_OK) return rc; // (nothing of the failed call was launched)
+        return body();               // the captured launches never ran: run them
+    }
+    hipGraphExec_t x = nullptr;
+    if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        e->state = 2;
+        return body();
+    }
+    e->graph = g;
+    e->exec = x;
+    e->state = 1;
+    ++ctx->graph_captures;
+    OI_HIP_CHECK(hipGraphLaunch(e->exec, ctx->stream));
+    return OI_OK;
+}
+
+extern "C" int oi_set_graph_replay(oi_ctx *ctx, int enable) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->use_graphs = enable != 0;
+    if (!ctx->use_graphs) {
+        OI_HIP_CHECK(hipSetDevice(ctx->device));
+        graphs_purge(ctx, 0);
+    }
     return OI_OK;
 }
 
@@ -150,6 +259,7 @@ static void ctx_release(oi_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     oi_profile_reset(ctx, 0);
+    graphs_purge(ctx, 0);
     for (auto &kv : ctx->ws) kv.second.release();
     delete ctx;
 }
@@ -341,6 +451,8 @@ extern "C" int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n
 }
 
 // ---------------------------------------------------------------- index
+static std::atomic<uint64_t> g_index_uid{1};
+
 extern "C" int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint32_t vocab, uint32_t doc_id_base,
                                oi_index **out) {
     if (!ctx || !out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
@@ -350,6 +462,7 @@ extern "C" int oi_index_create(oi_ctx *ctx, uint64_t n_docs, uint32_t dim, uint3
                OI_MAX_DIM);
     OI_REQUIRE(vocab > 0, "index: vocab must be > 0");
     oi_index *idx = new oi_index();
+    idx->uid = g_index_uid.fetch_add(1);
     idx->ctx = ctx;
     ctx->refs.fetch_add(1);
     idx->n_docs = n_docs;
@@ -370,6 +483,7 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     std::lock_guard<std::mutex> g(src->ctx->mu); // the source is not being built or searched while it is aliased
     if (!src->finalized || (!src->rows && !src->rows_bf16)) { oi_set_error("index view: the source must have rows and be finalized"); return OI_ERR_STATE; }
     oi_index *v = new oi_index();
+    v->uid = g_index_uid.fetch_add(1);
     v->ctx = ctx;
     ctx->refs.fetch_add(1);
     v->src = src;
@@ -400,6 +514,7 @@ static void index_release(oi_index *idx) {
         std::lock_guard<std::mutex> g(ctx->mu);
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+        graphs_purge(ctx, idx->uid);
         if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
         if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
         idx->uniq_keys.release(); idx->tf.release(); idx->doc_len.release(); idx->df_local.release();
@@ -1052,10 +1167,19 @@ extern "C" int oi_search(oi_index *idx, const float *qv, const uint32_t *qt, con
     float *d_bs = reinterpret_cast<float *>(d_cd + L);
     uint32_t *d_bd = reinterpret_cast<uint32_t *>(d_bs + L);
     uint32_t *d_cc = d_bd + L, *d_bc = d_cc + B;
+    if (location == OI_DEVICE) {
+        const uint64_t key[10] = {idx->uid, 3, (uint64_t)(uintptr_t)qv, (uint64_t)(uintptr_t)qt, (uint64_t)(uintptr_t)qo,
+                                  ((uint64_t)B << 32) | depth, (uint64_t)(uintptr_t)scores_out,
+                                  ((uint64_t)ctx->cosine_mode << 16) | ((uint64_t)idx->bm25_mode << 8) | (ctx->overlap_legs ? 1u : 0u),
+                                  ((uint64_t)idx->max_query_terms << 32) | k, (uint64_t)(uintptr_t)docs_out ^ ((uint64_t)(uintptr_t)counts_out << 1)};
+        return run_captured(ctx, key, [&]() -> int {
+            OI_HIP_CHECK(hipMemsetAsync(d_cc, 0, (size_t)B * 8, ctx->stream));
+            OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, d_cs, d_cd, d_cc, d_bs, d_bd, d_bc));
+            return oi_launch_rrf(ctx, d_cd, d_cc, d_bd, d_bc, B, depth, k, scores_out, docs_out, counts_out);
+        });
+    }
     OI_HIP_CHECK(hipMemsetAsync(d_cc, 0, (size_t)B * 8, st));
     OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, d_cs, d_cd, d_cc, d_bs, d_bd, d_bc));
-    if (location == OI_DEVICE)
-        return oi_launch_rrf(ctx, d_cd, d_cc, d_bd, d_bc, B, depth, k, scores_out, docs_out, counts_out);
     DevBuf &f = ctx->buf("search_out");
     OI_CHECK(f.ensure((2 * K + B) * 4 + 64));
     float *d_so = f.as<float>();
@@ -1122,11 +1246,20 @@ extern "C" int oi_search_lists_packed(oi_index *idx, const float *qv, const uint
         OI_CHECK(o.ensure(W * 4));
         d_out = o.as<uint32_t>();
     }
-    OI_HIP_CHECK(hipMemsetAsync(d_out + 4 * L, 0, (size_t)B * 8, st)); // counts
     float *sc = reinterpret_cast<float *>(d_out);
     uint32_t *dc = d_out + 2 * L, *cn = d_out + 4 * L;
-    OI_CHECK(search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, sc, dc, cn, sc + L, dc + L, cn + B));
-    if (location == OI_DEVICE) return OI_OK;
+    auto body = [&]() -> int {
+        OI_HIP_CHECK(hipMemsetAsync(d_out + 4 * L, 0, (size_t)B * 8, ctx->stream)); // counts
+        return search_lists_device(idx, q.qv, q.qt, q.qo, B, depth, sc, dc, cn, sc + L, dc + L, cn + B);
+    };
+    if (location == OI_DEVICE) {
+        const uint64_t key[10] = {idx->uid, 1, (uint64_t)(uintptr_t)qv, (uint64_t)(uintptr_t)qt, (uint64_t)(uintptr_t)qo,
+                                  ((uint64_t)B << 32) | depth, (uint64_t)(uintptr_t)packed_out,
+                                  ((uint64_t)ctx->cosine_mode << 16) | ((uint64_t)idx->bm25_mode << 8) | (ctx->overlap_legs ? 1u : 0u),
+                                  idx->max_query_terms, 0};
+        return run_captured(ctx, key, body);
+    }
+    OI_CHECK(body());
     OI_HIP_CHECK(hipMemcpyAsync(packed_out, d_out, W * 4, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));
     return check_overflow_locked(ctx);
@@ -1170,7 +1303,14 @@ extern "C" int oi_fuse_packed(oi_ctx *ctx, const uint32_t *packed_all, uint32_t 
     if (B == 0) return OI_OK;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
-    if (location == OI_DEVICE) return fuse_packed_device(ctx, packed_all, n_shards, B, depth, k, scores_out, docs_out, counts_out);
+    if (location == OI_DEVICE) {
+        const uint64_t key[10] = {0xF05Eull << 32, 2, (uint64_t)(uintptr_t)packed_all, ((uint64_t)n_shards << 32) | B,
+                                  ((uint64_t)depth << 32) | k, (uint64_t)(uintptr_t)scores_out, (uint64_t)(uintptr_t)docs_out,
+                                  (uint64_t)(uintptr_t)counts_out, 0, 0};
+        return run_captured(ctx, key, [&]() -> int {
+            return fuse_packed_device(ctx, packed_all, n_shards, B, depth, k, scores_out, docs_out, counts_out);
+        });
+    }
     hipStream_t st = ctx->stream;
     const size_t W = (size_t)OI_PACKED_WORDS(B, depth), K = (size_t)B * k;
     DevBuf &in = ctx->buf("packed_in"), &fo = ctx->buf("fuse_out");

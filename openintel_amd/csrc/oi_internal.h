@@ -79,6 +79,21 @@ struct ProfSpan {
     hipEvent_t a, b;
 };
 
+// Bumped whenever any DevBuf allocates, grows or is released: a captured launch sequence (below) holds raw workspace
+// pointers and is only replayed while no workspace has moved since it was captured.
+extern std::atomic<uint64_t> g_oi_ws_epoch;
+
+// One device-buffer call of the query path (oi_search_lists_packed, oi_fuse_packed, oi_search: ~30 launches, memsets and
+// event operations; 0.3 ms of host time at a 1.25M-row shard, where the GPU needs 0.7) captured into a hipGraph the second
+// time it is made with the same arguments, and replayed with ONE launch call from then on (oi_set_graph_replay).
+struct GraphEntry {
+    uint64_t key[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t epoch = 0, last_use = 0;
+    int state = 0; // 0 = seen once (ran eagerly: every workspace exists now), 1 = captured, 2 = not capturable (stays eager)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 struct oi_ctx {
     // Lifetime: the caller's handle holds one reference and every oi_index created on / viewed through the ctx one more;
     // oi_destroy drops the caller's, the teardown runs when the last one goes (api.hip: ctx_release).  An index can
@@ -101,6 +116,9 @@ struct oi_ctx {
     const uint32_t *last_screen_gate = nullptr; // the gate word of the last screened search (diagnostics)
     std::map<std::string, std::vector<ProfSpan>> prof;
     std::vector<hipEvent_t> event_pool;
+    bool use_graphs = false;          // oi_set_graph_replay
+    std::vector<GraphEntry> graphs;   // <= OI_MAX_GRAPHS, least recently used evicted
+    uint64_t graph_clock = 0, graph_replays = 0, graph_captures = 0;
 
     DevBuf &buf(const char *name) { return ws[name]; }
     void prof_begin(const char *tag);
@@ -122,6 +140,7 @@ struct ProfScope {
 
 // ---------------------------------------------------------------- index
 struct oi_index {
+    uint64_t uid = 0;         // process-unique (graph cache keys: an address can be reused, a uid cannot)
     std::atomic<int> refs{1}; // the caller's handle + one per live view (a view borrows this index's buffers)
     oi_index *src = nullptr;  // a view: the index whose buffers it borrows (holds a reference on it)
     oi_ctx *ctx = nullptr;    // holds a reference

@@ -145,7 +145,8 @@ class ShardedPipeline:
         `n_slots` submits later -- submit() orders that write after everything the caller's stream had queued by then, so
         a consumer that was enqueued on the caller's stream before the reuse is safe."""
 
-    def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int, lane_ctxs=()):
+    def __init__(self, retriever: "ShardedRetriever", fuse_ctx, n_queries: int, depth: int, k: int, lane_ctxs=(),
+                 graphs: bool = False):
         import torch
         from .retriever import SearchResult, fuse_packed, packed_words
         self.r, self.fctx, self.B, self.depth, self.k = retriever, fuse_ctx, int(n_queries), int(depth), int(k)
@@ -154,12 +155,26 @@ class ShardedPipeline:
         self.dev = dev
         self.side = torch.cuda.Stream(device=dev)
         fuse_ctx.set_stream(self.side)
-        # lane 0 = the retriever's own index on the caller's stream; lane j > 0 = a view on a stream of its own
-        self.lanes = [(retriever.local, None)]
+        # graphs=True: every batch is copied into its slot's staging buffers, so a slot's two C calls (lists, fusion) see
+        # the same pointers every time and the library replays them as captured hipGraphs -- one launch call each instead
+        # of ~35 launches / memsets / event operations (oi_set_graph_replay).  OFF by default: measured on ROCm 7.2 a
+        # replayed graph runs its parallel branches (BM25 leg beside the cosine leg) one after the other and graphs of two
+        # lanes do not overlap each other -- 0.84-0.98 ms per batch against 0.76 eager at a 1.25M-row shard
+        self.graphs = bool(graphs)
+        self.stage = {}
+        for c in [retriever.local.ctx, fuse_ctx, *lane_ctxs]:
+            c.set_graph_replay(self.graphs)
+        # lane 0 = the retriever's own index, lane j > 0 = a view of it; EVERY lane scores on a stream of its own.  (Round 2
+        # ran lane 0 on the caller's stream: `lane_stream.wait_stream(main)` -- "the queries are ready" -- then made every
+        # batch of lane 1 wait for the whole previous batch of lane 0, which sat in front of it on that stream: consecutive
+        # batches overlapped only every other time.  rocprofv3 timeline, profiles/r03_shard_timeline_before.txt.)
+        self.main_ctx_stream = None       # set while lane 0's context runs on its lane stream (restored by drain())
+        self.lanes = [(retriever.local, torch.cuda.Stream(device=dev))]
         for c in lane_ctxs:
             st = torch.cuda.Stream(device=dev)
             c.set_stream(st)
             self.lanes.append((retriever.local.view(c), st))
+        self.n_shards = retriever.world
         self.n_slots = max(4, 2 * len(self.lanes))   # (4: room for a second lane added by calibrate())
         self.calibration = None
         words = packed_words(self.B, self.depth)
@@ -177,28 +192,47 @@ class ShardedPipeline:
     def submit(self, qv, qt, qo) -> int:
         import torch
         slot = self.n % self.n_slots
-        index, lane_stream = self.lanes[self.n % len(self.lanes)]
+        index, st = self.lanes[self.n % len(self.lanes)]
         main = torch.cuda.current_stream(self.dev)
-        st = main if lane_stream is None else lane_stream
-        if lane_stream is not None:
-            lane_stream.wait_stream(main)              # the queries were produced on the caller's stream
-            for t in (qv, qt, qo):                     # ... and are read on the lane's: the allocator must know
-                if hasattr(t, "record_stream"):
-                    t.record_stream(lane_stream)
+        if self.main_ctx_stream is None:               # lane 0's context: onto its lane stream until drain()
+            self.main_ctx_stream = main
+            self.lanes[0][0].ctx.set_stream(self.lanes[0][1])
+        st.wait_stream(main)                           # the queries were produced on the caller's stream (which carries
+        for t in (qv, qt, qo):                         # nothing of the pipeline's own: no false dependency between batches)
+            if hasattr(t, "record_stream"):            # ... and are read on the lane's: the allocator must know
+                t.record_stream(st)
         if self.n >= self.n_slots:
             st.wait_event(self.fused[slot])            # the slot's packed buffer is free again
             self.side.wait_stream(main)                # readers of results[slot] queued on the caller's stream go first
         with torch.cuda.stream(st):
+            if self.graphs:
+                qv, qt, qo = self._staged(slot, qv, qt, qo)
             index.search_lists_packed(qv, qt, qo, depth=self.depth, out=self.packed[slot])
             self.lists_done[slot].record(st)
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.lists_done[slot])
-            if self.r.exchange:
-                self.r.dist.all_gather_into_tensor(self.flat[slot], self.packed[slot], group=self.r.group)   # the ONE exchange
-            self._fuse_packed(self.fctx, self.flat[slot], self.r.world, self.B, self.depth, self.k, out=self.results[slot])
+            self._fuse_packed(self.fctx, self._exchange(slot), self.n_shards, self.B, self.depth, self.k, out=self.results[slot])
             self.fused[slot].record(self.side)
         self.n += 1
         return slot
+
+    def _staged(self, slot: int, qv, qt, qo):
+        """Copy the batch into the slot's staging buffers (on the lane stream): stable pointers for the captured call."""
+        import torch
+        sg = self.stage.get(slot)
+        if sg is None or sg[0].shape != qv.shape or sg[1].numel() < qt.numel() or sg[2].shape != qo.shape:
+            sg = (torch.empty_like(qv), torch.empty(max(qt.numel(), 4 * self.B), dtype=qt.dtype, device=qt.device), torch.empty_like(qo))
+            self.stage[slot] = sg
+        sg[0].copy_(qv, non_blocking=True)
+        sg[1][:qt.numel()].copy_(qt, non_blocking=True)
+        sg[2].copy_(qo, non_blocking=True)
+        return sg
+
+    def _exchange(self, slot: int):
+        """All shards' packed lists of the batch in `slot` (runs on the exchange stream): the ONE all-gather per batch."""
+        if self.r.exchange:
+            self.r.dist.all_gather_into_tensor(self.flat[slot], self.packed[slot], group=self.r.group)
+        return self.flat[slot]
 
     def wait(self, slot: int) -> None:
         """Order the caller's current stream after the fusion of the batch in `slot`: results[slot] may be read (and the
@@ -222,7 +256,7 @@ class ShardedPipeline:
         assert len(self.lanes) == 1, "calibrate() starts from the single-lane pipeline"
 
         def period():
-            for i in range(4):
+            for i in range(2 * self.n_slots):          # every slot twice: the second call of a slot is the (slow) capture
                 self.submit(*batches[i % len(batches)])
             self.drain()
             torch.cuda.synchronize(self.dev)
@@ -240,9 +274,10 @@ class ShardedPipeline:
             c = make_ctx()
             st = torch.cuda.Stream(device=self.dev)
             c.set_stream(st)
+            c.set_graph_replay(self.graphs)
             lane = (self.r.local.view(c), st)
             self.lanes = [lane0, lane]
-            ms = period()
+            ms = period()                              # (period() ends in drain(): lane 0 is re-bound at the next submit)
             tried.append({"lanes": 2, "placement": p, "ms": ms})
             if ms < 0.97 * best_ms:            # a second lane has to earn its keep
                 if best_lane is not None:
@@ -259,12 +294,15 @@ class ShardedPipeline:
     def drain(self) -> None:
         import torch
         main = torch.cuda.current_stream(self.dev)
-        for _, st in self.lanes[1:]:
+        for _, st in self.lanes:
             main.wait_stream(st)
         main.wait_stream(self.side)
         self.fctx.synchronize()
-        for index, _ in self.lanes[1:]:
-            index.ctx.synchronize()                    # raises if a view's engine flagged a pool overflow
+        for index, _ in self.lanes:
+            index.ctx.synchronize()                    # raises if an engine flagged a pool overflow
+        if self.main_ctx_stream is not None:           # lane 0's context back onto the caller's stream
+            self.lanes[0][0].ctx.set_stream(self.main_ctx_stream)
+            self.main_ctx_stream = None
         self.r.check()
 
     def close(self) -> None:

@@ -1,0 +1,96 @@
+"""oi_set_graph_replay: repeated device-buffer query calls are captured into hipGraphs and replayed with one launch.  A replay
+must do exactly what the eager call does: the same lists bit for bit while the CONTENTS of the (same) buffers change from
+call to call, across a workspace reallocation in between, for the screened and the exact scorer, with and without the
+overlapped BM25 leg, and for oi_fuse_packed."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(n=120_000, dim=384, vocab=500, seed=3):
+    rng = np.random.default_rng(seed)
+    rows = rng.standard_normal((n, dim)).astype(np.float32)
+    rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    lens = rng.integers(1, 14, size=n)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    terms = rng.integers(0, vocab, size=int(offs[-1])).astype(np.uint32)
+    return rows, terms, offs
+
+
+def _batch(rng, B, dim, vocab):
+    q = rng.standard_normal((B, dim)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    nt = rng.integers(1, 6, size=B)
+    qo = np.zeros(B + 1, np.int32)
+    qo[1:] = np.cumsum(nt)
+    qt = rng.integers(0, vocab, size=int(qo[-1])).astype(np.int32)
+    return q, qt, qo
+
+
+@pytest.mark.parametrize("mode", ["screen", "exact"])
+def test_replayed_calls_equal_eager_calls_bit_for_bit(mode):
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib
+    dev = torch.device("cuda:0")
+    rows, terms, offs = _data()
+    n, dim = rows.shape
+    B, DEPTH, K = 64, 300, 40
+    d_rows = torch.from_numpy(rows).to(dev)
+
+    def make(graphs):
+        c = oi.HipContext(0)
+        c.set_stream(torch.cuda.Stream(device=dev))          # replay needs a real stream (not the default one)
+        c.set_cosine_mode(_lib.OI_COSINE_SCREEN if mode == "screen" else _lib.OI_COSINE_EXACT)
+        c.set_graph_replay(graphs)
+        ix = oi.HybridIndex(c, n, dim, 500, doc_id_base=7)
+        ix.set_embeddings(d_rows, normalize=False)
+        ix.set_forward(terms, offs)
+        ix.finalize()
+        return c, ix
+
+    cg, ig = make(True)
+    ce, ie = make(False)
+    rng = np.random.default_rng(1)
+    # the SAME device buffers every call; their contents change
+    qv = torch.zeros((B, dim), dtype=torch.float32, device=dev)
+    qt = torch.zeros(B * 6, dtype=torch.int32, device=dev)
+    qo = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    out_g = oi.SearchResult(torch.zeros((B, K), dtype=torch.float32, device=dev), torch.zeros((B, K), dtype=torch.int32, device=dev),
+                            torch.zeros(B, dtype=torch.int32, device=dev))
+    packed_g = torch.zeros(oi.packed_words(B, DEPTH), dtype=torch.int32, device=dev)
+    for it in range(9):
+        q, t, o = _batch(rng, B, dim, 500)
+        qv.copy_(torch.from_numpy(q)); qt[:t.size].copy_(torch.from_numpy(t)); qo.copy_(torch.from_numpy(o))
+        torch.cuda.synchronize()
+        if it == 3:            # another shape in between moves workspaces (bigger batch): the captured calls must notice
+            big = ig.search(torch.cat([qv, qv, qv]), torch.cat([qt, qt, qt]), torch.cat([qo, qo[1:] + qo[-1], qo[1:] + 2 * qo[-1]]),
+                            k=K, depth=DEPTH)
+            cg.synchronize()
+            assert int(big.counts.min()) > 0
+        if it == 5:
+            cg.set_overlap(False); ce.set_overlap(False)      # a mode change is part of the key
+        ig.search(qv, qt, qo, k=K, depth=DEPTH, out=out_g)
+        ig.search_lists_packed(qv, qt, qo, depth=DEPTH, out=packed_g)
+        cg.synchronize()
+        want = ie.search(qv, qt, qo, k=K, depth=DEPTH)
+        want_p = ie.search_lists_packed(qv, qt, qo, depth=DEPTH)
+        ce.synchronize()
+        assert torch.equal(out_g.docs, want.docs) and torch.equal(out_g.scores, want.scores) and torch.equal(out_g.counts, want.counts), it
+        cnt = packed_g[4 * B * DEPTH:].view(2, B)
+        assert torch.equal(cnt, want_p[4 * B * DEPTH:].view(2, B))
+        a, b = oi.unpack_lists(packed_g, B, DEPTH), oi.unpack_lists(want_p, B, DEPTH)
+        for qq in range(B):            # entries past a list's count are not defined: compare the valid prefix
+            nc, nb = int(a.cos_counts[qq]), int(a.bm25_counts[qq])
+            assert torch.equal(a.cos_docs[qq, :nc], b.cos_docs[qq, :nc]) and torch.equal(a.cos_scores[qq, :nc], b.cos_scores[qq, :nc])
+            assert torch.equal(a.bm25_docs[qq, :nb], b.bm25_docs[qq, :nb]) and torch.equal(a.bm25_scores[qq, :nb], b.bm25_scores[qq, :nb])
+        # the fusion call too: same buffers, new contents
+        fused = oi.fuse_packed(cg, packed_g, 1, B, DEPTH, K, out=out_g)
+        cg.synchronize()
+        assert torch.equal(fused.docs, want.docs) and torch.equal(fused.scores, want.scores)
+    replays, captures = cg.graph_stats()
+    assert captures >= 3 and replays >= 3, (replays, captures)
+    assert ce.graph_stats() == (0, 0)
+    ig.close(); ie.close(); cg.close(); ce.close()

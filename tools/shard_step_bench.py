@@ -82,37 +82,23 @@ class _OneRankOfS:
     """A ShardedRetriever stand-in whose 'exchange' is the S-shard buffer built above (world 1 has nothing to gather)."""
 
     def __init__(self):
-        self.local, self.device, self.world, self.group, self.dist = idx, dev, 1, None, None
+        self.local, self.device, self.world, self.group, self.dist, self.exchange = idx, dev, 1, None, None, False
 
     def check(self):
         ctx.synchronize()
 
 
 class _Pipe(sharded.ShardedPipeline):
-    def submit(self, qv_, qt_, qo_):
-        # as ShardedPipeline.submit, but the fusion reads the S-shard buffer (the timing of fuse_packed over 8 shards' lists)
-        slot = self.n % self.n_slots
-        index, lane_stream = self.lanes[self.n % len(self.lanes)]
-        main = torch.cuda.current_stream(self.dev)
-        st = main if lane_stream is None else lane_stream
-        if lane_stream is not None:
-            lane_stream.wait_stream(main)
-        if self.n >= self.n_slots:
-            st.wait_event(self.fused[slot])
-        with torch.cuda.stream(st):
-            index.search_lists_packed(qv_, qt_, qo_, depth=self.depth, out=self.packed[slot])
-            self.lists_done[slot].record(st)
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(self.lists_done[slot])
-            self._fuse_packed(self.fctx, flat, S, self.B, self.depth, self.k, out=self.results[slot])
-            self.fused[slot].record(self.side)
-        self.n += 1
-        return slot
+    """ShardedPipeline whose exchange returns the S-shard buffer built above (the timing of fuse_packed over 8 shards' lists)."""
+
+    def _exchange(self, slot):
+        return flat
 
 
 batches = [synth.query_batch_torch(B, DIM, dev, seed=synth.SEED_QUERY + 7919 * i) for i in range(4)]
 fctx = oi.HipContext(0)
 pipe = _Pipe(_OneRankOfS(), fctx, B, DEPTH, K)
+pipe.n_shards = S
 cal = pipe.calibrate(batches, lambda: oi.HipContext(0), reps=reps, placements=4)   # one lane, then four placements of a second
 print(json.dumps({"docs_per_shard": n, "shards": S, "batch": B, "lists_ms": t_lists, "lists_kernels_ms": prof,
                   "fuse_ms": t_fuse, "fuse_kernels_ms": prof_f, "step_without_exchange_ms": t_lists + t_fuse,
