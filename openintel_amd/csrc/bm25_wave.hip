@@ -33,6 +33,8 @@
 // with a dense accumulator array -- 65K cycles per task, instruction-bound on 32 fixed register slots per lane, the
 // rank sweep and a read-modify-write per posting.  DESIGN.md 4.3 has the ladders.)  HBM-bound by construction (8 B
 // per posting + 8 B per (block, term) bounds lookup); at this batch size the floor is launch and latency, not bytes.
+#include <algorithm>
+
 #include "oi_device.h"
 #include "oi_internal.h"
 
@@ -502,7 +504,8 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     uint64_t wgs = (n_tasks + BW_WAVES - 1) / BW_WAVES;
     // three resident workgroups per CU (LDS: 3 x 52 KiB).  A 128-entry table (39 KiB: four per CU) was measured and is slower,
     // 0.209 vs 0.137 ms per batch: tasks with more than 96 multi-doc postings are common and each costs a rescan of a halved window
-    const uint64_t max_wgs = 3ull * (uint64_t)ctx->num_cus;
+    uint64_t max_wgs = 3ull * (uint64_t)ctx->num_cus;
+    if (const char *e = oi_ablation_env("OI_BM25_WAVE_WGS")) max_wgs = std::max(1, atoi(e)) * (uint64_t)ctx->num_cus; // A/B: resident workgroups per CU
     if (wgs > max_wgs) wgs = max_wgs;
 #ifdef OI_ABLATION
     if (oi_ablation_env("OI_BM25_WAVE_TIMING")) { // diagnostic: per-section cycle sums (the stamps and forced waits cost time)

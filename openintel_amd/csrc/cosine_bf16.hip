@@ -71,6 +71,23 @@ __device__ __forceinline__ void cb_static_for(F &&f) {
         cb_static_for<I + 1, N>(f);
     }
 }
+// MFMA with the B operand named as AGPRs.  gfx950's matrix instructions take srcA / srcB from either half of the unified
+// register file, but the builtin lets the compiler choose: with more than 256 registers of resident queries it parks the
+// excess in AGPRs as SPILL slots and copies four registers back with v_accvgpr_read in front of every MFMA that needs them
+// (quad kernel: 304 copies in the tile loop, 8 per group of four MFMAs -- as much vector issue time as the epilogue).  Here the
+// whole query block lives in AGPRs and is read from there; the accumulators stay in VGPRs (the epilogue stores them to LDS).
+// The compiler does not see the matrix pipe's latency through an asm: a reader of `acc` other than the next cb_mfma_agpr of
+// the same accumulator must come after cb_mfma_drain().
+__device__ __forceinline__ void cb_mfma_agpr(cb_f32x16 &acc, const cb_bf16x8 &a, const cb_bf16x8 &b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void cb_mfma_agpr_first(cb_f32x16 &acc, const cb_bf16x8 &a, const cb_bf16x8 &b) { // acc = a x b
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void cb_mfma_drain() { // >= 19 wait states: the last MFMA's result is readable by any instruction
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void cb_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -456,64 +473,79 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     }
 
     // The epilogue of tile i-1 (sum of the four K quarters of this wave's query tile, filter, append) is spread over the
-    // 16 MFMA groups of tile i, one accumulator register per group: it runs in the shadow of the matrix pipe and of the
-    // DMA instead of holding both up (stand-alone it cost 65 % on top of the streaming loop).
+    // 16 MFMA groups of tile i: it runs in the shadow of the matrix pipe and of the DMA instead of holding both up
+    // (stand-alone it cost 65 % on top of the streaming loop).  Round 3 cut its LDS and issue traffic (the loop alone
+    // streams at 6.4-6.6 TB/s, the round-2 epilogue took it to 5.2):
+    //   * a wave keeps the partial of the query tile it OWNS in registers (16 copies per tile) and parks only the three
+    //     it does not own -- 48 KB per tile and workgroup instead of 64;
+    //   * parked as [writer][query tile][register block rb][lane][4 registers]: 12 ds_write_b128 per wave instead of 64
+    //     ds_write_b32, and the owner reads 12 ds_read_b128 (256 B/clk) instead of 64 ds_read_b32 (128 B/clk);
+    //   * the three foreign partials of a register block are read in groups 4 rb, 4 rb + 1, 4 rb + 2 (before the MFMAs) and
+    //     summed in group 4 rb + 3: score = ((own + p[w+1]) + p[w+2]) + p[w+3] (writers mod 4) -- a fixed order per query
+    //     tile, so a score is the same bits run to run; ONE branch per block tests max(four scores) >= tau, the per-register
+    //     test and the ragged-tile cut are behind it (survivors are rare once a threshold exists).
     uint64_t row0_prev = 0;
     bool have_prev = false;
     uint32_t rows_prev = 0; // rows of the previous tile inside the chunk (32 but for the last)
-    const float *red_mine = red + (w * 16) * 64 + lane; // [K quarter kq][register r] of MY query tile: + (kq * 64 + r) * 64
-    // the four partials of register r are read BEFORE the group's MFMAs and used after them: the LDS latency passes while
-    // the matrix pipe works (read and used back to back it was exposed in every group: +27 %)
-    auto epilogue_load = [&](auto r_, float (&e)[4]) {
-        constexpr int r = decltype(r_)::value;
+    typedef float cb_f32x4 __attribute__((ext_vector_type(4)));
+    cb_f32x4 *red4 = reinterpret_cast<cb_f32x4 *>(red); // [writer][query tile][rb][lane]
+    cb_f32x4 *park_base = red4 + (w * 16) * 64 + lane;          // + (t * 4 + rb) * 64
+    const cb_f32x4 *rd_base[3];                                 // writer (w + 1 + j) % 4, query tile w: + rb * 64
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) e[kq] = red_mine[(kq * 64 + r) * 64];
-    };
-    auto epilogue_use = [&](auto r_, const float (&e)[4]) {
-        constexpr int r = decltype(r_)::value;
-        const uint64_t row = row0_prev + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float s = ((e[0] + e[1]) + e[2]) + e[3]; // K quarters in order (every wave parks its own tile too: no branch on w)
-        if (DBG == 3) { if (s == 12345.678f) *overflow = 2u; return; } // sums only
-        // one float compare does the filter: tau_f is the threshold as a float (-inf while there is none, NaN for a padded
-        // query), false for a NaN score too; rows_prev cuts the ragged last tile
-        if ((uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * lh < rows_prev && s >= tau_f) {
-            const uint32_t pos = atomicAdd(&seg_fill[my_q], 1u); // LDS
-            if (pos < seg_cap) my_seg[(uint64_t)my_q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
-            else *overflow = 1u;
+    for (int j = 0; j < 3; ++j) rd_base[j] = red4 + ((((w + 1 + j) & 3u) * 4 + w) * 4) * 64 + lane;
+    cb_f32x16 own; // this wave's partial of its own query tile, previous tile
+    auto finish_block = [&](auto rb_, const cb_f32x4 (&p)[3]) {
+        constexpr int rb = decltype(rb_)::value;
+        float sc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i] = ((own[4 * rb + i] + p[0][i]) + p[1][i]) + p[2][i];
+        if (DBG == 3) { if (sc[0] + sc[1] + sc[2] + sc[3] == 12345.678f) *overflow = 2u; return; } // sums only
+        // tau_f is the threshold as a float (-inf while there is none, NaN for a padded query: every compare false); a NaN
+        // score drops out of the max and fails its own compare
+        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        if (mx >= tau_f) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t rr = (uint32_t)(i + 8 * rb) + 4u * lh; // row of register 4 rb + i inside the tile
+                if (rr < rows_prev && sc[i] >= tau_f) {
+                    const uint32_t pos = atomicAdd(&seg_fill[my_q], 1u); // LDS
+                    if (pos < seg_cap) my_seg[(uint64_t)my_q * pool_stride + pos] = oi_rank_key(sc[i], doc_id_base + (uint32_t)(row0_prev + rr));
+                    else *overflow = 1u;
+                }
+            }
         }
     };
 
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
         const bool has_next_tile = ti + 1 < my_nt;
         cb_f32x16 acc[NQT];
-#pragma unroll
-        for (int t = 0; t < NQT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         {
             cb_wait<4 * (P - 1)>();
             cb_bf16x8 a_cur = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + frag_off[0]);
+            cb_f32x4 pp[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             cb_static_for<0, NKC * 4>([&](auto gi_) {
                 constexpr int gi = decltype(gi_)::value;
                 constexpr int kc = gi / 4, g = gi % 4;
                 constexpr int sn = kc + P;
+                constexpr int rb = gi / 4, ej = gi % 4; // the previous tile's epilogue: register block rb, step ej
                 cb_bf16x8 a_nxt = a_cur;
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (DBG == 0 || DBG == 3) { // the previous tile's epilogue, register gi: its partials
-                    if (have_prev) epilogue_load(gi_, e);
+                if constexpr ((DBG == 0 || DBG == 3) && ej < 3) { // a foreign partial of block rb: read before the MFMAs
+                    if (have_prev) pp[ej] = rd_base[ej][rb * 64];
                 }
                 if constexpr (g < 3)
                     a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + (kc % NBUF) * CB_SLOT_BYTES + frag_off[g + 1]);
 #pragma unroll
-                for (int t = 0; t < NQT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+                for (int t = 0; t < NQT; ++t) {
+                    if constexpr (gi == 0) cb_mfma_agpr_first(acc[t], a_cur, qreg[t][gi]);
+                    else cb_mfma_agpr(acc[t], a_cur, qreg[t][gi]);
+                }
                 if constexpr (sn < NKC)
                     cb_issue_piece(cur, voff[g], sn * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024, false);
                 else
                     cb_issue_piece(nxt, voff[g], (sn - NKC) * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024,
                                    !has_next_tile);
-                if constexpr (DBG == 0 || DBG == 3) { // ... summed, filtered, appended
-                    if (have_prev) epilogue_use(gi_, e);
+                if constexpr ((DBG == 0 || DBG == 3) && ej == 3) { // ... block rb summed, filtered, appended
+                    if (have_prev) finish_block(std::integral_constant<int, rb>{}, pp);
                 }
                 if constexpr (g == 3 && kc + 1 < NKC) {
                     if (kc + P < NKC || has_next_tile) cb_wait<4 * (P - 1)>();
@@ -522,6 +554,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
                 }
                 a_cur = a_nxt;
             });
+            cb_mfma_drain(); // the accumulators are read (parked / copied) next
         }
         if (DBG == 1) {
             float x = 0.f;
@@ -533,11 +566,19 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
             continue;
         }
         __syncthreads(); // everyone has consumed the parked partials of the previous tile
-        // ---- the four quarters meet: every wave parks its four partial query tiles, [writer w][query tile t][register r][lane]
+        // ---- the four quarters meet: a wave parks the three query tiles it does not own and keeps its own
 #pragma unroll
-        for (int t = 0; t < NQT; ++t)
+        for (int t = 0; t < NQT; ++t) {
+            if ((uint32_t)t != w) { // uniform
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((w * 4 + t) * 16 + r) * 64 + lane] = acc[t][r];
+                for (int rb = 0; rb < 4; ++rb) {
+                    cb_f32x4 v = {acc[t][4 * rb], acc[t][4 * rb + 1], acc[t][4 * rb + 2], acc[t][4 * rb + 3]};
+                    park_base[(t * 4 + rb) * 64] = v;
+                }
+            } else {
+                own = acc[t];
+            }
+        }
         row0_prev = tile_row0(ti);
         rows_prev = row_end - row0_prev < 32 ? (uint32_t)(row_end - row0_prev) : 32u;
         have_prev = true;
@@ -545,11 +586,13 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
         cur = nxt;
         nxt = tile_srd(ti + 2);
     }
-    if (DBG == 0 && have_prev) // the last tile's epilogue has no MFMA loop to hide in
-        cb_static_for<0, 16>([&](auto r_) {
-            float e[4];
-            epilogue_load(r_, e);
-            epilogue_use(r_, e);
+    if ((DBG == 0 || DBG == 3) && have_prev) // the last tile's epilogue has no MFMA loop to hide in
+        cb_static_for<0, 4>([&](auto rb_) {
+            constexpr int rb = decltype(rb_)::value;
+            cb_f32x4 p[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) p[j] = rd_base[j][rb * 64];
+            finish_block(rb_, p);
         });
     __syncthreads();
     if (tid < 32 * NQT && tid < n_queries) {
