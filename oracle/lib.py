@@ -131,6 +131,7 @@ def _L() -> C.CDLL:
         lib.oio_merge_ranked.restype = C.c_uint32
         lib.oio_rrf_fuse.restype = C.c_uint32
         lib.oio_hybrid_search_batch.restype = C.c_int
+        lib.oio_hybrid_search_batch_blocked.restype = C.c_int
         lib.oio_max_threads.restype = C.c_int
         _lib = lib
     return _lib
@@ -391,9 +392,11 @@ def max_threads() -> int:
 
 
 def hybrid_search_batch(rows_normalized, term_ids, doc_offsets, vocab: int, query_vecs, query_terms, q_term_offsets,
-                        k: int, depth: int, n_threads: int = 1, df=None):
-    """A whole batch through the scalar pipeline, on n_threads host threads (parallel over queries; identical
-    results for any thread count).  Returns (scores [B,k], docs [B,k], counts [B], threads_used)."""
+                        k: int, depth: int, n_threads: int = 1, df=None, blocked: bool = False):
+    """A whole batch through the scalar pipeline, on n_threads host threads (blocked=False: parallel over queries, every
+    query streams the corpus; blocked=True: rows / docs outermost and split over the threads, every row block scored
+    against all queries while cached -- identical results either way, for any thread count).
+    Returns (scores [B,k], docs [B,k], counts [B], threads_used)."""
     rows = np.ascontiguousarray(rows_normalized, dtype=np.float32)
     t = np.ascontiguousarray(term_ids, dtype=np.uint32)
     o = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
@@ -406,7 +409,8 @@ def hybrid_search_batch(rows_normalized, term_ids, doc_offsets, vocab: int, quer
     if df is not None:
         df = np.ascontiguousarray(df, dtype=np.uint32)
     so, do, co = np.zeros((B, k), np.float32), np.zeros((B, k), np.uint32), np.zeros(B, np.uint32)
-    used = _L().oio_hybrid_search_batch(_p(rows), C.c_uint64(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(t), _p(o),
+    fn = _L().oio_hybrid_search_batch_blocked if blocked else _L().oio_hybrid_search_batch
+    used = fn(_p(rows), C.c_uint64(rows.shape[0]), C.c_uint32(rows.shape[1]), _p(t), _p(o),
                                         C.c_uint32(vocab), _p(df) if df is not None else None, _p(qv), _p(qt), _p(qo),
                                         C.c_uint32(B), C.c_uint32(depth), C.c_uint32(k), C.c_int(n_threads), _p(so),
                                         _p(do), _p(co))

