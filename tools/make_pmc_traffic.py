@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json (what bench.py's roofline.traffic reads) from two tools/pmc_profile.sh summaries:
+    python tools/make_pmc_traffic.py <default-mode pmc_summary.json> <--cosine exact pmc_summary.json> <tag>
+The default-mode run supplies the screen kernel and the BM25 kernel, the exact-mode run the f32 MFMA kernel (in a
+default-mode run that kernel also has one gated launch per batch that exits at once and would dilute the averages)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = json.load(open(sys.argv[1]))
+x = json.load(open(sys.argv[2]))
+tag = sys.argv[3]
+ALG = 10_000_000 * 768 * 4
+sc = d["cosine_screen"]
+out = {
+    "source": "profiles/%s_pmc_summary.json (tools/pmc_profile.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes over "
+              "bench.py --steps 3 --warmup 1, default scorer; round 3)" % tag,
+    "correction": "HBM read bytes = FETCH_SIZE*1024*2 (gfx950 tallies 128-B requests at 64 B on wide coalesced streams, "
+                  "MI355X_MICROARCH.md section HBM); write bytes = WRITE_SIZE*1024",
+    "kernel": "cosine_screen_filter<768,2>",
+    "cosine_launches": sc["launches"],
+    "cosine_hbm_bytes_per_launch": (sc["hbm_read_bytes"] + sc.get("hbm_write_bytes", 0.0)) / sc["launches"],
+    "cosine_hbm_read_bytes_per_step": sc["hbm_read_bytes"] / sc["launches"] * 4,
+    "cosine_algorithmic_bytes_per_step": ALG,
+    "cosine_eff_clock_GHz": sc.get("eff_clock_GHz"),
+    "cosine_lds_bank_conflict_cycles_frac": sc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, sc.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+}
+bw = d.get("bm25_wave")
+if bw:
+    out["bm25_wave_kernel"] = {
+        "launches": bw["launches"], "hbm_read_bytes_per_launch": bw["hbm_read_bytes"] / bw["launches"],
+        "hbm_write_bytes_per_launch": bw.get("hbm_write_bytes", 0.0) / bw["launches"],
+        "lds_bank_conflict_cycles_frac": bw.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, bw.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+        "waves_waiting_frac": bw.get("SQ_WAIT_ANY", 0.0) / max(1.0, bw.get("SQ_WAVE_CYCLES", 1.0)),
+        "note": "narrow (8-B per lane) loads: the FETCH_SIZE x2 correction is calibrated for 16-B-per-lane streams only; read as an upper bound"}
+ex = x["cosine_ksplit"]
+out["exact_kernel"] = {
+    "kernel": "cosine_ksplit16_filter<768,2>",
+    "cosine_launches": ex["launches"],
+    "cosine_hbm_bytes_per_launch": (ex["hbm_read_bytes"] + ex.get("hbm_write_bytes", 0.0)) / ex["launches"],
+    "cosine_hbm_read_bytes_per_step": ex["hbm_read_bytes"] / ex["launches"] * 4,
+    "cosine_algorithmic_bytes_per_step": ALG,
+    "cosine_mfma_busy_frac_at_delivered_clock": ex.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, ex.get("GRBM_GUI_ACTIVE", 1.0) / 8 * 1024),
+    "cosine_mfma_busy_over_sq_busy": ex.get("mfma_busy_over_sq_busy"),
+    "cosine_eff_clock_GHz": ex.get("eff_clock_GHz"),
+    "cosine_lds_bank_conflict_cycles_frac": ex.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, ex.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+}
+out["exact_kernel_source"] = ("profiles/%s_exact_pmc_summary.json (the same passes over bench.py --cosine exact --steps 3 --warmup 1; "
+                              "round 3, the kernel with non-temporal loads)" % tag)
+json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -8,7 +8,11 @@ R=$GRAFT_REPO_ROOT
 T=${1:-prof}
 OUT=$R/gpurun_out/$T
 mkdir -p $OUT
+# SKIP_PMC=1: everything but the counter passes; PMC_ONLY=1: only those (two gpurun calls fit the per-call limit)
+if [ -z "$PMC_ONLY" ]; then
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err && echo "bench ok"
+OI_BENCH_FORCE_DIST=1 python3 $R/bench.py --gpus 1 --docs 1250000 --steps 200 --warmup 20 --no-cpu-baseline --no-screen-copy > $OUT/rccl_world1_shard.json 2> $OUT/rccl_world1.err && echo "rccl world1 ok"
+OI_BENCH_BACKEND=gloo OI_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --docs 2500000 --steps 100 --warmup 10 --no-cpu-baseline --no-screen-copy > $OUT/launcher_gloo2.json 2> $OUT/launcher_gloo2.err && echo "gloo2 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
 python3 $R/bench.py --cosine exact --steps 10 --no-cpu-baseline > $OUT/bench_exact.json 2> $OUT/bench_exact.err && echo "exact ok"
 python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
@@ -22,4 +26,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bm25 -- python3 $R/tools/bm25_bench.py 10000000 3 > /dev/null 2> $OUT/stats_bm25.err && echo "stats bm25 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lexicon -- python3 $R/tools/lexicon_bench.py 10000000 5 > /dev/null 2> $OUT/stats_lexicon.err && echo "stats lexicon ok"
 python3 $R/tools/shard_step_bench.py 1250000 50 > $OUT/shard_step.json 2> $OUT/shard_step.err && echo "shard ok"
+fi
+if [ -z "$SKIP_PMC" ]; then
 bash $R/tools/pmc_profile.sh $T/pmc > $OUT/pmc.log 2>&1 && echo "pmc ok"
+bash $R/tools/pmc_profile.sh $T/pmc_exact --cosine exact > $OUT/pmc_exact.log 2>&1 && echo "pmc exact ok"
+fi
