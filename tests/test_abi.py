@@ -66,3 +66,23 @@ def test_product_build_has_no_ablation_switches():
                  b"OI_BM25_WAVE_DBG", b"OI_BM25_WAVE_TIMING"):
         assert name not in blob, name
     assert b"OI_COSINE_MODE" in blob and b"OI_BM25_MODE" in blob   # the two documented mode selectors stay
+
+
+def test_null_handles_are_refused_without_touching_a_device():
+    """Argument checks come before any HIP or RCCL call: a null handle is OI_ERR_INVALID_ARG with a message, on a box with no
+    GPU too (round 3's new entry points included)."""
+    import ctypes as C
+    from openintel_amd import _lib
+    lib = _lib.load()
+    INVALID = _lib.OI_ERR_INVALID_ARG
+    none = C.c_void_p(None)
+    out = C.c_void_p()
+    assert lib.oi_set_graph_replay(none, 1) == INVALID and lib.oi_last_error()
+    assert lib.oi_comm_unique_id(none) == INVALID
+    assert lib.oi_comm_create(none, none, 0, 1, C.byref(out)) == INVALID and not out.value
+    assert lib.oi_index_finalize_sharded(none, none) == INVALID
+    assert lib.oi_search_sharded(none, none, none, none, none, 1, 1, 1, _lib.OI_HOST, none, none, none) == INVALID
+    lib.oi_comm_destroy(none)       # destroying nothing is a no-op, as for oi_destroy / oi_index_destroy
+    lib.oi_destroy(none)
+    lib.oi_index_destroy(none)
+    assert lib.oi_set_stream(none, none) == INVALID and lib.oi_synchronize(none) == INVALID
