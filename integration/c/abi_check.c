@@ -1,0 +1,88 @@
+/* abi_check.c -- a plain-C host of libopenintel_hip.so (C99, no C++ runtime of its own): what the reference's FFI sees.
+ *
+ *   gcc -std=c99 -Wall -Wextra -pedantic -I include integration/c/abi_check.c -L openintel_amd -lopenintel_hip \
+ *       -Wl,-rpath,$PWD/openintel_amd -lm -o /tmp/abi_check && /tmp/abi_check
+ *
+ * Without a GPU it checks that the header is valid C, that the library links and that a missing device is a loud
+ * OI_ERR_NO_DEVICE (there is no CPU path).  With a gfx950 device it scores three posts through the PostAnalyzer entry
+ * point (post_analyzer.rs:7-11 / lexicon.rs:106-120's sentences) and runs one hybrid query of a 1000-post index
+ * (BASELINE configs[0]'s shape: 384-d, top-10). */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "openintel_hip.h"
+
+static int fail(const char *what, int rc) {
+    fprintf(stderr, "abi_check: %s failed: %d (%s)\n", what, rc, oi_last_error());
+    return 1;
+}
+
+int main(void) {
+    oi_ctx *ctx = NULL;
+    int rc;
+    if (oi_abi_version() != OI_ABI_VERSION) return fail("oi_abi_version", oi_abi_version());
+    rc = oi_create(0, &ctx);
+    if (rc == OI_ERR_NO_DEVICE) {
+        if (ctx != NULL || oi_last_error()[0] == '\0') return fail("no-device contract", rc);
+        printf("abi_check: no gfx950 device (%s) -- link and header ok\n", oi_last_error());
+        return 0;
+    }
+    if (rc != OI_OK) return fail("oi_create", rc);
+
+    { /* PostAnalyzer::analyze */
+        const char *posts[3] = {"AAPL to the moon, loading calls all day", "AAPL is going to dump, buying puts", "AAPL earnings are next week"};
+        unsigned char blob[256];
+        uint64_t offs[4] = {0, 0, 0, 0};
+        double pol[3];
+        uint8_t spec[3];
+        int i;
+        for (i = 0; i < 3; ++i) {
+            memcpy(blob + offs[i], posts[i], strlen(posts[i]));
+            offs[i + 1] = offs[i] + strlen(posts[i]);
+        }
+        rc = oi_lexicon_analyze(ctx, blob, offs, 3, pol, spec);
+        if (rc != OI_OK) return fail("oi_lexicon_analyze", rc);
+        if (!(pol[0] > 0.0 && spec[0] == 1 && pol[1] < 0.0 && spec[1] == 1 && pol[2] == 0.0 && spec[2] == 0)) {
+            fprintf(stderr, "abi_check: lexicon signals differ from lexicon.rs:109-119: %g/%d %g/%d %g/%d\n", pol[0], spec[0], pol[1], spec[1], pol[2], spec[2]);
+            return 1;
+        }
+    }
+    { /* the hybrid query: doc 123 holds the query's vector and its terms, so it must come first */
+        enum { N = 1000, D = 384, V = 64, K = 10 };
+        float *rows = (float *)calloc((size_t)N * D, sizeof(float)), *q = (float *)calloc(D, sizeof(float));
+        uint32_t *terms = (uint32_t *)malloc(sizeof(uint32_t) * N * 3);
+        uint64_t *offs = (uint64_t *)malloc(sizeof(uint64_t) * (N + 1));
+        uint32_t qt[2] = {7, 9}, qo[2] = {0, 2}, docs[K], counts[1];
+        float scores[K];
+        oi_index *idx = NULL;
+        uint64_t tokens = 0;
+        uint32_t i, k, seed = 12345u;
+        for (i = 0; i < N; ++i) {
+            for (k = 0; k < D; ++k) { seed = seed * 1664525u + 1013904223u; rows[(size_t)i * D + k] = (float)((seed >> 9) & 0xFFFF) / 65536.0f - 0.5f; }
+            offs[i] = 3ull * i;
+            terms[3 * i] = i % V; terms[3 * i + 1] = (i * 7u) % V; terms[3 * i + 2] = (i * 13u) % V;
+        }
+        offs[N] = 3ull * N;
+        terms[3 * 123] = 7; terms[3 * 123 + 1] = 9; terms[3 * 123 + 2] = 7;
+        memcpy(q, rows + (size_t)123 * D, sizeof(float) * D);
+        { double ss = 0.0; for (k = 0; k < D; ++k) ss += (double)q[k] * q[k]; for (k = 0; k < D; ++k) q[k] = (float)(q[k] / (ss > 0 ? sqrt(ss) : 1.0)); }
+        if ((rc = oi_index_create(ctx, N, D, V, 0, &idx)) != OI_OK) return fail("oi_index_create", rc);
+        if ((rc = oi_index_set_embeddings(idx, rows, OI_HOST, 1)) != OI_OK) return fail("oi_index_set_embeddings", rc);
+        if ((rc = oi_index_set_forward(idx, terms, offs, OI_HOST)) != OI_OK) return fail("oi_index_set_forward", rc);
+        if ((rc = oi_index_local_stats(idx, &tokens, NULL)) != OI_OK) return fail("oi_index_local_stats", rc);
+        if ((rc = oi_index_finalize(idx, N, tokens, NULL)) != OI_OK) return fail("oi_index_finalize", rc);
+        if ((rc = oi_search(idx, q, qt, qo, 1, 100, K, OI_HOST, scores, docs, counts)) != OI_OK) return fail("oi_search", rc);
+        if (counts[0] != K || docs[0] != 123) {
+            fprintf(stderr, "abi_check: hybrid query returned %u docs, first %u (expected 10, 123)\n", counts[0], docs[0]);
+            return 1;
+        }
+        oi_destroy(ctx); /* any destruction order is fine: the ctx first ... */
+        ctx = NULL;
+        oi_index_destroy(idx); /* ... the index after it */
+        free(rows); free(q); free(terms); free(offs);
+    }
+    printf("abi_check: ok\n");
+    return 0;
+}
