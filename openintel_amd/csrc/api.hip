@@ -120,6 +120,7 @@ extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *tota
 // ---------------------------------------------------------------- captured launch sequences (hipGraph replay)
 #define OI_MAX_GRAPHS 32
 
+// (callers make sure no launch of the graph is still in flight: every path that frees one synchronises the ctx stream first)
 static void graph_free(GraphEntry &e) {
     if (e.exec) (void)hipGraphExecDestroy(e.exec);
     if (e.graph) (void)hipGraphDestroy(e.graph);
@@ -150,6 +151,7 @@ template <class F> static int run_captured(oi_ctx *ctx, const uint64_t (&key)[10
             size_t lru = 0;
             for (size_t i = 1; i < ctx->graphs.size(); ++i)
                 if (ctx->graphs[i].last_use < ctx->graphs[lru].last_use) lru = i;
+            OI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // rare (more than OI_MAX_GRAPHS distinct calls): its last replay may still run
             graph_free(ctx->graphs[lru]);
             ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
         }
@@ -163,6 +165,7 @@ template <class F> static int run_captured(oi_ctx *ctx, const uint64_t (&key)[10
     }
     e->last_use = ++ctx->graph_clock;
     if (e->epoch != epoch) { // a workspace moved since: start over (eager now, capture next time)
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         graph_free(*e);
         e->state = 0;
         const int rc = body();
@@ -212,6 +215,7 @@ extern "C" int oi_set_graph_replay(oi_ctx *ctx, int enable) {
     ctx->use_graphs = enable != 0;
     if (!ctx->use_graphs) {
         OI_HIP_CHECK(hipSetDevice(ctx->device));
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); // no replay in flight when its graph goes
         graphs_purge(ctx, 0);
     }
     return OI_OK;
