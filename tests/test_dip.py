@@ -170,6 +170,32 @@ def test_touching_titles_and_large_tiles_gpu(scanner):
 
 
 @pytest_gpu
+def test_heavy_tailed_lengths_at_the_window_limit_gpu(scanner):
+    """The tile is chosen from the AVERAGE title length (256 titles while they fill <= 7/8 of the 24 KB window): with a
+    heavy-tailed length distribution some tiles fit the window, some overflow it and are redone one lane per title.
+    Both kinds, next to each other, must equal the oracle; so must an average just under and just over each tile step."""
+    rng = np.random.default_rng(77)
+    base = synth.headlines_np(60_000, seed=26)
+    titles, i = [], 0
+    while i < len(base) - 64:
+        k = 1 if rng.random() < 0.99 else int(rng.integers(8, 40))   # 1 % of the titles are 8..40 headlines long
+        titles.append(" ".join(base[i:i + k]))
+        i += k
+    lens = np.array([len(t.encode()) for t in titles])
+    win = 24 * 1024
+    avg = int(lens.sum()) // len(lens) + 1
+    tile = next(t for t in (256, 224, 192, 160, 128, 96, 64, 48, 32, 16, 8) if avg * t <= win * 7 // 8)   # headline.hip
+    assert tile >= 192
+    sums = np.add.reduceat(lens, np.arange(0, len(lens), tile))
+    assert (sums > win).any() and (sums < win).any(), "both the windowed and the overflow path must be exercised"
+    _check_scan(scanner, titles, synth.HEADLINE_TICKER, ["ultra clean"])
+    # averages either side of the 7/8 rule for tiles of 256 and 224 titles (84 and 96 bytes)
+    for avg in (83, 85, 95, 97):
+        fixed = [(t + " " + t + " " + t)[:avg].ljust(avg, ".") for t in base[:3000]]
+        _check_scan(scanner, fixed, synth.HEADLINE_TICKER, ["ultra clean"])
+
+
+@pytest_gpu
 def test_device_buffers_and_limits_gpu(scanner):
     import torch
     from oracle import lib
