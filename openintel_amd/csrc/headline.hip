@@ -40,7 +40,7 @@
 #define HL_CHUNKS (HL_WIN_BYTES / 16)
 #define HL_PER_LANE (HL_CHUNKS / HL_THREADS) // 16-byte chunks a lane stages and scans
 #define HL_NODES 384u              // keyword hits per tile before the tile is redone lane-per-title
-#define HL_RING 128u               // candidate ring per wave (power of two; at most 127 wait at once)
+#define HL_RING 64u                // candidate ring per wave and kind (keyword / pattern): one batch of the wave
 #define HL_MAX_PAT_BYTES 1024
 #define HL_MAX_PATTERNS 32
 #define HL_MAX_WORDS 64            // packed pattern words; patterns beyond take the byte walker
@@ -203,7 +203,7 @@ struct HlShared {
     uint32_t res[HL_MAX_TILE];             // bits 0..15 keyword mask, bit 16 about-company, bits 17.. head node + 1
     uint32_t node[HL_NODES];               // keyword (4 bits) | pos << 4 | (next node + 1) << 19
     uint32_t ctab[256];                    // by first byte of a token: hot.first_char of its class, 0 if not alnum
-    uint32_t ring[HL_WAVES][HL_RING];      // candidates: pos | length class << 16
+    uint32_t ring[HL_WAVES][2][HL_RING];   // candidates, [0] keyword [1] pattern: pos | length class << 16
     uint8_t tchunk[HL_CHUNKS];             // title owning the first byte of each chunk (0 before the first title)
     uint32_t n_nodes;
 };
@@ -263,52 +263,84 @@ __device__ static bool hl_match_rest(const HlShared &s, uint32_t p, uint32_t q, 
     return true;
 }
 
-// dbg (ablation builds): 3 = token packing only, 4 = no keyword bookkeeping (node lists), 5 = no company patterns
-__device__ static void hl_verify(HlShared &s, const HlParams *prm, uint32_t nt, uint32_t e, int dbg = 0) {
+// A candidate is verified by kind, a batch of one kind at a time: a wave runs ONE of the two paths per batch instead
+// of both in turn for a mixed batch.  dbg (ablation builds): 3 = token packing only, 4 = no keyword bookkeeping
+// (node lists), 5 = no company patterns.
+//
+// Keyword candidate: the token's (first char, exact length 3..13) begins a keyword.
+__device__ static void hl_verify_keyword(HlShared &s, uint32_t nt, uint32_t e, int dbg = 0) {
+    const uint32_t pos = e & 0xFFFFu, lc = e >> 16;
+    uint64_t lo, hi;
+    hl_pack_token(s, pos, lc, lo, hi);
+    if (dbg == 3) { if ((lo ^ hi) == 0xDEADBEEFull) s.n_nodes = 0; return; }
+    if (dbg == 4) return;
+    const uint32_t sl = hl_kw_slot(lo, s.hot.kw_mult);
+    if (s.hot.kw_lo[sl] == lo && s.hot.kw_hi[sl] == hi) {
+        const uint32_t k = s.hot.kw_id[sl];
+        const uint32_t j = hl_title_of(s, nt, pos);
+        const uint32_t idx = atomicAdd(&s.n_nodes, 1u);
+        if (idx < HL_NODES) { // push onto title j's list; past the cap the tile is redone (n_nodes tells)
+            uint32_t old = s.res[j], assumed;
+            do {
+                assumed = old;
+                s.node[idx] = k | (pos << 4) | ((assumed >> 17) << 19);
+                old = atomicCAS(&s.res[j], assumed, (assumed & 0x1FFFFu) | (1u << k) | ((idx + 1u) << 17));
+            } while (old != assumed);
+        }
+    }
+}
+
+// Pattern candidate: the token's (first char, length class) is that of a company pattern's first word.  Words by
+// packed compare, long words by the byte walker.
+__device__ static void hl_verify_pattern(HlShared &s, const HlParams *prm, uint32_t nt, uint32_t e, int dbg = 0) {
     const uint32_t pos = e & 0xFFFFu, lc = e >> 16;
     uint64_t lo, hi;
     hl_pack_token(s, pos, lc, lo, hi); // exact for lc < HL_LONG; longer tokens are never compared packed
-    const uint32_t fc = s.ctab[(uint32_t)lo & 0xFFu]; // lowercased first byte: same class
-    uint32_t j = ~0u;
     if (dbg == 3) { if ((lo ^ hi) == 0xDEADBEEFull) s.n_nodes = 0; return; }
-    if (((fc >> lc) & 1u) && dbg != 4) { // keyword: lc is the exact length, 3..13
-        const uint32_t sl = hl_kw_slot(lo, s.hot.kw_mult);
-        if (s.hot.kw_lo[sl] == lo && s.hot.kw_hi[sl] == hi) {
-            const uint32_t k = s.hot.kw_id[sl];
-            j = hl_title_of(s, nt, pos);
-            const uint32_t idx = atomicAdd(&s.n_nodes, 1u);
-            if (idx < HL_NODES) { // push onto title j's list; past the cap the tile is redone (n_nodes tells)
-                uint32_t old = s.res[j], assumed;
-                do {
-                    assumed = old;
-                    s.node[idx] = k | (pos << 4) | ((assumed >> 17) << 19);
-                    old = atomicCAS(&s.res[j], assumed, (assumed & 0x1FFFFu) | (1u << k) | ((idx + 1u) << 17));
-                } while (old != assumed);
-            }
+    if (dbg == 5) return;
+    uint32_t j = ~0u;
+    const uint32_t np = s.hot.n_patterns;
+    for (uint32_t p = 0; p < np; ++p) {
+        if (s.hot.pat_first_len[p] != lc) continue;
+        const uint32_t w0 = s.hot.pat_w0[p];
+        if (lc < HL_LONG && (s.hot.wd_lo[w0] != lo || s.hot.wd_hi[w0] != hi)) continue;
+        if (j == ~0u) j = hl_title_of(s, nt, pos);
+        if ((s.res[j] >> 16) & 1u) break;
+        bool hit;
+        if (s.hot.pat_bytewise[p]) {
+            HlLdsReader rd{s.text};
+            const uint32_t o = prm->pat_off[p];
+            hit = hl_match_at(rd, pos, s.off[j + 1], prm->pat + o, prm->pat_off[p + 1] - o);
+        } else {
+            hit = hl_match_rest(s, p, pos + lc, s.off[j + 1]);
+        }
+        if (hit) {
+            atomicOr(&s.res[j], 1u << 16);
+            break;
         }
     }
-    if (((fc >> (16u + lc)) & 1u) && dbg != 5) { // company pattern: words by packed compare, long words by the byte walker
-        const uint32_t np = s.hot.n_patterns;
-        for (uint32_t p = 0; p < np; ++p) {
-            if (s.hot.pat_first_len[p] != lc) continue;
-            const uint32_t w0 = s.hot.pat_w0[p];
-            if (lc < HL_LONG && (s.hot.wd_lo[w0] != lo || s.hot.wd_hi[w0] != hi)) continue;
-            if (j == ~0u) j = hl_title_of(s, nt, pos);
-            if ((s.res[j] >> 16) & 1u) break;
-            bool hit;
-            if (s.hot.pat_bytewise[p]) {
-                HlLdsReader rd{s.text};
-                const uint32_t o = prm->pat_off[p];
-                hit = hl_match_at(rd, pos, s.off[j + 1], prm->pat + o, prm->pat_off[p + 1] - o);
-            } else {
-                hit = hl_match_rest(s, p, pos + lc, s.off[j + 1]);
-            }
-            if (hit) {
-                atomicOr(&s.res[j], 1u << 16);
-                break;
-            }
+}
+
+// Append this round's candidates of one kind (lanes with `has`) to the wave's ring of that kind; when they do not
+// fit beside the ones waiting, the waiting ones (a nearly full batch) are verified first.  Wave-uniform cursors.
+template <int KIND>
+__device__ __forceinline__ void hl_ring_push(HlShared &s, const HlParams *prm, uint32_t nt, uint32_t wv, uint32_t lane,
+                                             bool has, uint32_t e, uint32_t &head, uint32_t &tail, int dbg) {
+    const uint64_t m = __ballot(has);
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    if (tail - head + cnt > HL_RING) { // a wave's LDS operations complete in order: the reads precede the writes below
+        if (lane < tail - head && dbg != 2) {
+            const uint32_t w = s.ring[wv][KIND][(head + lane) & (HL_RING - 1u)];
+            if (KIND == 0) hl_verify_keyword(s, nt, w, dbg);
+            else hl_verify_pattern(s, prm, nt, w, dbg);
         }
+        head = tail;
     }
+    if (has) {
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        s.ring[wv][KIND][(tail + below) & (HL_RING - 1u)] = e;
+    }
+    tail += cnt;
 }
 
 // The piece the blob ends in, zero-filled past the end.
@@ -415,15 +447,16 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
     __syncthreads();
     if (TM) tk[2] = clock64();
 
-    // ---- token pass over the lane's chunks.  The loop is wave-uniform: candidates are compacted with
-    // ballots into this wave's ring (no atomics), and whenever 64 are waiting a full wave verifies them.
-    uint32_t head = 0, tail = 0; // wave-uniform ring cursors
+    // ---- token pass over the lane's chunks.  Per chunk a lane first walks its tokens on its own (no ballots) and
+    // marks the candidates in a bitmap -- bit b: the token starting at byte b may be a keyword, bit 16 + b: it may
+    // begin a company pattern -- then the wave compacts the marked ones with ballots into its two rings, by kind.
+    uint32_t kh = 0, kt = 0, ph = 0, pt = 0; // wave-uniform ring cursors: keyword ring, pattern ring
     const uint32_t min_len = s.hot.min_len;
     if (dbg != 1) {
         for (uint32_t k = 0; k < HL_PER_LANE; ++k) {
             if (wv * 64u + k * HL_THREADS >= n16) break; // uniform: the wave has no chunk left
             const uint32_t c = tid + k * HL_THREADS, c0 = c << 4;
-            uint32_t starts = 0, Z = 0;
+            uint32_t starts = 0, Z = 0x80000000u; // bit 31 keeps every ctz below defined
             if (c < n16) {
                 const uint32_t A = hl_am32(s, c);
                 const uint32_t prev = (s.am[c] >> 15) & 1u;
@@ -438,36 +471,35 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
                 if (min_len >= 3u) starts &= ~(Z >> 2);
             }
             const uint8_t *tbytes = reinterpret_cast<const uint8_t *>(s.text) + c0;
-            while (__ballot(starts != 0)) {
-                bool cand = false;
-                uint32_t e = 0;
-                if (starts) {
-                    const uint32_t b = __builtin_ctz(starts);
-                    starts &= starts - 1;
-                    const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // exact below HL_LONG (b + 14 <= 31)
-                    const uint32_t lc = len < HL_LONG ? len : HL_LONG;
-                    const uint32_t fc = s.ctab[tbytes[b]];
-                    cand = ((fc >> lc) & 0x10001u) != 0; // (first char, length) begins a keyword or a pattern
-                    e = (c0 + b) | (lc << 16);
-                }
-                const uint64_t m = __ballot(cand);
-                if (cand) {
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s.ring[wv][(tail + below) & (HL_RING - 1u)] = e;
-                }
-                tail += (uint32_t)__popcll(m);
-                if (tail - head >= 64u && dbg != 2) { // a wave's LDS operations complete in order
-                    hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)], dbg);
-                    head += 64u;
-                }
+            uint32_t cm = 0;
+            while (starts) {
+                const uint32_t b = __builtin_ctz(starts);
+                starts &= starts - 1;
+                const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // exact below HL_LONG (b + 14 <= 31)
+                const uint32_t lc = len < HL_LONG ? len : HL_LONG;
+                const uint32_t fc = s.ctab[tbytes[b]];
+                cm |= ((fc >> lc) & 0x10001u) << b; // (first char, length) begins a keyword / a pattern
+            }
+            uint32_t kb = cm & 0xFFFFu, pb = cm >> 16;
+            while (__ballot(kb != 0)) {
+                const bool has = kb != 0;
+                const uint32_t b = has ? (uint32_t)__builtin_ctz(kb) : 0u;
+                kb &= kb - 1u;
+                const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u; // a keyword candidate's length is exact (3..13)
+                hl_ring_push<0>(s, params, nt, wv, lane, has, (c0 + b) | (len << 16), kh, kt, dbg);
+            }
+            while (__ballot(pb != 0)) {
+                const bool has = pb != 0;
+                const uint32_t b = has ? (uint32_t)__builtin_ctz(pb) : 0u;
+                pb &= pb - 1u;
+                const uint32_t len = __builtin_ctz(Z >> (b + 1u)) + 1u;
+                hl_ring_push<1>(s, params, nt, wv, lane, has, (c0 + b) | ((len < HL_LONG ? len : HL_LONG) << 16), ph, pt, dbg);
             }
         }
         if (TM) tk[3] = clock64();
-        if (dbg != 2) {
-            while (head < tail) {
-                if (head + lane < tail) hl_verify(s, params, nt, s.ring[wv][(head + lane) & (HL_RING - 1u)], dbg);
-                head += 64u;
-            }
+        if (dbg != 2) { // what still waits: one batch per kind
+            if (lane < kt - kh) hl_verify_keyword(s, nt, s.ring[wv][0][(kh + lane) & (HL_RING - 1u)], dbg);
+            if (lane < pt - ph) hl_verify_pattern(s, params, nt, s.ring[wv][1][(ph + lane) & (HL_RING - 1u)], dbg);
         }
     } else {
         if (TM) tk[3] = clock64();
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(HL_THREADS, 4) void headline_scan_kernel(const uint
         atomicAdd(&timing[4], tk[5] - tk[4]); // wait at the barrier
         atomicAdd(&timing[5], t6 - tk[5]);    // results
         atomicAdd(&timing[6], 1ull);
-        atomicAdd(&timing[7], (unsigned long long)tail);
+        atomicAdd(&timing[7], (unsigned long long)(kt + pt));
     }
 }
 
