@@ -20,16 +20,18 @@
 // carried as a flag.
 //
 // Kernel (headline_scan_kernel): a workgroup takes `tile` consecutive titles (chosen on the host
-// from the average title length so that a tile's bytes fit the 24 KB LDS window), stages their
-// bytes with coalesced 16-byte loads and turns every 16-byte chunk into 16 "alnum" bits on the
-// way.  The token pass then works on bitmaps: token starts, lengths and the cut at title
-// boundaries are a few bit operations per chunk; a token becomes a candidate only if its (first
-// char, length) can begin a keyword or a company pattern (one LDS table lookup).  Candidates are
-// compacted with wave ballots into a per-wave ring and verified 64 at a time: packed 16-byte
-// compares against a perfect hash (keywords) and the packed words of the patterns.  Hits are rare;
-// each becomes a node in a per-title list, folded at the end into the keyword mask and the
-// first-occurrence order the reference's Vec has.  Tiles that do not fit the window, or that hold
-// more hits than nodes, are done one lane per title (hl_scan_title), which is also kernel v1.
+// from the average title length so that a tile's bytes fill at most 7/8 of the 24 KB LDS window),
+// stages their bytes with coalesced 16-byte loads and turns every 16-byte chunk into 16 "alnum"
+// bits on the way.  The token pass then works on bitmaps: token starts, lengths and the cut at title
+// boundaries are a few bit operations per chunk; a lane walks its chunk's tokens on its own and
+// marks a token as a candidate only if its (first char, length) can begin a keyword or a company
+// pattern (one LDS table lookup).  The marked tokens are compacted with wave ballots into two
+// per-wave rings, by kind, and verified a batch of ONE kind at a time (a mixed batch would run both
+// paths in turn): packed 16-byte compares against a perfect hash (keywords) or the packed words of
+// the patterns.  Hits are rare; each keyword hit becomes a node in a per-title list, folded at the
+// end into the keyword mask and the first-occurrence order the reference's Vec has.  Tiles that do
+// not fit the window, or that hold more hits than nodes, are done one lane per title
+// (hl_scan_title), which is also kernel v1.
 #include "oi_device.h"
 #include "oi_internal.h"
 
