@@ -66,11 +66,14 @@ struct __attribute__((aligned(16))) HlHot {
     uint32_t first_char[40];
     uint8_t kw_id[HL_KW_SLOTS];
     uint8_t wd_len[HL_MAX_WORDS];           // 1..13
-    uint8_t pat_w0[HL_MAX_PATTERNS + 1];    // words of pattern p: wd[pat_w0[p] .. pat_w0[p + 1])
+    uint8_t pat_w0[HL_MAX_PATTERNS + 4];    // words of pattern p: wd[pat_w0[p] .. pat_w0[p + 1]) (33 used; dword-sized)
     uint8_t pat_bytewise[HL_MAX_PATTERNS];  // 1: has a long word (or the word table was full): byte walker
     uint8_t pat_first_len[HL_MAX_PATTERNS]; // length class of the first word
-    uint8_t pad1[15];
+    uint8_t pad1[12];
 };
+static_assert(offsetof(HlHot, wd_len) % 4 == 0 && offsetof(HlHot, pat_w0) % 4 == 0 && offsetof(HlHot, pat_bytewise) % 4 == 0 &&
+                  offsetof(HlHot, pat_first_len) % 4 == 0,
+              "hl_u8 reads the byte tables as dwords");
 struct HlParams {
     HlHot hot;
     uint16_t pat_off[HL_MAX_PATTERNS + 2];
@@ -235,15 +238,22 @@ __device__ static inline void hl_pack_token(const HlShared &s, uint32_t pos, uin
     else if (len < 16) hi &= (1ull << (8u * (len - 8u))) - 1ull;
 }
 
+// Entry i of a dword-aligned byte table of the call's tables in HBM.  With a wave-uniform i this is a scalar load and
+// two scalar operations: the pattern tables are walked by pattern and word number, the same for every lane, so reading
+// them through the scalar cache instead of LDS takes them off the vector and LDS pipes.
+__device__ __forceinline__ uint32_t hl_u8(const uint8_t *table, uint32_t i) {
+    return (reinterpret_cast<const uint32_t *>(table)[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
+}
+
 // 32 alnum bits starting at chunk c's first byte (bit i = byte 16c + i)
 __device__ static inline uint32_t hl_am32(const HlShared &s, uint32_t c) {
     return (uint32_t)s.am[1 + c] | ((uint32_t)s.am[2 + c] << 16);
 }
 
 // Words 1.. of pattern p against the title's tokens after the one ending at `q`; `end` = title end.
-__device__ static bool hl_match_rest(const HlShared &s, uint32_t p, uint32_t q, uint32_t end) {
-    const uint32_t w1 = s.hot.pat_w0[p + 1];
-    for (uint32_t w = s.hot.pat_w0[p] + 1u; w < w1; ++w) {
+__device__ static bool hl_match_rest(const HlShared &s, const HlHot &gh, uint32_t p, uint32_t q, uint32_t end) {
+    const uint32_t w1 = hl_u8(gh.pat_w0, p + 1u);
+    for (uint32_t w = hl_u8(gh.pat_w0, p) + 1u; w < w1; ++w) {
         // next token start: first alnum byte at or after q, before the title's end
         uint32_t st = q;
         for (;;) {
@@ -256,10 +266,10 @@ __device__ static bool hl_match_rest(const HlShared &s, uint32_t p, uint32_t q, 
         const uint32_t y = ~(hl_am32(s, st >> 4) >> (st & 15u)) | (1u << 16); // run length, capped at 16
         uint32_t len = __builtin_ctz(y);
         if (len > end - st) len = end - st;
-        if (len != s.hot.wd_len[w]) return false; // wd_len < HL_LONG <= 16: the comparison is exact
+        if (len != hl_u8(gh.wd_len, w)) return false; // wd_len < HL_LONG <= 16: the comparison is exact
         uint64_t lo, hi;
         hl_pack_token(s, st, len, lo, hi);
-        if (lo != s.hot.wd_lo[w] || hi != s.hot.wd_hi[w]) return false;
+        if (lo != gh.wd_lo[w] || hi != gh.wd_hi[w]) return false;
         q = st + len;
     }
     return true;
@@ -301,20 +311,21 @@ __device__ static void hl_verify_pattern(HlShared &s, const HlParams *prm, uint3
     if (dbg == 3) { if ((lo ^ hi) == 0xDEADBEEFull) s.n_nodes = 0; return; }
     if (dbg == 5) return;
     uint32_t j = ~0u;
-    const uint32_t np = s.hot.n_patterns;
+    const HlHot &gh = prm->hot; // the pattern tables by (uniform) pattern number: scalar loads, not LDS reads
+    const uint32_t np = gh.n_patterns;
     for (uint32_t p = 0; p < np; ++p) {
-        if (s.hot.pat_first_len[p] != lc) continue;
-        const uint32_t w0 = s.hot.pat_w0[p];
-        if (lc < HL_LONG && (s.hot.wd_lo[w0] != lo || s.hot.wd_hi[w0] != hi)) continue;
+        if (hl_u8(gh.pat_first_len, p) != lc) continue;
+        const uint32_t w0 = hl_u8(gh.pat_w0, p);
+        if (lc < HL_LONG && (gh.wd_lo[w0] != lo || gh.wd_hi[w0] != hi)) continue;
         if (j == ~0u) j = hl_title_of(s, nt, pos);
         if ((s.res[j] >> 16) & 1u) break;
         bool hit;
-        if (s.hot.pat_bytewise[p]) {
+        if (hl_u8(gh.pat_bytewise, p)) {
             HlLdsReader rd{s.text};
             const uint32_t o = prm->pat_off[p];
             hit = hl_match_at(rd, pos, s.off[j + 1], prm->pat + o, prm->pat_off[p + 1] - o);
         } else {
-            hit = hl_match_rest(s, p, pos + lc, s.off[j + 1]);
+            hit = hl_match_rest(s, gh, p, pos + lc, s.off[j + 1]);
         }
         if (hit) {
             atomicOr(&s.res[j], 1u << 16);
