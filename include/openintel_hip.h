@@ -14,6 +14,10 @@
  *                               (called at src/application/analyze.rs:62-63)
  *   oi_social_summary*       <- SpeculationEngine::social_summary
  *                               src/domain/engine/speculation_engine.rs:70-125
+ *   oi_social_summary_segmented / oi_lexicon_scan_segments_device
+ *                            <- the per-ticker loop of the batch callers run_scan / run_compare
+ *                               src/mcp/tools.rs:193-225, :303-352 (each iteration = analyze.rs:61-63 +
+ *                               speculation_engine.rs:70-125), as ONE pooled scan + one reduction per ticker
  *   oi_headline_scan*        <- catalyst_hits + headline_mentions_company over the dip
  *                               gate's titles   src/domain/dip.rs:247-272 (loop at :617-626)
  *   oi_index_* / oi_search*  <- NO reference interface exists: the
@@ -172,6 +176,30 @@ int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts,
 int oi_lexicon_summary_device(oi_ctx *ctx, const uint8_t *d_text_blob, const uint64_t *d_offsets, uint64_t n_posts,
                               uint64_t blob_bytes, const uint8_t *d_sources, double bull_bear_threshold,
                               double *d_polarity_out, uint8_t *d_speculative_out, oi_social_counters *out_host);
+
+/* The batch callers: run_scan (src/mcp/tools.rs:193-225) and run_compare (:303-352) run application::analyze once per
+ * ticker.  Here the posts of ALL tickers are pooled into one batch -- one scan -- and every ticker gets its
+ * social_summary sums from one reduction: segment s = posts [seg_offsets[s], seg_offsets[s+1]) (non-decreasing,
+ * seg_offsets[n_segments] <= n_posts; an empty segment gives zeros), out[s] = that ticker's counters.
+ * polarity_sum is the reference's own loop (speculation_engine.rs:82-86): added one signal at a time, in input order, from
+ * +0.0 -- BIT-IDENTICAL to the reference's f64 (and so is net_sentiment = polarity_sum / total), unlike the tree of
+ * oi_social_summary.  One wave per segment: meant for many segments of a ticker's size (50 posts per source,
+ * tools.rs:101); a single segment of 10M posts takes ~50 ms.
+ * location OI_HOST: every pointer is host memory, the call returns with `out` filled; seg_offsets[n_segments] > n_posts
+ * -> OI_ERR_ANALYZER_MISMATCH (speculation_engine.rs:29-34), decreasing offsets -> OI_ERR_INVALID_ARG.
+ * location OI_DEVICE: every pointer (out too: n_segments records) is HBM, asynchronous on the ctx stream; offsets past
+ * n_posts are clamped by the kernel.  sources may be NULL (by_source stays 0). */
+int oi_social_summary_segmented(oi_ctx *ctx, const uint8_t *sources, const double *polarity, const uint8_t *speculative,
+                                uint64_t n_posts, const uint64_t *seg_offsets, uint64_t n_segments,
+                                double bull_bear_threshold, int location, oi_social_counters *out);
+
+/* oi_lexicon_analyze_device + oi_social_summary_segmented(OI_DEVICE) as one call on the ctx stream: the pooled posts of
+ * n_segments tickers in, one record per ticker out (d_out, HBM).  d_polarity_out / d_speculative_out may be NULL (the
+ * signals then live in the ctx's workspace only).  Asynchronous. */
+int oi_lexicon_scan_segments_device(oi_ctx *ctx, const uint8_t *d_text_blob, const uint64_t *d_offsets, uint64_t n_posts,
+                                    uint64_t blob_bytes, const uint8_t *d_sources, const uint64_t *d_seg_offsets,
+                                    uint64_t n_segments, double bull_bear_threshold, double *d_polarity_out,
+                                    uint8_t *d_speculative_out, oi_social_counters *d_out);
 
 /* ------------------------------------------------------------------------- */
 /* Headline gate (src/domain/dip.rs:204-272)                                   */

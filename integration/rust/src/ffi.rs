@@ -64,6 +64,14 @@ extern "C" {
                                      d_polarity_out: *mut f64, d_speculative_out: *mut u8,
                                      out_host: *mut OiSocialCounters) -> c_int;
 
+    pub fn oi_social_summary_segmented(ctx: *mut OiCtx, sources: *const u8, polarity: *const f64, speculative: *const u8,
+                                       n_posts: u64, seg_offsets: *const u64, n_segments: u64, bull_bear_threshold: f64,
+                                       location: c_int, out: *mut OiSocialCounters) -> c_int;
+    pub fn oi_lexicon_scan_segments_device(ctx: *mut OiCtx, d_text_blob: *const u8, d_offsets: *const u64, n_posts: u64,
+                                           blob_bytes: u64, d_sources: *const u8, d_seg_offsets: *const u64,
+                                           n_segments: u64, bull_bear_threshold: f64, d_polarity_out: *mut f64,
+                                           d_speculative_out: *mut u8, d_out: *mut OiSocialCounters) -> c_int;
+
     pub fn oi_catalyst_keyword(index: u32) -> *const c_char;
     pub fn oi_headline_scan(ctx: *mut OiCtx, blob: *const u8, offsets: *const u64, n_titles: u64, ticker: *const u8,
                             ticker_len: u64, forms_blob: *const u8, form_offsets: *const u32, n_forms: u32,

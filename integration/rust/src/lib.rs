@@ -74,6 +74,31 @@ pub fn analyze_texts(ctx: &HipCtx, texts: &[&str]) -> Result<Vec<(f64, bool)>, H
     Ok(pol.into_iter().zip(spec).map(|(p, s)| (p, s != 0)).collect())
 }
 
+/// The batch tools' unit of work (mcp/tools.rs:193-225 `run_scan`, :303-352 `run_compare`): the texts of MANY tickers
+/// through one scan, and every ticker's `social_summary` sums (speculation_engine.rs:76-97) from one reduction.
+/// `segments[s]` = that ticker's (text, source) pairs in fetch order; returns the per-post signals, index-aligned with
+/// the flattened input, and one counters record per ticker whose `polarity_sum` is the reference's input-order sum.
+pub fn analyze_segments(ctx: &HipCtx, segments: &[Vec<(&str, u8)>], bull_bear_threshold: f64)
+    -> Result<(Vec<(f64, bool)>, Vec<ffi::OiSocialCounters>), HipError> {
+    let (blob, offsets) = gather(segments.iter().flatten().map(|(t, _)| *t));
+    let sources: Vec<u8> = segments.iter().flatten().map(|(_, s)| *s).collect();
+    let n = sources.len();
+    let mut seg = vec![0u64];
+    for s in segments {
+        seg.push(seg.last().unwrap() + s.len() as u64);
+    }
+    let (mut pol, mut spec) = (vec![0f64; n], vec![0u8; n]);
+    check(unsafe {
+        ffi::oi_lexicon_analyze(ctx.raw(), blob.as_ptr(), offsets.as_ptr(), n as u64, pol.as_mut_ptr(), spec.as_mut_ptr())
+    })?;
+    let mut out: Vec<ffi::OiSocialCounters> = (0..segments.len()).map(|_| unsafe { std::mem::zeroed() }).collect();
+    check(unsafe {
+        ffi::oi_social_summary_segmented(ctx.raw(), sources.as_ptr(), pol.as_ptr(), spec.as_ptr(), n as u64, seg.as_ptr(),
+                                         segments.len() as u64, bull_bear_threshold, ffi::OI_HOST, out.as_mut_ptr())
+    })?;
+    Ok((pol.into_iter().zip(spec).map(|(p, s)| (p, s != 0)).collect(), out))
+}
+
 /// Per-title result of the headline gate's scan (dip.rs:247-272).
 pub struct TitleScan {
     /// indices into CATALYST_KEYWORDS (dip.rs:38-55) in first-occurrence order: `catalyst_hits(&[title])`

@@ -100,14 +100,12 @@ class AppConfig:  # settings.rs:10-52
 
 
 # ----------------------------------------------------------------------------- use case
-def analyze(req: AnalysisRequest, social_sources: Sequence[SocialDataSource],
-            market_source: Optional[MarketDataSource], analyzer: PostAnalyzer,
-            now: Optional[_dt.datetime] = None) -> SpeculationReport:
-    """application::analyze (analyze.rs:16-73), same note order and error behaviour.
-
-    Sources are polled in list order; the reference joins them concurrently but consumes
-    the results in the same list order (join_all keeps positions), so posts and notes come
-    out identically."""
+def gather(req: AnalysisRequest, social_sources: Sequence[SocialDataSource],
+           market_source: Optional[MarketDataSource]):
+    """Everything of application::analyze before the analyzer runs (analyze.rs:21-60): the parsed ticker, the posts of
+    the enabled sources in list order, the market snapshot, the request notes.  Raises what the reference returns as Err
+    (InvalidTicker, NoData).  Shared by `analyze` and the batch callers (batch.py), which pool the posts of many tickers
+    into one analyzer call."""
     ticker = Ticker.parse(req.ticker)  # :21
 
     notes: List[str] = []
@@ -134,7 +132,18 @@ def analyze(req: AnalysisRequest, social_sources: Sequence[SocialDataSource],
 
     if not posts and market is None:  # :58-60
         raise NoData()
+    return ticker, posts, market, notes
 
+
+def analyze(req: AnalysisRequest, social_sources: Sequence[SocialDataSource],
+            market_source: Optional[MarketDataSource], analyzer: PostAnalyzer,
+            now: Optional[_dt.datetime] = None) -> SpeculationReport:
+    """application::analyze (analyze.rs:16-73), same note order and error behaviour.
+
+    Sources are polled in list order; the reference joins them concurrently but consumes
+    the results in the same list order (join_all keeps positions), so posts and notes come
+    out identically."""
+    ticker, posts, market, notes = gather(req, social_sources, market_source)
     signals = analyzer.analyze(posts)  # :61-62 -- the hot path
     if now is None:
         now = _dt.datetime.now(_dt.timezone.utc)

@@ -454,6 +454,80 @@ extern "C" int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n
     return oi_launch_social_summary(ctx, dsrc, p.as<double>(), f.as<uint8_t>(), n, tau, out);
 }
 
+// Per-segment sums of a pooled batch (the batch callers: mcp/tools.rs:193-225, :303-352).
+extern "C" int oi_social_summary_segmented(oi_ctx *ctx, const uint8_t *sources, const double *polarity,
+                                           const uint8_t *speculative, uint64_t n_posts, const uint64_t *seg_offsets,
+                                           uint64_t n_segments, double tau, int location, oi_social_counters *out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n_segments == 0) return OI_OK;
+    OI_REQUIRE(seg_offsets && out, "segmented summary: null buffer");
+    OI_REQUIRE((polarity && speculative) || n_posts == 0, "segmented summary: null buffer");
+    OI_REQUIRE(location == OI_HOST || location == OI_DEVICE, "segmented summary: bad location");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (location == OI_DEVICE)
+        return oi_launch_social_summary_segmented(ctx, sources, polarity, speculative, n_posts, seg_offsets, n_segments, tau, out);
+    for (uint64_t s = 0; s < n_segments; ++s)
+        OI_REQUIRE(seg_offsets[s] <= seg_offsets[s + 1], "segmented summary: segment %llu has offsets %llu > %llu",
+                   (unsigned long long)s, (unsigned long long)seg_offsets[s], (unsigned long long)seg_offsets[s + 1]);
+    if (seg_offsets[n_segments] > n_posts) { // the analyzer handed back fewer signals than the segments cover (speculation_engine.rs:29-34)
+        oi_set_error("segments cover %llu posts, %llu signals given", (unsigned long long)seg_offsets[n_segments],
+                     (unsigned long long)n_posts);
+        return OI_ERR_ANALYZER_MISMATCH;
+    }
+    hipStream_t st = ctx->stream;
+    DevBuf &sb = ctx->buf("sum_src"), &p = ctx->buf("sum_pol"), &f = ctx->buf("sum_spec"), &so = ctx->buf("sum_seg"),
+           &ob = ctx->buf("sum_seg_out");
+    OI_CHECK(p.ensure(sizeof(double) * (n_posts + 1)));
+    OI_CHECK(f.ensure(n_posts + 1));
+    OI_CHECK(so.ensure(sizeof(uint64_t) * (n_segments + 1)));
+    OI_CHECK(ob.ensure(sizeof(oi_social_counters) * n_segments));
+    if (n_posts) {
+        OI_HIP_CHECK(hipMemcpyAsync(p.p, polarity, sizeof(double) * n_posts, hipMemcpyHostToDevice, st));
+        OI_HIP_CHECK(hipMemcpyAsync(f.p, speculative, n_posts, hipMemcpyHostToDevice, st));
+    }
+    const uint8_t *dsrc = nullptr;
+    if (sources && n_posts) {
+        OI_CHECK(sb.ensure(n_posts));
+        OI_HIP_CHECK(hipMemcpyAsync(sb.p, sources, n_posts, hipMemcpyHostToDevice, st));
+        dsrc = sb.as<uint8_t>();
+    }
+    OI_HIP_CHECK(hipMemcpyAsync(so.p, seg_offsets, sizeof(uint64_t) * (n_segments + 1), hipMemcpyHostToDevice, st));
+    OI_CHECK(oi_launch_social_summary_segmented(ctx, dsrc, p.as<double>(), f.as<uint8_t>(), n_posts, so.as<uint64_t>(),
+                                                n_segments, tau, ob.as<oi_social_counters>()));
+    OI_HIP_CHECK(hipMemcpyAsync(out, ob.p, sizeof(oi_social_counters) * n_segments, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    return OI_OK;
+}
+
+// LexiconAnalyzer::analyze over the pooled posts of many tickers + every ticker's social_summary sums: two launches on the
+// ctx stream, nothing copied, nothing synchronised.
+extern "C" int oi_lexicon_scan_segments_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                                               uint64_t blob_bytes, const uint8_t *d_sources, const uint64_t *d_seg_offsets,
+                                               uint64_t n_segments, double tau, double *d_pol, uint8_t *d_spec,
+                                               oi_social_counters *d_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n_segments == 0) return OI_OK;
+    OI_REQUIRE(d_seg_offsets && d_out, "scan segments: null buffer");
+    OI_REQUIRE(n == 0 || (d_offsets && (d_blob || blob_bytes == 0)), "scan segments: null buffer");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n) {
+        if (!d_pol) { // the signals are wanted only as the reduction's input: the ctx's own workspace
+            DevBuf &p = ctx->buf("lex_pol");
+            OI_CHECK(p.ensure(sizeof(double) * n));
+            d_pol = p.as<double>();
+        }
+        if (!d_spec) {
+            DevBuf &f = ctx->buf("lex_spec");
+            OI_CHECK(f.ensure(n));
+            d_spec = f.as<uint8_t>();
+        }
+        OI_CHECK(oi_launch_lexicon(ctx, d_blob, d_offsets, n, blob_bytes, d_pol, d_spec));
+    }
+    return oi_launch_social_summary_segmented(ctx, d_sources, d_pol, d_spec, n, d_seg_offsets, n_segments, tau, d_out);
+}
+
 // ---------------------------------------------------------------- index
 static std::atomic<uint64_t> g_index_uid{1};
 

@@ -1137,3 +1137,106 @@ int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double
     }
     return OI_OK;
 }
+
+// ---- social summary per segment -----------------------------------------------------
+// The reference's only batch entry (mcp/tools.rs:193-225 run_scan, :303-352 run_compare) runs application::analyze
+// once per ticker; here the posts of ALL tickers go through one scan and this kernel gives every ticker (segment) its
+// social_summary sums (speculation_engine.rs:76-97).  One wave per segment, segments strided over the grid.  The
+// integer counters are lane-parallel (64 signals per step, ballots).  polarity_sum is added ONE SIGNAL AT A TIME in
+// input order from +0.0 -- the reference's own `polarity_sum += v` loop (:83-86), so the sum and the net_sentiment made
+// from it are bit-identical to the reference's, not a tree with a bound.  The chain costs ONE vector instruction per
+// signal: the step's polarities, already in registers for the counters, are parked in the wave's own LDS slot and read
+// back at wave-uniform addresses (a broadcast read, two signals per ds_read_b128), each added with one v_add_f64.
+// (Measured at 10M posts in 100K tickers: two v_readlane + add per signal 0.15-0.22 ms; the polarities through the scalar
+// cache, s_load_dwordx16 + eight adds, 0.109 ms -- the scalar memory path does not carry 80 MB; this form: see DESIGN.md.
+// ONE segment of 10M posts is still one wave's 10M dependent adds, ~40 ms -- the unsegmented oi_social_summary with its
+// tree is the call for that.)
+#define SEG_THREADS 256
+#define SEG_ROUNDS 4 // 64-signal rounds of a segment whose loads are in flight together
+__global__ __launch_bounds__(SEG_THREADS) void social_summary_segmented_kernel(const uint8_t *__restrict__ sources,
+                                                                                const double *__restrict__ pol,
+                                                                                const uint8_t *__restrict__ spec, uint64_t n,
+                                                                                const uint64_t *__restrict__ seg, uint64_t n_seg,
+                                                                                double tau, oi_social_counters *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double seg_slot[SEG_THREADS / 64][64 * SEG_ROUNDS]; // a wave's step, in input order
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: the segment walk is scalar code
+    const uint64_t n_waves = (uint64_t)gridDim.x * (SEG_THREADS / 64);
+    for (uint64_t sg = (uint64_t)blockIdx.x * (SEG_THREADS / 64) + wv; sg < n_seg; sg += n_waves) {
+        uint64_t b = seg[sg], e = seg[sg + 1];
+        if (e > n) e = n; // a malformed offsets array must not read past the signals (the host entry point rejects it)
+        if (b > e) b = e;
+        uint64_t src1 = 0, bull = 0, bear = 0, sp = 0;
+        double sum = 0.0; // :82
+        const uint8_t *srcp = sources ? sources : spec; // without sources the flags are read twice and the count dropped
+        double *slot = seg_slot[wv];
+        for (uint64_t base = b; base < e; base += 64 * SEG_ROUNDS) {
+            // all of a step's loads first, never predicated (a lane past the end re-reads the segment's last signal and
+            // ignores it): a ticker's ~100 posts are one step, one memory round trip
+            double v[SEG_ROUNDS];
+            uint8_t f[SEG_ROUNDS], s1[SEG_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < SEG_ROUNDS; ++r) {
+                const uint64_t i = base + 64u * r + lane, ic = i < e ? i : e - 1;
+                v[r] = pol[ic];
+                f[r] = spec[ic];
+                s1[r] = srcp[ic]; // (no branch around a load: it would be waited for at the join)
+            }
+#pragma unroll
+            for (int r = 0; r < SEG_ROUNDS; ++r) {
+                const uint64_t r0 = base + 64u * r;
+                if (r0 >= e) break; // wave-uniform
+                const bool ok = r0 + lane < e;
+                const double x = ok ? v[r] : 0.0;
+                const bool is_bull = ok && x > tau;               // :86-92: bullish, else bearish, else neutral
+                const bool is_bear = ok && !is_bull && x < -tau;
+                bull += (uint64_t)__popcll(__ballot(is_bull));
+                bear += (uint64_t)__popcll(__ballot(is_bear));
+                sp += (uint64_t)__popcll(__ballot(ok && f[r] != 0));
+                src1 += (uint64_t)__popcll(__ballot(ok && s1[r] != 0));
+                slot[64 * r + lane] = x;
+            }
+            // the ordered sum of the step's signals: a wave's LDS operations complete in order, so the reads below see
+            // every lane's store; the addresses are wave-uniform
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t m = e - base < 64u * SEG_ROUNDS ? (uint32_t)(e - base) : 64u * SEG_ROUNDS; // scalar
+            uint32_t k = 0;
+            for (; k + 8 <= m; k += 8) {
+                double t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = slot[k + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += t[j];
+            }
+            for (; k < m; ++k) sum += slot[k];
+            __builtin_amdgcn_wave_barrier(); // the next step's stores come after these reads
+        }
+        if (lane == 0) {
+            oi_social_counters o;
+            o.total = e - b;
+            o.by_source[0] = sources ? (e - b) - src1 : 0; // as oi_social_summary: no sources, no histogram
+            o.by_source[1] = sources ? src1 : 0;
+            o.bullish = bull;
+            o.bearish = bear;
+            o.neutral = (e - b) - bull - bear;
+            o.spec_count = sp;
+            o.polarity_sum = sum;
+            out[sg] = o;
+        }
+    }
+}
+
+int oi_launch_social_summary_segmented(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol, const uint8_t *d_spec,
+                                       uint64_t n, const uint64_t *d_seg, uint64_t n_seg, double tau,
+                                       oi_social_counters *d_out) {
+    if (n_seg == 0) return OI_OK;
+    const uint64_t per_wg = SEG_THREADS / 64;
+    uint64_t blocks = (n_seg + per_wg - 1) / per_wg;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 16; // 64 waves per CU in the grid: the segments are strided over them
+    if (blocks > cap) blocks = cap;
+    ProfScope ps(ctx, "social_summary_segmented");
+    hipLaunchKernelGGL(social_summary_segmented_kernel, dim3((uint32_t)blocks), dim3(SEG_THREADS), 0, ctx->stream, d_sources,
+                       d_pol, d_spec, n, d_seg, n_seg, tau, d_out);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}

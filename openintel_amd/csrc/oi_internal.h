@@ -190,6 +190,9 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
 int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol,
                              const uint8_t *d_spec, uint64_t n, double tau,
                              oi_social_counters *out_host);
+int oi_launch_social_summary_segmented(oi_ctx *ctx, const uint8_t *d_sources, const double *d_pol, const uint8_t *d_spec,
+                                       uint64_t n, const uint64_t *d_seg, uint64_t n_seg, double tau,
+                                       oi_social_counters *d_out);
 // headline.hip
 int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
                             uint64_t blob_bytes, const uint8_t *ticker, uint64_t ticker_len,

@@ -261,6 +261,24 @@ def social_summary(sources, polarity, speculative, cfg: Optional[EngineConfig] =
     return out
 
 
+def social_summary_segmented(sources, polarity, speculative, seg_offsets, cfg: Optional[EngineConfig] = None):
+    """social_summary of every segment [seg_offsets[s], seg_offsets[s+1]) of a pooled batch: the per-ticker loop of
+    run_scan / run_compare (mcp/tools.rs:193-225, :303-352).  Returns a ctypes array of SocialSummary."""
+    sources = np.ascontiguousarray(sources, dtype=np.uint8)
+    polarity = np.ascontiguousarray(polarity, dtype=np.float64)
+    speculative = np.ascontiguousarray(speculative, dtype=np.uint8)
+    seg = np.ascontiguousarray(seg_offsets, dtype=np.uint64)
+    assert sources.size == polarity.size == speculative.size
+    n_seg = seg.size - 1
+    assert n_seg >= 0 and (n_seg == 0 or (np.all(seg[1:] >= seg[:-1]) and int(seg[-1]) <= polarity.size))
+    cfg = cfg or default_config()
+    out = (SocialSummary * max(n_seg, 1))()
+    if n_seg:
+        _L().oio_social_summary_segmented(_p(sources), _p(polarity), _p(speculative), _p(seg), C.c_uint64(n_seg),
+                                          C.byref(cfg), out)
+    return out[:n_seg] if n_seg else []
+
+
 def aggregate(ticker: str, sources, polarity, speculative, market: Optional[MarketSnapshot] = None,
               market_ticker: Optional[str] = None, cfg: Optional[EngineConfig] = None):
     """Returns (rc, Report).  len(sources) models posts.len(); len(polarity) signals.len()."""

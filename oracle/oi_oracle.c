@@ -325,6 +325,19 @@ void oio_social_summary_compute(const uint8_t *sources, const double *polarity,
     out->polarity_sum = polarity_sum;
 }
 
+/* The batch callers (src/mcp/tools.rs:193-225 run_scan, :303-352 run_compare) call application::analyze once per
+ * ticker, i.e. social_summary (above) once per ticker's posts.  Segment s = signals [seg[s], seg[s+1]): the same
+ * function on each slice, nothing else -- the per-ticker loop of the reference written over a pooled batch. */
+void oio_social_summary_segmented(const uint8_t *sources, const double *polarity, const uint8_t *speculative,
+                                  const uint64_t *seg, uint64_t n_segments, const oio_engine_config *cfg,
+                                  oio_social_summary *out) {
+    static const uint8_t none = 0;
+    for (uint64_t s = 0; s < n_segments; s++) {
+        uint64_t b = seg[s], n = seg[s + 1] - seg[s];
+        oio_social_summary_compute(n ? sources + b : &none, polarity + b, speculative + b, n, cfg, &out[s]);
+    }
+}
+
 /* src/domain/engine/speculation_engine.rs:127-148 */
 void oio_market_summary_compute(const oio_market_snapshot *m, oio_market_summary *out) {
     memset(out, 0, sizeof(*out));

@@ -146,6 +146,9 @@ void oio_social_summary_compute(const uint8_t *sources, const double *polarity,
 void oio_market_summary_compute(const oio_market_snapshot *m,
                                 oio_market_summary *out);
 /* A5: src/domain/engine/speculation_engine.rs:151-176 */
+void oio_social_summary_segmented(const uint8_t *sources, const double *polarity, const uint8_t *speculative,
+                                  const uint64_t *seg, uint64_t n_segments, const oio_engine_config *cfg,
+                                  oio_social_summary *out);
 double oio_crowding(const oio_social_summary *social,
                     const oio_market_summary *market /* NULL = None */,
                     const oio_engine_config *cfg);
