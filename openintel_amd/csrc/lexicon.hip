@@ -1147,23 +1147,32 @@ int oi_launch_social_summary(oi_ctx *ctx, const uint8_t *d_sources, const double
 // from it are bit-identical to the reference's, not a tree with a bound.  The chain costs ONE vector instruction per
 // signal: the step's polarities, already in registers for the counters, are parked in the wave's own LDS slot and read
 // back at wave-uniform addresses (a broadcast read, two signals per ds_read_b128), each added with one v_add_f64.
-// (Measured at 10M posts in 100K tickers: two v_readlane + add per signal 0.15-0.22 ms; the polarities through the scalar
-// cache, s_load_dwordx16 + eight adds, 0.109 ms -- the scalar memory path does not carry 80 MB; this form: see DESIGN.md.
-// ONE segment of 10M posts is still one wave's 10M dependent adds, ~40 ms -- the unsegmented oi_social_summary with its
-// tree is the call for that.)
+// (Measured at 10M posts in 100K tickers, tools/scan_bench.py: two v_readlane + add per signal 0.15-0.22 ms; the
+// polarities through the scalar cache, s_load_dwordx16 + eight adds, 0.109 ms; this form 0.072 ms -- ordered sums 0.028,
+// counters 0.011, loads and per-segment latency the rest, ~0.015 of it at any size (tools/r03_seg_probe.sh).  ONE segment
+// of 10M posts is still one wave's 10M dependent adds, ~40 ms -- the unsegmented oi_social_summary with its tree is the
+// call for that; 1M segments of 10 posts take 0.29 ms, a memory round trip per segment and wave.)
 #define SEG_THREADS 256
 #define SEG_ROUNDS 4 // 64-signal rounds of a segment whose loads are in flight together
 __global__ __launch_bounds__(SEG_THREADS) void social_summary_segmented_kernel(const uint8_t *__restrict__ sources,
                                                                                 const double *__restrict__ pol,
                                                                                 const uint8_t *__restrict__ spec, uint64_t n,
                                                                                 const uint64_t *__restrict__ seg, uint64_t n_seg,
-                                                                                double tau, oi_social_counters *__restrict__ out) {
+                                                                                double tau, oi_social_counters *__restrict__ out, int dbg) {
     __shared__ __attribute__((aligned(16))) double seg_slot[SEG_THREADS / 64][64 * SEG_ROUNDS]; // a wave's step, in input order
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: the segment walk is scalar code
     const uint64_t n_waves = (uint64_t)gridDim.x * (SEG_THREADS / 64);
-    for (uint64_t sg = (uint64_t)blockIdx.x * (SEG_THREADS / 64) + wv; sg < n_seg; sg += n_waves) {
-        uint64_t b = seg[sg], e = seg[sg + 1];
+    uint64_t sg = (uint64_t)blockIdx.x * (SEG_THREADS / 64) + wv;
+    if (sg >= n_seg) return;
+    uint64_t nb = seg[sg], ne = seg[sg + 1];
+    for (; sg < n_seg; sg += n_waves) {
+        uint64_t b = nb, e = ne;
+        // the NEXT segment's bounds now, used a segment later: bounds -> signals is two dependent round trips per segment
+        // otherwise (the offsets of consecutive tickers share a line, but they go to different waves and CUs)
+        const uint64_t nsg = sg + n_waves < n_seg ? sg + n_waves : sg;
+        nb = seg[nsg];
+        ne = seg[nsg + 1];
         if (e > n) e = n; // a malformed offsets array must not read past the signals (the host entry point rejects it)
         if (b > e) b = e;
         uint64_t src1 = 0, bull = 0, bear = 0, sp = 0;
@@ -1185,7 +1194,7 @@ __global__ __launch_bounds__(SEG_THREADS) void social_summary_segmented_kernel(c
 #pragma unroll
             for (int r = 0; r < SEG_ROUNDS; ++r) {
                 const uint64_t r0 = base + 64u * r;
-                if (r0 >= e) break; // wave-uniform
+                if (r0 >= e || dbg == 2) break; // wave-uniform
                 const bool ok = r0 + lane < e;
                 const double x = ok ? v[r] : 0.0;
                 const bool is_bull = ok && x > tau;               // :86-92: bullish, else bearish, else neutral
@@ -1200,15 +1209,17 @@ __global__ __launch_bounds__(SEG_THREADS) void social_summary_segmented_kernel(c
             // every lane's store; the addresses are wave-uniform
             __builtin_amdgcn_wave_barrier();
             const uint32_t m = e - base < 64u * SEG_ROUNDS ? (uint32_t)(e - base) : 64u * SEG_ROUNDS; // scalar
-            uint32_t k = 0;
-            for (; k + 8 <= m; k += 8) {
-                double t[8];
+            if (lane == 0 && dbg != 1) { // ONE lane: a read broadcast to 64 lanes costs the LDS as many cycles as 64 different reads
+                uint32_t k = 0;
+                for (; k + 8 <= m; k += 8) {
+                    double t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = slot[k + j];
+                    for (int j = 0; j < 8; ++j) t[j] = slot[k + j];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) sum += t[j];
+                    for (int j = 0; j < 8; ++j) sum += t[j];
+                }
+                for (; k < m; ++k) sum += slot[k];
             }
-            for (; k < m; ++k) sum += slot[k];
             __builtin_amdgcn_wave_barrier(); // the next step's stores come after these reads
         }
         if (lane == 0) {
@@ -1234,9 +1245,10 @@ int oi_launch_social_summary_segmented(oi_ctx *ctx, const uint8_t *d_sources, co
     uint64_t blocks = (n_seg + per_wg - 1) / per_wg;
     const uint64_t cap = (uint64_t)ctx->num_cus * 16; // 64 waves per CU in the grid: the segments are strided over them
     if (blocks > cap) blocks = cap;
+    static const int dbg = oi_ablation_env("OI_SEG_DBG") ? atoi(oi_ablation_env("OI_SEG_DBG")) : 0; // ablations (wrong results): 1 no ordered sum, 2 no counters / no stores to LDS
     ProfScope ps(ctx, "social_summary_segmented");
     hipLaunchKernelGGL(social_summary_segmented_kernel, dim3((uint32_t)blocks), dim3(SEG_THREADS), 0, ctx->stream, d_sources,
-                       d_pol, d_spec, n, d_seg, n_seg, tau, d_out);
+                       d_pol, d_spec, n, d_seg, n_seg, tau, d_out, dbg);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
