@@ -332,13 +332,15 @@ class ShardedAnalyzer:
     DESIGN.md section 5.  The global counters then go through SpeculationEngine.aggregate_counters (host scalars).
 
     `analyze_shard(*shard_inputs)` returns an object with those eight fields (the HIP one: make_hip_sharded_analyzer;
-    tests/test_sharded_gloo.py injects the CPU oracle)."""
+    tests/test_sharded_gloo.py injects the CPU oracle).  `segment_summaries` is the batch callers' form: whole tickers
+    per rank, bit-identical records."""
 
     WORDS = 8
 
-    def __init__(self, analyze_shard: Callable, device, group=None):
+    def __init__(self, analyze_shard: Callable, device, group=None, scan_segments_shard: Optional[Callable] = None):
         import torch.distributed as dist
         self.analyze_shard, self.device, self.group, self.dist = analyze_shard, device, group, dist
+        self.scan_segments_shard = scan_segments_shard
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -371,6 +373,37 @@ class ShardedAnalyzer:
         return out
 
 
+    @staticmethod
+    def ticker_bounds(n_tickers: int, world: int, rank: int):
+        """Contiguous ticker range of `rank` (the batch callers' shards: whole tickers, so no sum is ever split)."""
+        per = (n_tickers + world - 1) // world
+        lo = min(n_tickers, rank * per)
+        return lo, min(n_tickers, lo + per)
+
+    def segment_summaries(self, n_tickers: int, *shard_inputs):
+        """The batch callers' form over ranks: the TICKERS of a scan are sharded -- rank r holds the posts
+        of tickers ticker_bounds(n_tickers, world, r), pooled -- every rank runs its scan + per-ticker reduction
+        (`scan_segments_shard(*shard_inputs)` -> int64 tensor of 8 words per local ticker, an `oi_social_counters` each),
+        and ONE all-gather of the records follows (padded to the largest shard).  A ticker's sums are computed whole on one
+        rank, in input order: the gathered records are bit-identical to the unsharded ones, polarity_sum included -- no
+        reassociation, unlike `summary`.  Returns an int64 array [n_tickers, 8] (host), the same on every rank."""
+        import torch
+        lo, hi = self.ticker_bounds(n_tickers, self.world, self.rank)
+        mine = self.scan_segments_shard(*shard_inputs)
+        assert mine.numel() == (hi - lo) * self.WORDS, "one 8-word record per local ticker"
+        if self.world == 1:
+            return mine.cpu().numpy().reshape(n_tickers, self.WORDS).copy()
+        per = (n_tickers + self.world - 1) // self.world
+        padded = torch.zeros(per * self.WORDS, dtype=torch.int64, device=self.device)
+        padded[: mine.numel()] = mine
+        allw = torch.empty(self.world * per * self.WORDS, dtype=torch.int64, device=self.device)
+        self.dist.all_gather_into_tensor(allw, padded, group=self.group)              # the ONE exchange
+        g = allw.cpu().numpy().reshape(self.world, per, self.WORDS)
+        rows = [g[r, : self.ticker_bounds(n_tickers, self.world, r)[1] - self.ticker_bounds(n_tickers, self.world, r)[0]]
+                for r in range(self.world)]
+        return np.concatenate(rows, axis=0)
+
+
 def make_hip_sharded_analyzer(ctx, device, cfg=None, group=None) -> ShardedAnalyzer:
     """Wire the HIP lexicon scan + summary reduction of `ctx` into a ShardedAnalyzer.  Shard inputs: torch CUDA
     tensors (uint8 text blob, int64 offsets[n+1], uint8 sources[n] or None)."""
@@ -383,7 +416,14 @@ def make_hip_sharded_analyzer(ctx, device, cfg=None, group=None) -> ShardedAnaly
         # one pass over the shard's text: the scan with the social_summary reduction fused in, nothing written per post
         return an.summary_device(d_blob, d_offsets, d_sources, tau=cfg.bull_bear_threshold)
 
-    return ShardedAnalyzer(analyze_shard, device, group)
+    def scan_segments_shard(d_blob, d_offsets, d_sources, d_seg_offsets):
+        # the rank's tickers, pooled: one scan + one per-ticker reduction, records left in HBM
+        import torch
+        out = torch.zeros((d_seg_offsets.numel() - 1) * ShardedAnalyzer.WORDS, dtype=torch.int64, device=device)
+        an.scan_segments_device(d_blob, d_offsets, d_sources, d_seg_offsets, out, cfg.bull_bear_threshold)
+        return out
+
+    return ShardedAnalyzer(analyze_shard, device, group, scan_segments_shard=scan_segments_shard)
 
 
 def make_hip_sharded(ctx, index, device, group=None) -> ShardedRetriever:

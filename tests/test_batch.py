@@ -419,3 +419,32 @@ def test_full_size_10M_posts_in_100K_tickers_gpu(hip):
         b, e = int(seg[k]), int(seg[k + 1])
         acc = np.add.accumulate(np.concatenate([[0.0], pol[b:e]]))[-1]  # sequential, input order
         assert np.float64(got["polarity_sum"][k]).tobytes() == np.float64(acc).tobytes(), k
+
+
+@pytest_gpu
+def test_ticker_sharded_records_equal_unsharded_gpu(hip):
+    """ShardedAnalyzer.segment_summaries through the HIP path (world 1: the rank owns every ticker) and as two
+    half-shards scanned one after the other on the one GPU: the records are those of the single pooled call."""
+    import torch
+    from openintel_amd import synth
+    from openintel_amd.sharded import ShardedAnalyzer, make_hip_sharded_analyzer
+    n, n_tick = 300_000, 4001
+    dev = torch.device("cuda:0")
+    blob, offs = synth.posts_torch(n, dev, seed=45)
+    rng = np.random.default_rng(4)
+    seg = np.concatenate([[0], np.sort(rng.integers(0, n + 1, n_tick - 1)), [n]]).astype(np.int64)
+    src = (torch.arange(n, device=dev) % 2 == 0).to(torch.uint8)
+    sa = make_hip_sharded_analyzer(hip.ctx, dev)
+    whole = sa.segment_summaries(n_tick, blob, offs, src, torch.from_numpy(seg).to(dev))
+    assert whole.shape == (n_tick, 8) and int(whole[:, 0].sum()) == n
+    parts = []
+    for rank in (0, 1):
+        lo, hi = ShardedAnalyzer.ticker_bounds(n_tick, 2, rank)
+        p0, p1 = int(seg[lo]), int(seg[hi])
+        b0, b1 = int(offs[p0]), int(offs[p1])
+        sub_offs = (offs[p0:p1 + 1] - b0).contiguous()
+        sub_seg = torch.from_numpy(seg[lo:hi + 1] - seg[lo]).to(dev)
+        rec = sa.scan_segments_shard(blob[b0:b1].clone(), sub_offs, src[p0:p1].contiguous(), sub_seg)
+        parts.append(rec.cpu().numpy().reshape(hi - lo, 8))
+    assert np.array_equal(np.concatenate(parts), whole)
+

@@ -221,3 +221,55 @@ def test_two_ranks_lexicon_summary_matches_unsharded_oracle(n, golden):
     rest = _oracle_counters(texts[n // 2:], src[n // 2:])[0].polarity_sum
     assert g[7] == half + rest                                                      # rank-order sum of the partials
     assert abs(g[7] - ref.polarity_sum) <= n * 2.0 ** -52 * max(1.0, float(np.abs(np.cumsum(pol)).max()))
+
+
+# ------------------------------------------------------------------ the batch callers over ranks: whole tickers per rank
+def _ticker_cuts(n, n_tickers, seed):
+    rng = np.random.default_rng(seed)
+    cuts = np.sort(rng.integers(0, n + 1, n_tickers - 1))
+    return np.concatenate([[0], cuts, [n]]).astype(np.uint64)   # ragged, some tickers empty
+
+
+def _oracle_records(texts, src, seg):
+    """8 int64 words per ticker, laid out like oi_social_counters (the f64's bits in the last word)."""
+    _, pol, spec = _oracle_counters(texts, src)
+    out = np.zeros((seg.size - 1, 8), dtype=np.int64)
+    for k, o in enumerate(O.social_summary_segmented(src, pol, spec, seg)):
+        out[k, :7] = (o.total_mentions, o.mentions_by_source[0], o.mentions_by_source[1], o.bullish, o.bearish, o.neutral,
+                      o.spec_count)
+        out[k, 7] = np.array([o.polarity_sum], dtype=np.float64).view(np.int64)[0]
+    return out
+
+
+def _segments_worker(rank, world, port, ret, n, n_tickers):
+    from openintel_amd.sharded import ShardedAnalyzer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        texts, src = _posts(n, 78)
+        seg = _ticker_cuts(n, n_tickers, 5)
+        lo, hi = ShardedAnalyzer.ticker_bounds(n_tickers, world, rank)
+        p0, p1 = int(seg[lo]), int(seg[hi])                    # the rank's tickers' posts, pooled
+
+        def scan(t, s_, sg):
+            return torch.from_numpy(_oracle_records(t, s_, sg).reshape(-1))
+        sa = ShardedAnalyzer(None, torch.device("cpu"), scan_segments_shard=scan)
+        g = sa.segment_summaries(n_tickers, texts[p0:p1], src[p0:p1], seg[lo:hi + 1] - seg[lo])
+        ret[rank] = g.tobytes()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("n,n_tickers", [(600, 7), (5000, 64), (3000, 101)])
+def test_two_ranks_ticker_shards_equal_the_unsharded_per_ticker_sums(n, n_tickers):
+    """Whole tickers per rank: every record, polarity_sum's bits included, equals the unsharded oracle's -- there is no
+    reassociation to bound (unlike the one-report form above)."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_segments_worker, args=(world, _free_port(), ret, n, n_tickers), nprocs=world, join=True)
+    texts, src = _posts(n, 78)
+    ref = _oracle_records(texts, src, _ticker_cuts(n, n_tickers, 5))
+    assert ret[0] == ret[1] == ref.tobytes()
+
