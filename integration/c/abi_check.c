@@ -5,7 +5,7 @@
  *
  * Without a GPU it checks that the header is valid C, that the library links and that a missing device is a loud
  * OI_ERR_NO_DEVICE (there is no CPU path).  With a gfx950 device it scores three posts through the PostAnalyzer entry
- * point (post_analyzer.rs:7-11 / lexicon.rs:106-120's sentences) and runs one hybrid query of a 1000-post index
+ * point (post_analyzer.rs:7-11 / lexicon.rs:106-120's sentences), sums a pooled batch per ticker, and runs one hybrid query of a 1000-post index
  * (BASELINE configs[0]'s shape: 384-d, top-10). */
 #include <math.h>
 #include <stdio.h>
@@ -46,6 +46,25 @@ int main(void) {
         if (rc != OI_OK) return fail("oi_lexicon_analyze", rc);
         if (!(pol[0] > 0.0 && spec[0] == 1 && pol[1] < 0.0 && spec[1] == 1 && pol[2] == 0.0 && spec[2] == 0)) {
             fprintf(stderr, "abi_check: lexicon signals differ from lexicon.rs:109-119: %g/%d %g/%d %g/%d\n", pol[0], spec[0], pol[1], spec[1], pol[2], spec[2]);
+            return 1;
+        }
+    }
+    { /* the batch tools' per-ticker sums (mcp/tools.rs:193-225): two tickers' signals pooled, the second one empty */
+        const double pol[5] = {1.0, -1.0, 0.0, 0.5, 1e-17};
+        const uint8_t spec[5] = {1, 0, 0, 1, 0}, src[5] = {0, 1, 1, 0, 0};
+        const uint64_t seg[4] = {0, 5, 5, 5};
+        oi_social_counters out[3];
+        double want = 0.0;
+        int i;
+        for (i = 0; i < 5; ++i) want += pol[i]; /* speculation_engine.rs:82-86, input order */
+        rc = oi_social_summary_segmented(ctx, src, pol, spec, 5, seg, 3, 0.2, OI_HOST, out);
+        if (rc != OI_OK) return fail("oi_social_summary_segmented", rc);
+        if (!(out[0].total == 5 && out[0].bullish == 2 && out[0].bearish == 1 && out[0].neutral == 2 && out[0].spec_count == 2 &&
+              out[0].by_source[0] == 3 && out[0].by_source[1] == 2 && out[0].polarity_sum == want && out[1].total == 0 &&
+              out[2].total == 0 && out[2].polarity_sum == 0.0)) {
+            fprintf(stderr, "abi_check: per-ticker sums differ: total %llu bull %llu bear %llu sum %.17g (want %.17g)\n",
+                    (unsigned long long)out[0].total, (unsigned long long)out[0].bullish, (unsigned long long)out[0].bearish,
+                    out[0].polarity_sum, want);
             return 1;
         }
     }
