@@ -134,7 +134,10 @@ class HipLexiconAnalyzer(PostAnalyzer):
             seg_offsets[1:] = np.cumsum([len(seg) for seg in segments])
         pol, spec = self.analyze_packed(*pack_posts([p.text.as_str() for p in flat]))
         sources = np.fromiter((int(p.source) for p in flat), dtype=np.uint8, count=len(flat))
-        counters = self.summary_segments(sources, pol, spec, seg_offsets, tau)
+        try:
+            counters = self.summary_segments(sources, pol, spec, seg_offsets, tau)
+        except _lib.OiError as e:  # the same mapping as the scan's failures: DomainError::SourceFailure
+            raise SourceFailure("hip-analyzer", e.message)
         signals = [[PostSignal(float(pol[i]), bool(spec[i])) for i in range(int(seg_offsets[k]), int(seg_offsets[k + 1]))]
                    for k in range(len(segments))]
         return signals, counters
