@@ -57,6 +57,20 @@ void DevBuf::release() {
     borrowed = false;
 }
 
+int PinBuf::ensure(size_t bytes) {
+    if (bytes <= cap) return OI_OK;
+    release();
+    const size_t want = (bytes + 4095) & ~(size_t)4095;
+    OI_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return OI_OK;
+}
+void PinBuf::release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
 // ---------------------------------------------------------------- profiling hooks
 void oi_ctx::prof_begin(const char *tag) {
     ProfSpan s;
@@ -265,6 +279,8 @@ static void ctx_release(oi_ctx *ctx) {
     oi_profile_reset(ctx, 0);
     graphs_purge(ctx, 0);
     for (auto &kv : ctx->ws) kv.second.release();
+    ctx->pin_in.release();
+    ctx->pin_out.release();
     delete ctx;
 }
 
@@ -1092,15 +1108,36 @@ int stage_queries(oi_index *idx, const float *qv, const uint32_t *qt, const uint
     oi_ctx *ctx = idx->ctx;
     if (location == OI_DEVICE) { *out = QueryStage{qv, qt, qo}; return OI_OK; }
     hipStream_t st = ctx->stream;
-    DevBuf &a = ctx->buf("q_vecs"), &b = ctx->buf("q_terms"), &c = ctx->buf("q_offs");
+    // one page-locked staging buffer, one DMA: [vectors | terms | offsets], each part 16-byte aligned
     const uint32_t nt = qo[B];
-    OI_CHECK(a.ensure(sizeof(float) * (size_t)B * idx->dim));
-    OI_CHECK(b.ensure(sizeof(uint32_t) * (nt ? nt : 1)));
-    OI_CHECK(c.ensure(sizeof(uint32_t) * (B + 1)));
-    OI_HIP_CHECK(hipMemcpyAsync(a.p, qv, sizeof(float) * (size_t)B * idx->dim, hipMemcpyHostToDevice, st));
-    if (nt) OI_HIP_CHECK(hipMemcpyAsync(b.p, qt, sizeof(uint32_t) * nt, hipMemcpyHostToDevice, st));
-    OI_HIP_CHECK(hipMemcpyAsync(c.p, qo, sizeof(uint32_t) * (B + 1), hipMemcpyHostToDevice, st));
-    *out = QueryStage{a.as<float>(), b.as<uint32_t>(), c.as<uint32_t>()};
+    const size_t vb = sizeof(float) * (size_t)B * idx->dim, tb = sizeof(uint32_t) * (size_t)(nt ? nt : 1), ob = sizeof(uint32_t) * ((size_t)B + 1);
+    const size_t off_t = (vb + 15) & ~(size_t)15, off_o = off_t + ((tb + 15) & ~(size_t)15), total = off_o + ob;
+    DevBuf &a = ctx->buf("q_stage");
+    OI_CHECK(a.ensure(total));
+    OI_CHECK(ctx->pin_in.ensure(total));
+    uint8_t *h = ctx->pin_in.as<uint8_t>();
+    memcpy(h, qv, vb);
+    if (nt) memcpy(h + off_t, qt, sizeof(uint32_t) * nt);
+    memcpy(h + off_o, qo, ob);
+    OI_HIP_CHECK(hipMemcpyAsync(a.p, h, total, hipMemcpyHostToDevice, st));
+    uint8_t *d = a.as<uint8_t>();
+    *out = QueryStage{reinterpret_cast<const float *>(d), reinterpret_cast<const uint32_t *>(d + off_t),
+                      reinterpret_cast<const uint32_t *>(d + off_o)};
+    return OI_OK;
+}
+
+// The fused result block [scores K | docs K | counts B] (contiguous in HBM) to the caller's three host arrays: one DMA into
+// the context's page-locked buffer, the stream synchronised, three host copies.
+int results_to_host(oi_ctx *ctx, const float *d_block, size_t K, uint32_t B, float *scores_out, uint32_t *docs_out,
+                    uint32_t *counts_out) {
+    const size_t bytes = (2 * K + B) * 4;
+    OI_CHECK(ctx->pin_out.ensure(bytes));
+    OI_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, d_block, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const uint8_t *h = ctx->pin_out.as<uint8_t>();
+    memcpy(scores_out, h, K * 4);
+    memcpy(docs_out, h + K * 4, K * 4);
+    memcpy(counts_out, h + 2 * K * 4, (size_t)B * 4);
     return OI_OK;
 }
 
@@ -1264,10 +1301,7 @@ extern "C" int oi_search(oi_index *idx, const float *qv, const uint32_t *qt, con
     uint32_t *d_do = reinterpret_cast<uint32_t *>(d_so + K), *d_co = d_do + K;
     OI_HIP_CHECK(hipMemsetAsync(f.p, 0, (2 * K + B) * 4, st));
     OI_CHECK(oi_launch_rrf(ctx, d_cd, d_cc, d_bd, d_bc, B, depth, k, d_so, d_do, d_co));
-    OI_HIP_CHECK(hipMemcpyAsync(scores_out, d_so, K * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipMemcpyAsync(docs_out, d_do, K * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipMemcpyAsync(counts_out, d_co, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipStreamSynchronize(st));
+    OI_CHECK(results_to_host(ctx, d_so, K, B, scores_out, docs_out, counts_out));
     return check_overflow_locked(ctx);
 }
 
@@ -1503,9 +1537,6 @@ extern "C" int oi_search_sharded(oi_index *idx, oi_comm *comm, const float *qv, 
     uint32_t *o_d = reinterpret_cast<uint32_t *>(o_s + K), *o_c = o_d + K;
     OI_HIP_CHECK(hipMemsetAsync(o_s, 0, (2 * K + B) * 4, st));
     OI_CHECK(fuse_packed_device(ctx, fl.as<uint32_t>(), comm->world, B, depth, k, o_s, o_d, o_c));
-    OI_HIP_CHECK(hipMemcpyAsync(scores_out, o_s, K * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipMemcpyAsync(docs_out, o_d, K * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipMemcpyAsync(counts_out, o_c, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipStreamSynchronize(st));
+    OI_CHECK(results_to_host(ctx, o_s, K, B, scores_out, docs_out, counts_out));
     return check_overflow_locked(ctx);
 }

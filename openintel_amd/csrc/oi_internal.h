@@ -75,6 +75,20 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Page-locked host staging of a context (the OI_HOST entry points of the query path): the caller's pageable arrays are
+// packed into it and moved with ONE DMA each way -- three pageable copies each way are staged by the runtime one after the
+// other.  Every OI_HOST call ends with a stream synchronise inside the ctx mutex, so a buffer is free again at the next call.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    int ensure(size_t bytes);
+    void release();
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct ProfSpan {
     hipEvent_t a, b;
 };
@@ -119,6 +133,8 @@ struct oi_ctx {
     bool use_graphs = false;          // oi_set_graph_replay
     std::vector<GraphEntry> graphs;   // <= OI_MAX_GRAPHS, least recently used evicted
     uint64_t graph_clock = 0, graph_replays = 0, graph_captures = 0;
+
+    PinBuf pin_in, pin_out;
 
     DevBuf &buf(const char *name) { return ws[name]; }
     void prof_begin(const char *tag);
