@@ -78,6 +78,7 @@ struct DevBuf {
 // Page-locked host staging of a context (the OI_HOST entry points of the query path): the caller's pageable arrays are
 // packed into it and moved with ONE DMA each way -- three pageable copies each way are staged by the runtime one after the
 // other.  Every OI_HOST call ends with a stream synchronise inside the ctx mutex, so a buffer is free again at the next call.
+#define OI_PINNED_STAGE_MAX ((size_t)1 << 20) // calls moving more than this use the caller's pageable arrays directly (measured: no gain above ~1 MB)
 struct PinBuf {
     void *p = nullptr;
     size_t cap = 0;
