@@ -446,6 +446,32 @@ extern "C" int oi_headline_scan(oi_ctx *ctx, const uint8_t *blob, const uint64_t
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // the dip gate's own call is a handful of headlines per ticker (dip.rs:617-626): like oi_lexicon_analyze, a small call
+    // goes through the page-locked buffers -- titles + offsets in one DMA, order | mask | about back in one
+    const size_t off_o = (bytes + 15) & ~(size_t)15, in_bytes = off_o + sizeof(uint64_t) * (n + 1);
+    const size_t out_m = sizeof(uint64_t) * n, out_a = out_m + sizeof(uint16_t) * n, out_bytes = out_a + n;
+    if (in_bytes <= OI_PINNED_STAGE_MAX) {
+        DevBuf &si = ctx->buf("hl_stage_in"), &so = ctx->buf("hl_stage_out");
+        OI_CHECK(si.ensure(in_bytes + 64));
+        OI_CHECK(so.ensure(out_bytes));
+        OI_CHECK(ctx->pin_in.ensure(in_bytes));
+        OI_CHECK(ctx->pin_out.ensure(out_bytes));
+        uint8_t *h = ctx->pin_in.as<uint8_t>();
+        if (bytes) memcpy(h, blob, bytes);
+        memcpy(h + off_o, offsets, sizeof(uint64_t) * (n + 1));
+        OI_HIP_CHECK(hipMemcpyAsync(si.p, h, in_bytes, hipMemcpyHostToDevice, st));
+        uint8_t *d = so.as<uint8_t>();
+        OI_CHECK(oi_launch_headline_scan(ctx, si.as<uint8_t>(), reinterpret_cast<const uint64_t *>(si.as<uint8_t>() + off_o), n,
+                                         bytes, ticker, ticker_len, forms_blob, form_offsets, n_forms,
+                                         reinterpret_cast<uint16_t *>(d + out_m), reinterpret_cast<uint64_t *>(d), d + out_a));
+        OI_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, so.p, out_bytes, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipStreamSynchronize(st));
+        const uint8_t *r = ctx->pin_out.as<uint8_t>();
+        memcpy(order_out, r, out_m);
+        memcpy(mask_out, r + out_m, sizeof(uint16_t) * n);
+        memcpy(about_out, r + out_a, n);
+        return OI_OK;
+    }
     DevBuf &b = ctx->buf("hl_blob"), &o = ctx->buf("hl_off"), &m = ctx->buf("hl_mask"), &r = ctx->buf("hl_order"),
            &a = ctx->buf("hl_about");
     OI_CHECK(b.ensure(bytes + 64));
@@ -516,27 +542,46 @@ extern "C" int oi_social_summary_segmented(oi_ctx *ctx, const uint8_t *sources, 
         return OI_ERR_ANALYZER_MISMATCH;
     }
     hipStream_t st = ctx->stream;
-    DevBuf &sb = ctx->buf("sum_src"), &p = ctx->buf("sum_pol"), &f = ctx->buf("sum_spec"), &so = ctx->buf("sum_seg"),
-           &ob = ctx->buf("sum_seg_out");
-    OI_CHECK(p.ensure(sizeof(double) * (n_posts + 1)));
-    OI_CHECK(f.ensure(n_posts + 1));
-    OI_CHECK(so.ensure(sizeof(uint64_t) * (n_segments + 1)));
-    OI_CHECK(ob.ensure(sizeof(oi_social_counters) * n_segments));
-    if (n_posts) {
-        OI_HIP_CHECK(hipMemcpyAsync(p.p, polarity, sizeof(double) * n_posts, hipMemcpyHostToDevice, st));
-        OI_HIP_CHECK(hipMemcpyAsync(f.p, speculative, n_posts, hipMemcpyHostToDevice, st));
+    // [polarity f64 | segment offsets u64 | speculative u8 | sources u8] in one buffer, one DMA for a call under 1 MB (a
+    // scan_watchlist call: a few thousand signals); the records come back in one
+    const size_t pb = sizeof(double) * n_posts, gb = sizeof(uint64_t) * (n_segments + 1);
+    const size_t off_g = pb, off_f = off_g + gb, off_s = off_f + ((n_posts + 15) & ~(size_t)15), in_bytes = off_s + n_posts + 16;
+    const size_t out_bytes = sizeof(oi_social_counters) * n_segments;
+    const bool pinned = in_bytes <= OI_PINNED_STAGE_MAX && out_bytes <= OI_PINNED_STAGE_MAX;
+    DevBuf &si = ctx->buf("sum_seg_in"), &ob = ctx->buf("sum_seg_out");
+    OI_CHECK(si.ensure(in_bytes));
+    OI_CHECK(ob.ensure(out_bytes));
+    uint8_t *d = si.as<uint8_t>();
+    if (pinned) {
+        OI_CHECK(ctx->pin_in.ensure(in_bytes));
+        OI_CHECK(ctx->pin_out.ensure(out_bytes));
+        uint8_t *h = ctx->pin_in.as<uint8_t>();
+        if (n_posts) {
+            memcpy(h, polarity, pb);
+            memcpy(h + off_f, speculative, n_posts);
+            if (sources) memcpy(h + off_s, sources, n_posts);
+        }
+        memcpy(h + off_g, seg_offsets, gb);
+        OI_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    } else {
+        if (n_posts) {
+            OI_HIP_CHECK(hipMemcpyAsync(d, polarity, pb, hipMemcpyHostToDevice, st));
+            OI_HIP_CHECK(hipMemcpyAsync(d + off_f, speculative, n_posts, hipMemcpyHostToDevice, st));
+            if (sources) OI_HIP_CHECK(hipMemcpyAsync(d + off_s, sources, n_posts, hipMemcpyHostToDevice, st));
+        }
+        OI_HIP_CHECK(hipMemcpyAsync(d + off_g, seg_offsets, gb, hipMemcpyHostToDevice, st));
     }
-    const uint8_t *dsrc = nullptr;
-    if (sources && n_posts) {
-        OI_CHECK(sb.ensure(n_posts));
-        OI_HIP_CHECK(hipMemcpyAsync(sb.p, sources, n_posts, hipMemcpyHostToDevice, st));
-        dsrc = sb.as<uint8_t>();
+    OI_CHECK(oi_launch_social_summary_segmented(ctx, sources && n_posts ? d + off_s : nullptr, reinterpret_cast<const double *>(d),
+                                                d + off_f, n_posts, reinterpret_cast<const uint64_t *>(d + off_g), n_segments, tau,
+                                                ob.as<oi_social_counters>()));
+    if (pinned) {
+        OI_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, ob.p, out_bytes, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipStreamSynchronize(st));
+        memcpy(out, ctx->pin_out.p, out_bytes);
+    } else {
+        OI_HIP_CHECK(hipMemcpyAsync(out, ob.p, out_bytes, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipStreamSynchronize(st));
     }
-    OI_HIP_CHECK(hipMemcpyAsync(so.p, seg_offsets, sizeof(uint64_t) * (n_segments + 1), hipMemcpyHostToDevice, st));
-    OI_CHECK(oi_launch_social_summary_segmented(ctx, dsrc, p.as<double>(), f.as<uint8_t>(), n_posts, so.as<uint64_t>(),
-                                                n_segments, tau, ob.as<oi_social_counters>()));
-    OI_HIP_CHECK(hipMemcpyAsync(out, ob.p, sizeof(oi_social_counters) * n_segments, hipMemcpyDeviceToHost, st));
-    OI_HIP_CHECK(hipStreamSynchronize(st));
     return OI_OK;
 }
 
