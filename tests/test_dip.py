@@ -196,6 +196,40 @@ def test_heavy_tailed_lengths_at_the_window_limit_gpu(scanner):
 
 
 @pytest_gpu
+def test_headline_fuzz_against_the_oracle_gpu(scanner):
+    """Random titles over an alphabet that is hostile to the scan -- every keyword, its near misses and other cases, the
+    company's words in and out of order, separators of every kind (none at all included: titles touch in the blob),
+    multi-byte chars, digits -- in three densities: ordinary, candidate-dense (a wave's keyword ring and pattern ring
+    both fill and are verified in the loop) and hit-dense (more keyword hits than list nodes: the tile is redone one lane
+    per title); several tickers / name forms per seed, bit for bit against the oracle."""
+    kw = list(scanner.keywords)
+    near = [w[:-1] for w in kw] + [w + "s" for w in kw] + [w.upper() for w in kw] + [w.capitalize() for w in kw] + \
+           ["x" + w for w in kw]
+    company = ["ultra", "clean", "ultra clean", "Ultra Clean", "ULTRA  CLEAN", "ultraclean", "clean ultra", "uctt", "UCTT", "uctt2",
+               "brk", "b", "BRK.B", "holdings", "ultra clean holdings"]
+    filler = ["the", "stock", "up", "q3", "2026", "a", "of", "é", "\U0001F680", "\u4e2a", "x" * 13, "y" * 14, "z" * 40, "to", "in"]
+    seps = [" ", " ", " ", " ", "", ".", ", ", "\n", "\t", "-", "'", "  ", "$", "\u2014", "/", "_", "\x00", ": "]
+    cases = [("UCTT", ["ultra clean"]), ("BRK.B", ["brk b", "", "holdings"]), ("U", ["ultra clean holdings", "clean"]),
+             ("", []), ("uctt", ["x" * 13 + " the", "é", "a of"])]
+    for seed in range(8):
+        rng = np.random.default_rng(2000 + seed)
+        density = ("ordinary", "candidates", "hits")[seed % 3]
+        pieces = {"ordinary": kw + near + company + filler * 6,
+                  "candidates": kw * 4 + near * 2 + company * 4 + filler,
+                  "hits": kw * 12 + company * 2 + filler}[density]
+        titles = []
+        for _ in range(int(rng.integers(300, 2500))):
+            kind = rng.random()
+            n_tok = 0 if kind < 0.05 else int(rng.integers(1, 4)) if kind < 0.3 else int(rng.integers(4, 30)) if kind < 0.985 \
+                else int(rng.integers(300, 1500))
+            ids = rng.integers(0, len(pieces), size=n_tok)
+            sp = rng.integers(0, len(seps), size=n_tok)
+            titles.append("".join(pieces[i] + seps[j] for i, j in zip(ids, sp)))
+        for ticker, forms in cases[seed % 2::2] if seed % 4 else cases:
+            _check_scan(scanner, titles, ticker, forms)
+
+
+@pytest_gpu
 def test_device_buffers_and_limits_gpu(scanner):
     import torch
     from oracle import lib
