@@ -2,8 +2,10 @@
 
 Host mirror of the reference's batch tools (paths relative to the openintel repo):
 
+    run_list_sources                               src/mcp/tools.rs:23-37
     request_from                                   src/mcp/tools.rs:71-96
     summarize                                      src/mcp/tools.rs:99-108
+    AnalyzeOutput / run_analyze (no dip deps)      src/mcp/tools.rs:53-66, 110-162
     ScanArgs / ScanEntry / ScanOutput / run_scan   src/mcp/tools.rs:163-225
     RankBy / CompareArgs / RankedEntry / CompareError / CompareOutput
     rank_metric / sort_ranked / run_compare        src/mcp/tools.rs:227-352
@@ -56,6 +58,33 @@ def summarize(report: SpeculationReport) -> str:
     return "%s — %s · crowding %.0f%% · %d mentions (%s)" % (
         report.ticker.as_str(), _debug_name(report.fusion.alignment), report.fusion.crowding * 100.0,
         report.social.total_mentions, _debug_name(report.social_confidence))
+
+
+# ----------------------------------------------------------------------------- list_sources / analyze_ticker
+def run_list_sources(social_sources: Sequence[SocialDataSource], market_source: MarketDataSource) -> dict:
+    """tools.rs:23-37: the data sources actually wired (`social` reflects the injected list, not SourceKind::ALL)."""
+    return {"social": [s.kind().as_str() for s in social_sources], "market": [market_source.name()]}
+
+
+@dataclass
+class AnalyzeOutput:  # tools.rs:53-66; dip_signal / dip_note need the dip dependencies (bars, filings, news: out of scope)
+    summary: str
+    report: SpeculationReport
+    dip_signal: Optional[object] = None
+    dip_note: Optional[str] = None
+    disclaimer: str = DISCLAIMER
+
+
+def run_analyze(ticker: str, social_sources: Sequence[SocialDataSource], market_source: MarketDataSource,
+                analyzer: PostAnalyzer, enable_reddit: Optional[bool] = None, enable_bluesky: Optional[bool] = None,
+                no_market: Optional[bool] = None, limit: Optional[int] = None,
+                now: Optional[_dt.datetime] = None) -> AnalyzeOutput:
+    """tools.rs:110-162 without the dip attachment (`dip_deps = None`: the reference's own default in its tests, :676-696):
+    one ticker, the report and its one-line gloss.  Raises the DomainError the reference returns as Err."""
+    from .application import analyze
+    req = request_from(ticker, enable_reddit, enable_bluesky, no_market, limit)
+    report = analyze(req, social_sources, market_source, analyzer, now=now)
+    return AnalyzeOutput(summary=summarize(report), report=report)
 
 
 # ----------------------------------------------------------------------------- the pooled analysis

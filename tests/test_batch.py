@@ -164,6 +164,21 @@ def test_request_from_defaults_and_flags():
     assert r.enabled_sources == [SourceKind.REDDIT, SourceKind.BLUESKY]
 
 
+def test_list_sources_and_single_ticker_tool(golden):
+    from openintel_amd.domain import InvalidTicker
+    market = MockMarketSource(golden["mock_market"])
+    # tools.rs:668-673 list_sources_reports_all_adapters
+    out = batch.run_list_sources(fixture_social(golden), market)
+    assert out == {"social": ["reddit", "bluesky"], "market": ["mock-market"]}
+    # tools.rs:676-696 run_analyze_returns_confirming_bullish_report
+    res = batch.run_analyze("AAPL", fixture_social(golden), market, OracleAnalyzer(), now=NOW)
+    assert "ConfirmingBullish" in res.summary and res.report.social.total_mentions == 10
+    assert res.dip_signal is None and "Not financial advice" in res.disclaimer  # mock market is UP +4 %: no dip signal
+    # tools.rs:698-713 run_analyze_rejects_bad_ticker
+    with pytest.raises(InvalidTicker):
+        batch.run_analyze("$$$", fixture_social(golden), market, OracleAnalyzer())
+
+
 def test_tools_reference_cases_with_the_oracle(golden):
     check_tools(golden, OracleAnalyzer())
     check_tools(golden, OracleSegmentAnalyzer())
