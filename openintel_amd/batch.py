@@ -28,7 +28,7 @@ import datetime as _dt
 import enum
 import functools
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 from .analyzer import PostAnalyzer, counters_record
