@@ -61,12 +61,22 @@ int PinBuf::ensure(size_t bytes) {
     if (bytes <= cap) return OI_OK;
     release();
     const size_t want = (bytes + 4095) & ~(size_t)4095;
-    OI_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) {
+        pinned = true;
+    } else { // no page-locked memory to be had (a locked-memory limit): pageable staging -- the same calls, staged by the runtime
+        (void)hipGetLastError();
+        p = aligned_alloc(4096, want);
+        pinned = false;
+        if (!p) { oi_set_error("host staging buffer: out of memory (%zu bytes)", want); return OI_ERR_HIP; }
+    }
     cap = want;
     return OI_OK;
 }
 void PinBuf::release() {
-    if (p) (void)hipHostFree(p);
+    if (p) {
+        if (pinned) (void)hipHostFree(p);
+        else free(p);
+    }
     p = nullptr;
     cap = 0;
 }

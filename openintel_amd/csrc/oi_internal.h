@@ -82,6 +82,7 @@ struct DevBuf {
 struct PinBuf {
     void *p = nullptr;
     size_t cap = 0;
+    bool pinned = false; // false: hipHostMalloc refused, plain memory stands in (slower copies, same results)
     PinBuf() = default;
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
