@@ -9,6 +9,7 @@ Host mirror of the reference's batch tools (paths relative to the openintel repo
     ScanArgs / ScanEntry / ScanOutput / run_scan   src/mcp/tools.rs:163-225
     RankBy / CompareArgs / RankedEntry / CompareError / CompareOutput
     rank_metric / sort_ranked / run_compare        src/mcp/tools.rs:227-352
+    SentimentSummary / sentiment_for (per dip row) src/domain/dip.rs:428-431, src/application/dip.rs:175-194
 
 The reference runs `application::analyze` once per ticker (`join_all`, tools.rs:206-220) and never pools posts of
 different tickers: each ticker's few dozen posts go through their own `LexiconAnalyzer::analyze`.  On the GPU the batch
@@ -145,6 +146,32 @@ def analyze_many(requests: Sequence[AnalysisRequest], social_sources: Sequence[S
         except DomainError as e:
             results[i] = e
     return results
+
+
+# ----------------------------------------------------------------------------- the dip screen's sentiment step
+SOCIAL_LIMIT = 50  # application/dip.rs:44
+
+
+@dataclass
+class SentimentSummary:  # domain/dip.rs:428-431
+    net_sentiment: float
+    mentions: int
+
+
+def sentiments_for(tickers: Sequence[str], social_sources: Sequence[SocialDataSource], analyzer: PostAnalyzer,
+                   now: Optional[_dt.datetime] = None) -> List[Optional[SentimentSummary]]:
+    """`sentiment_for` (application/dip.rs:175-194) for every row of a dip scan at once: the social-only analysis the
+    screen runs per loser (all sources, no market, limit 50), pooled like run_scan.  Any failure -- no sources, an invalid
+    ticker, no posts -- degrades to None, as in the reference (the domain then scores divergence 0 with a note)."""
+    if not social_sources:
+        return [None] * len(tickers)
+    reqs = [AnalysisRequest(ticker=t, enabled_sources=list(SourceKind.ALL), market_enabled=False, limit=SOCIAL_LIMIT,
+                            engine=EngineConfig()) for t in tickers]
+    out: List[Optional[SentimentSummary]] = []
+    for res in analyze_many(reqs, social_sources, None, analyzer, now):
+        out.append(None if isinstance(res, DomainError) else
+                   SentimentSummary(net_sentiment=float(res.social.net_sentiment), mentions=int(res.social.total_mentions)))
+    return out
 
 
 # ----------------------------------------------------------------------------- scan_watchlist

@@ -179,6 +179,28 @@ def test_list_sources_and_single_ticker_tool(golden):
         batch.run_analyze("$$$", fixture_social(golden), market, OracleAnalyzer())
 
 
+def test_dip_rows_sentiment_is_the_single_ticker_analysis(golden):
+    """application/dip.rs:175-194: social-only, all sources, limit 50; any failure is None.  Pooled over the rows of a scan
+    it equals the ticker-by-ticker analysis."""
+    social = [TickerSource(SourceKind.REDDIT, 1, fail_for=("GME",)), TickerSource(SourceKind.BLUESKY, 2, fail_for=("GME",))]
+    rows = ["AAPL", "GME", "$$$", "TSLA", "F"]
+    for analyzer in (OracleAnalyzer(), OracleSegmentAnalyzer()):
+        got = batch.sentiments_for(rows, social, analyzer, now=NOW)
+        assert got[1] is None and got[2] is None  # every source failed -> NoData; invalid ticker
+        for t, g in zip(rows, got):
+            rq = app.AnalysisRequest(ticker=t, enabled_sources=list(SourceKind.ALL), market_enabled=False, limit=50)
+            try:
+                rep = app.analyze(rq, social, None, OracleAnalyzer(), now=NOW)
+            except DomainError:
+                assert g is None
+                continue
+            assert g == batch.SentimentSummary(float(rep.social.net_sentiment), rep.social.total_mentions)
+    assert batch.sentiments_for(rows, [], OracleAnalyzer()) == [None] * 5  # dip.rs:179-181
+    # the fixture: 10 posts, net 0.5 (tests/golden: the reference's own numbers)
+    s = batch.sentiments_for(["AAPL"], fixture_social(golden), OracleAnalyzer())[0]
+    assert s.mentions == 10 and s.net_sentiment == 0.5
+
+
 def test_tools_reference_cases_with_the_oracle(golden):
     check_tools(golden, OracleAnalyzer())
     check_tools(golden, OracleSegmentAnalyzer())
