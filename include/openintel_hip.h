@@ -235,6 +235,17 @@ int oi_headline_scan_device(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
                             const uint32_t *form_offsets, uint32_t n_forms, uint16_t *d_mask_out,
                             uint64_t *d_order_out, uint8_t *d_about_out);
 
+/* The gate over the ROWS of a dip scan (src/application/dip.rs: one `check` per loser -> domain/dip.rs:612-659 on that
+ * row's headlines, ticker and name forms).  Row r owns titles [row_offsets[r], row_offsets[r+1]) (row_offsets[0] = 0,
+ * row_offsets[n_rows] = n_titles), ticker tickers_blob[ticker_offsets[r] .. ticker_offsets[r+1]) and name forms
+ * row_form_offsets[r] .. row_form_offsets[r+1] (indices into form_offsets, which holds total_forms + 1 byte offsets into
+ * forms_blob).  Outputs as oi_headline_scan, index-aligned with the titles.  Host buffers; one staging copy, one launch
+ * per row back to back, one copy back -- a 25-row scan costs about what four single-row calls do.  At most 4096 rows. */
+int oi_headline_scan_rows(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n_titles,
+                          const uint64_t *row_offsets, uint32_t n_rows, const uint8_t *tickers_blob,
+                          const uint32_t *ticker_offsets, const uint8_t *forms_blob, const uint32_t *form_offsets,
+                          const uint32_t *row_form_offsets, uint16_t *mask_out, uint64_t *order_out, uint8_t *about_out);
+
 /* ------------------------------------------------------------------------- */
 /* Hybrid retrieval (builder-defined; parity unpinned vs the reference)        */
 /* ------------------------------------------------------------------------- */

@@ -76,6 +76,11 @@ extern "C" {
     pub fn oi_headline_scan(ctx: *mut OiCtx, blob: *const u8, offsets: *const u64, n_titles: u64, ticker: *const u8,
                             ticker_len: u64, forms_blob: *const u8, form_offsets: *const u32, n_forms: u32,
                             mask_out: *mut u16, order_out: *mut u64, about_out: *mut u8) -> c_int;
+    pub fn oi_headline_scan_rows(ctx: *mut OiCtx, blob: *const u8, offsets: *const u64, n_titles: u64,
+                                 row_offsets: *const u64, n_rows: u32, tickers_blob: *const u8,
+                                 ticker_offsets: *const u32, forms_blob: *const u8, form_offsets: *const u32,
+                                 row_form_offsets: *const u32, mask_out: *mut u16, order_out: *mut u64,
+                                 about_out: *mut u8) -> c_int;
     pub fn oi_headline_scan_device(ctx: *mut OiCtx, d_blob: *const u8, d_offsets: *const u64, n_titles: u64,
                                    blob_bytes: u64, ticker: *const u8, ticker_len: u64, forms_blob: *const u8,
                                    form_offsets: *const u32, n_forms: u32, d_mask_out: *mut u16,

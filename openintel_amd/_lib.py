@@ -70,6 +70,7 @@ SIGNATURES = {
     "oi_catalyst_keyword": (C.c_char_p, [_U32]),
     "oi_headline_scan": (_I, [_P, _P, _P, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
     "oi_headline_scan_device": (_I, [_P, _P, _P, _U64, _U64, _P, _U64, _P, _P, _U32, _P, _P, _P]),
+    "oi_headline_scan_rows": (_I, [_P, _P, _P, _U64, _P, _U32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "oi_social_summary": (_I, [_P, _P, _U64, _P, _P, _U64, C.c_double, _I, C.POINTER(SocialCounters)]),
     "oi_social_summary_segmented": (_I, [_P, _P, _P, _P, _U64, _P, _U64, C.c_double, _I, _P]),
     "oi_lexicon_scan_segments_device": (_I, [_P, _P, _P, _U64, _U64, _P, _P, _U64, C.c_double, _P, _P, _P]),

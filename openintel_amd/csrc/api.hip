@@ -500,6 +500,74 @@ extern "C" int oi_headline_scan(oi_ctx *ctx, const uint8_t *blob, const uint64_t
     return OI_OK;
 }
 
+// The dip screen's headline gate over the ROWS of a scan (application/dip.rs: one `check` per loser, each calling the gate
+// of domain/dip.rs:612-659 on its own headlines with its own ticker and name forms): one staging copy of all titles, one
+// launch per row back to back on the stream, one copy back, one synchronise.
+extern "C" int oi_headline_scan_rows(oi_ctx *ctx, const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                                     const uint64_t *row_offsets, uint32_t n_rows, const uint8_t *tickers_blob,
+                                     const uint32_t *ticker_offsets, const uint8_t *forms_blob, const uint32_t *form_offsets,
+                                     const uint32_t *row_form_offsets, uint16_t *mask_out, uint64_t *order_out,
+                                     uint8_t *about_out) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    if (n_rows == 0) return OI_OK;
+    OI_REQUIRE(n_rows <= 4096, "headline rows: at most 4096 rows per call (%u given)", n_rows);
+    OI_REQUIRE(row_offsets && ticker_offsets && row_form_offsets, "headline rows: null row table");
+    OI_REQUIRE(row_offsets[0] == 0 && row_offsets[n_rows] == n, "headline rows: the rows must cover titles [0, %llu)",
+               (unsigned long long)n);
+    for (uint32_t r = 0; r < n_rows; ++r)
+        OI_REQUIRE(row_offsets[r] <= row_offsets[r + 1] && ticker_offsets[r] <= ticker_offsets[r + 1] &&
+                       row_form_offsets[r] <= row_form_offsets[r + 1],
+                   "headline rows: row %u has descending offsets", r);
+    OI_REQUIRE(tickers_blob || ticker_offsets[n_rows] == 0, "headline rows: null tickers");
+    OI_REQUIRE(row_form_offsets[n_rows] == 0 || (forms_blob && form_offsets), "headline rows: null forms");
+    if (n == 0) return OI_OK;
+    OI_REQUIRE(offsets && mask_out && order_out && about_out, "headline rows: null buffer");
+    OI_REQUIRE(offsets[0] == 0, "headline rows: offsets[0] must be 0");
+    const uint64_t bytes = offsets[n];
+    OI_REQUIRE(blob || bytes == 0, "headline rows: null title blob");
+    for (uint64_t i = 0; i < n; ++i)
+        OI_REQUIRE(offsets[i + 1] >= offsets[i] && offsets[i + 1] - offsets[i] < (1ull << 32),
+                   "headline rows: offsets must ascend and a title must be shorter than 4 GiB");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // staging: [titles | offsets | one table set per row] in, [order | mask | about] out
+    const size_t pb = oi_headline_params_bytes();
+    const size_t off_o = (bytes + 15) & ~(size_t)15, off_p = (off_o + sizeof(uint64_t) * (n + 1) + 15) & ~(size_t)15;
+    const size_t in_bytes = off_p + pb * n_rows;
+    const size_t out_m = sizeof(uint64_t) * n, out_a = out_m + sizeof(uint16_t) * n, out_bytes = out_a + n;
+    DevBuf &si = ctx->buf("hl_rows_in"), &so = ctx->buf("hl_rows_out");
+    OI_CHECK(si.ensure(in_bytes + 64));
+    OI_CHECK(so.ensure(out_bytes));
+    OI_CHECK(ctx->pin_in.ensure(in_bytes));
+    OI_CHECK(ctx->pin_out.ensure(out_bytes));
+    uint8_t *h = ctx->pin_in.as<uint8_t>();
+    if (bytes) memcpy(h, blob, bytes);
+    memcpy(h + off_o, offsets, sizeof(uint64_t) * (n + 1));
+    for (uint32_t r = 0; r < n_rows; ++r)
+        OI_CHECK(oi_headline_build_params(h + off_p + pb * r, tickers_blob ? tickers_blob + ticker_offsets[r] : nullptr,
+                                          ticker_offsets[r + 1] - ticker_offsets[r], forms_blob,
+                                          form_offsets ? form_offsets + row_form_offsets[r] : nullptr,
+                                          row_form_offsets[r + 1] - row_form_offsets[r]));
+    OI_HIP_CHECK(hipMemcpyAsync(si.p, h, in_bytes, hipMemcpyHostToDevice, st));
+    uint8_t *d = si.as<uint8_t>(), *o = so.as<uint8_t>();
+    const uint64_t *d_offs = reinterpret_cast<const uint64_t *>(d + off_o);
+    for (uint32_t r = 0; r < n_rows; ++r) {
+        const uint64_t t0 = row_offsets[r], t1 = row_offsets[r + 1];
+        if (t1 == t0) continue;
+        OI_CHECK(oi_launch_headline_scan_params(ctx, d, d_offs + t0, t1 - t0, bytes, offsets[t1] - offsets[t0], d + off_p + pb * r,
+                                                reinterpret_cast<uint16_t *>(o + out_m) + t0,
+                                                reinterpret_cast<uint64_t *>(o) + t0, o + out_a + t0));
+    }
+    OI_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, so.p, out_bytes, hipMemcpyDeviceToHost, st));
+    OI_HIP_CHECK(hipStreamSynchronize(st));
+    const uint8_t *rr = ctx->pin_out.as<uint8_t>();
+    memcpy(order_out, rr, out_m);
+    memcpy(mask_out, rr + out_m, sizeof(uint16_t) * n);
+    memcpy(about_out, rr + out_a, n);
+    return OI_OK;
+}
+
 extern "C" int oi_social_summary(oi_ctx *ctx, const uint8_t *sources, uint64_t n_posts, const double *polarity,
                                  const uint8_t *speculative, uint64_t n_signals, double tau, int location,
                                  oi_social_counters *out) {

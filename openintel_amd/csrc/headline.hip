@@ -689,16 +689,33 @@ static int hl_build_params(HlParams &prm, const uint8_t *ticker, uint64_t ticker
     return OI_OK;
 }
 
+// The per-call tables are opaque outside this file: their size, and a builder into caller memory (oi_headline_scan_rows
+// builds one per row of a dip scan into one staging buffer).
+size_t oi_headline_params_bytes() { return sizeof(HlParams); }
+int oi_headline_build_params(void *dst, const uint8_t *ticker, uint64_t ticker_len, const uint8_t *forms_blob,
+                             const uint32_t *form_offsets, uint32_t n_forms) {
+    return hl_build_params(*reinterpret_cast<HlParams *>(dst), ticker, ticker_len, forms_blob, form_offsets, n_forms);
+}
+
 int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
                             uint64_t blob_bytes, const uint8_t *ticker, uint64_t ticker_len,
                             const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms,
                             uint16_t *d_mask, uint64_t *d_order, uint8_t *d_about) {
-    OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "headline scan: title blob must be 16-byte aligned in HBM");
     static thread_local HlParams prm; // staged synchronously by the pageable copy below
     OI_CHECK(hl_build_params(prm, ticker, ticker_len, forms_blob, form_offsets, n_forms));
     DevBuf &dp = ctx->buf("hl_params");
     OI_CHECK(dp.ensure(sizeof(HlParams)));
     OI_HIP_CHECK(hipMemcpyAsync(dp.p, &prm, sizeof(HlParams), hipMemcpyHostToDevice, ctx->stream));
+    return oi_launch_headline_scan_params(ctx, d_blob, d_offsets, n, blob_bytes, blob_bytes, dp.p, d_mask, d_order, d_about);
+}
+
+// The scan of titles [0, n) of `d_offsets` (absolute byte offsets into d_blob: a sub-range of a larger batch works, its
+// offsets pointer advanced) with tables already in HBM.  text_bytes: the bytes of these n titles, for the tile choice.
+int oi_launch_headline_scan_params(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                                   uint64_t blob_bytes, uint64_t text_bytes, const void *d_params, uint16_t *d_mask,
+                                   uint64_t *d_order, uint8_t *d_about) {
+    OI_REQUIRE(((uintptr_t)d_blob & 15u) == 0, "headline scan: title blob must be 16-byte aligned in HBM");
+    const HlParams *dpp = reinterpret_cast<const HlParams *>(d_params);
     // titles per workgroup: the largest tile whose average bytes fill at most 7/8 of the LDS window.  The cost per
     // workgroup is largely fixed per wave (one partial verify batch, three barriers, two dependent HBM round trips),
     // so the time falls with the tile (10M titles of 76 bytes: 192 -> 0.664 ms, 224 -> 0.63, 256 -> 0.585); a tile
@@ -706,7 +723,7 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     // titles a tile is 14 % over its average only if the mean of 256 lengths is, > 4 sigma for sigma = mean / 2.
     static const uint32_t kTiles[] = {256, 224, 192, 160, 128, 96, 64, 48, 32, 16, 8};
     static const uint32_t forced = oi_ablation_env("OI_HEADLINE_TILE") ? (uint32_t)atoi(oi_ablation_env("OI_HEADLINE_TILE")) : 0u;
-    const uint64_t avg = blob_bytes / n + 1;
+    const uint64_t avg = text_bytes / n + 1;
     uint32_t tile = 8;
     for (uint32_t t : kTiles)
         if (avg * t <= (HL_WIN_BYTES * 7) / 8) { tile = t; break; }
@@ -726,13 +743,13 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     ctx->prof_begin("headline");
     if (v1)
         hipLaunchKernelGGL(headline_scan_kernel_v1, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                           dp.as<HlParams>(), d_mask, d_order, d_about);
+                           dpp, d_mask, d_order, d_about);
     else if (d_timing)
         hipLaunchKernelGGL(headline_scan_kernel<true>, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets,
-                           n, blob_bytes, tile, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
+                           n, blob_bytes, tile, dpp, d_mask, d_order, d_about, dbg, d_timing);
     else
         hipLaunchKernelGGL(headline_scan_kernel<false>, dim3(grid), dim3(HL_THREADS), 0, ctx->stream, d_blob, d_offsets,
-                           n, blob_bytes, tile, dp.as<HlParams>(), d_mask, d_order, d_about, dbg, d_timing);
+                           n, blob_bytes, tile, dpp, d_mask, d_order, d_about, dbg, d_timing);
     ctx->prof_end("headline");
     OI_HIP_CHECK(hipGetLastError());
     if (d_timing) {

@@ -216,6 +216,12 @@ int oi_launch_headline_scan(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
                             uint64_t blob_bytes, const uint8_t *ticker, uint64_t ticker_len,
                             const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms,
                             uint16_t *d_mask, uint64_t *d_order, uint8_t *d_about);
+size_t oi_headline_params_bytes();
+int oi_headline_build_params(void *dst, const uint8_t *ticker, uint64_t ticker_len, const uint8_t *forms_blob,
+                             const uint32_t *form_offsets, uint32_t n_forms);
+int oi_launch_headline_scan_params(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *d_offsets, uint64_t n,
+                                   uint64_t blob_bytes, uint64_t text_bytes, const void *d_params, uint16_t *d_mask,
+                                   uint64_t *d_order, uint8_t *d_about);
 // select.hip
 // Candidate pools, one per query, never touched by a global atomic in the batch kernels:
 //   keys[q*stride + 0 .. carry_cap)                    the top-k carried over from earlier corpus chunks

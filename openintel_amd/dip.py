@@ -129,6 +129,37 @@ class HeadlineScanner:
         blob, offs = pack_posts(titles)
         return self.scan_packed(blob, offs, ticker, name_forms)
 
+    def scan_rows(self, rows: Sequence[Tuple[Sequence[str], str, Sequence[str]]]):
+        """The rows of a dip scan in ONE call (oi_headline_scan_rows): rows[r] = (titles, ticker, name_forms).  Returns, per
+        row, what `scan(titles, ticker, name_forms)` returns -- (mask u16[n_r], order u64[n_r], about u8[n_r])."""
+        titles = [t for r in rows for t in r[0]]
+        blob, offs = pack_posts(titles)
+        row_off = np.zeros(len(rows) + 1, dtype=np.uint64)
+        tick_off = np.zeros(len(rows) + 1, dtype=np.uint32)
+        rform_off = np.zeros(len(rows) + 1, dtype=np.uint32)
+        tickers, forms = [], []
+        for i, (ts, ticker, name_forms) in enumerate(rows):
+            tb = ticker.encode("utf-8")
+            tickers.append(tb)
+            forms.extend(name_forms)
+            row_off[i + 1] = row_off[i] + len(ts)
+            tick_off[i + 1] = tick_off[i] + len(tb)
+            rform_off[i + 1] = rform_off[i] + len(name_forms)
+        tblob = np.frombuffer(b"".join(tickers) + b"\0", dtype=np.uint8)
+        fblob, foffs = pack_forms(forms)
+        n = len(titles)
+        mask, order, about = np.zeros(n, np.uint16), np.zeros(n, np.uint64), np.zeros(n, np.uint8)
+        if rows:
+            _lib.check(self.ctx.lib.oi_headline_scan_rows(
+                self.ctx.handle, _lib.ptr(blob) if blob.size else None, _lib.ptr(offs), n, _lib.ptr(row_off), len(rows),
+                _lib.ptr(tblob), _lib.ptr(tick_off), _lib.ptr(fblob), _lib.ptr(foffs), _lib.ptr(rform_off),
+                _lib.ptr(mask), _lib.ptr(order), _lib.ptr(about)))
+        out = []
+        for i in range(len(rows)):
+            a, b = int(row_off[i]), int(row_off[i + 1])
+            out.append((mask[a:b], order[a:b], about[a:b]))
+        return out
+
     # ------------------------------------------------------------------ reference API
     def catalyst_hits(self, texts: Sequence[str]) -> List[str]:
         """dip.rs:261-272: hits across the texts, deduped, first-occurrence order."""
@@ -173,6 +204,26 @@ def no_catalyst_headline(scanner: HeadlineScanner, ticker: str, company_names: S
         return GateStatus("unknown", unavailable_reason), []
     name_forms = company_name_forms(company_names)  # blank/junk names derive no forms -> strict path
     mask, order, about = scanner.scan([h.title for h in headlines], ticker, name_forms)
+    return _gate_from_scan(scanner, ticker, name_forms, headlines, mask, order, about)
+
+
+def no_catalyst_headline_rows(scanner: HeadlineScanner, rows) -> List[Tuple[GateStatus, List[str]]]:
+    """The gate for every row of a dip scan (application/dip.rs: `check` per loser) with ONE scan call for all rows'
+    headlines.  rows[r] = (ticker, company_names, headlines or None, unavailable_reason); the result per row is what
+    `no_catalyst_headline` returns for it."""
+    live = [(i, t, company_name_forms(names), hs) for i, (t, names, hs, _) in enumerate(rows) if hs is not None]
+    scans = scanner.scan_rows([([h.title for h in hs], t, forms) for _, t, forms, hs in live]) if live else []
+    out: List[Optional[Tuple[GateStatus, List[str]]]] = [None] * len(rows)
+    for (i, t, forms, hs), (mask, order, about) in zip(live, scans):
+        out[i] = _gate_from_scan(scanner, t, forms, hs, mask, order, about)
+    for i, (_, _, hs, why) in enumerate(rows):
+        if hs is None:
+            out[i] = (GateStatus("unknown", why), [])
+    return out
+
+
+def _gate_from_scan(scanner: HeadlineScanner, ticker: str, name_forms: Sequence[str], headlines: Sequence[Headline],
+                    mask, order, about) -> Tuple[GateStatus, List[str]]:
     evidence: List[str] = []
     matched: List[str] = []
     unmatched: List[str] = []

@@ -25,6 +25,9 @@ class OracleScanner:
         blob, offs = pack_posts(titles)
         return self.lib.headline_scan(blob, offs, ticker, name_forms)
 
+    def scan_rows(self, rows):  # the reference's loop: one scan per row (application/dip.rs `check` per loser)
+        return [self.scan(ts, ticker, forms) for ts, ticker, forms in rows]
+
 
 def _gate_cases(golden, scanner):
     for c in golden["dip"]["gate"]:
@@ -52,7 +55,28 @@ def _gate_cases(golden, scanner):
     assert st == dip.GateStatus("unknown", "news feed down") and ev == []
 
 
+def _gate_rows(golden, scanner):
+    """The gate over the rows of a scan, one scan call for all of them, equals the gate row by row -- on the reference's
+    own gate cases as the rows, plus an unavailable feed, a row without headlines and a row without a company name."""
+    rows = [(c["ticker"], c["company_names"], [dip.Headline(title=t, publisher=p) for p, t in c["headlines"]], "")
+            for c in golden["dip"]["gate"]]
+    rows.insert(2, ("VIK", [], None, "news feed down"))
+    rows.append(("ZZZ", ["Zed Corp"], [], ""))
+    rows.append(("UCTT", [], [dip.Headline("UCTT guidance cut", "Wire"), dip.Headline("fraud probe at rival", "X")], ""))
+    got = dip.no_catalyst_headline_rows(scanner, rows)
+    assert len(got) == len(rows)
+    for (ticker, names, hs, why), g in zip(rows, got):
+        assert g == dip.no_catalyst_headline(scanner, ticker, names, hs, unavailable_reason=why), ticker
+    assert got[2] == (dip.GateStatus("unknown", "news feed down"), [])
+    assert dip.no_catalyst_headline_rows(scanner, []) == []
+
+
 # ----------------------------------------------------------------------------- CPU
+def test_gate_over_rows_with_oracle_scanner(golden):
+    _gate_rows(golden, OracleScanner())
+
+
+
 def test_oracle_matches_reference_vectors(golden):
     from oracle import lib, pyref
     g = golden["dip"]
@@ -129,6 +153,39 @@ def test_reference_vectors_gpu(golden, scanner):
     for c in g["headline_mentions_company"]:
         assert scanner.headline_mentions_company(c["title"], c["ticker"], c["forms"]) is c["expect"], c
     _gate_cases(golden, scanner)
+
+
+@pytest_gpu
+def test_gate_over_rows_gpu(golden, scanner):
+    _gate_rows(golden, scanner)
+
+
+@pytest_gpu
+def test_scan_rows_equals_row_by_row_and_the_oracle_gpu(scanner):
+    """oi_headline_scan_rows: 40 rows of 0..60 titles, each with its own ticker and name forms (some without forms, one
+    with an empty ticker, long rows next to empty ones) -- per row identical to oi_headline_scan and to the oracle."""
+    from oracle import lib
+    rng = np.random.default_rng(7)
+    base = synth.headlines_np(3000, seed=27)
+    companies = [("UCTT", ["ultra clean"]), ("BRK.B", ["brk b", "holdings"]), ("U", []), ("", ["ultra clean holdings"]),
+                 ("VIK", dip.company_name_forms(["Viking Holdings Ltd"])), ("earnings", ["miss guidance"])]
+    rows, at = [], 0
+    for r in range(40):
+        k = 0 if r % 9 == 4 else int(rng.integers(1, 60)) if r != 17 else 700
+        ticker, forms = companies[r % len(companies)]
+        rows.append((base[at:at + k], ticker, forms))
+        at += k
+    got = scanner.scan_rows(rows)
+    assert len(got) == len(rows)
+    for (titles, ticker, forms), (m, o, a) in zip(rows, got):
+        blob, offs = pack_posts(titles)
+        rm, ro, ra = lib.headline_scan(blob, offs, ticker, forms)
+        assert np.array_equal(m, rm) and np.array_equal(o, ro) and np.array_equal(a, ra), (ticker, len(titles))
+        sm, so_, sa = scanner.scan(titles, ticker, forms)
+        assert np.array_equal(m, sm) and np.array_equal(o, so_) and np.array_equal(a, sa)
+    assert scanner.scan_rows([]) == []
+    one = scanner.scan_rows([([], "UCTT", ["ultra clean"])])
+    assert len(one) == 1 and one[0][0].size == 0
 
 
 @pytest_gpu

@@ -61,4 +61,19 @@ for n in (10, 100, 1000):  # the dip gate's call: a ticker's headlines (dip.rs:6
         ts.append((time.perf_counter() - t0) * 1e6)
     ts.sort()
     res["titles_%d" % n] = {"median_us": round(ts[len(ts) // 2], 1), "min_us": round(ts[0], 1), "bytes": int(blob.size)}
+rows = [(synth.headlines_np(8, seed=40 + r), synth.HEADLINE_TICKER, forms) for r in range(25)]  # a dip scan: 25 rows x 8 titles
+for _ in range(5):
+    sc.scan_rows(rows)
+ts, ts1 = [], []
+for _ in range(30):
+    t0 = time.perf_counter()
+    sc.scan_rows(rows)
+    ts.append((time.perf_counter() - t0) * 1e6)
+    t0 = time.perf_counter()
+    for titles, tk, fm in rows:
+        sc.scan(titles, tk, fm)
+    ts1.append((time.perf_counter() - t0) * 1e6)
+ts.sort(); ts1.sort()
+res["dip_rows_25x8_one_call"] = {"median_us": round(ts[len(ts) // 2], 1), "min_us": round(ts[0], 1)}
+res["dip_rows_25x8_row_by_row"] = {"median_us": round(ts1[len(ts1) // 2], 1), "min_us": round(ts1[0], 1)}
 print(json.dumps(res))
