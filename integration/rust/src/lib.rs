@@ -130,6 +130,43 @@ pub fn scan_titles(ctx: &HipCtx, titles: &[&str], ticker: &str, name_forms: &[St
         .collect())
 }
 
+/// The gate's scan for every row of a dip scan in one call (application/dip.rs: `check` per loser; `oi_headline_scan_rows`):
+/// `rows[r]` = (that loser's headlines, its ticker, its `company_name_forms`).  Per row what `scan_titles` returns.
+pub fn scan_title_rows(ctx: &HipCtx, rows: &[(Vec<&str>, &str, Vec<String>)]) -> Result<Vec<Vec<TitleScan>>, HipError> {
+    let (blob, offsets) = gather(rows.iter().flat_map(|r| r.0.iter().copied()));
+    let (mut row_off, mut tick_off, mut rform_off) = (vec![0u64], vec![0u32], vec![0u32]);
+    let (mut tblob, mut fblob, mut foffs) = (Vec::new(), Vec::new(), vec![0u32]);
+    for (titles, ticker, forms) in rows {
+        row_off.push(row_off.last().unwrap() + titles.len() as u64);
+        tblob.extend_from_slice(ticker.as_bytes());
+        tick_off.push(tblob.len() as u32);
+        for f in forms {
+            fblob.extend_from_slice(f.as_bytes());
+            foffs.push(fblob.len() as u32);
+        }
+        rform_off.push(foffs.len() as u32 - 1);
+    }
+    let n = *row_off.last().unwrap() as usize;
+    let (mut mask, mut order, mut about) = (vec![0u16; n], vec![0u64; n], vec![0u8; n]);
+    check(unsafe {
+        ffi::oi_headline_scan_rows(ctx.raw(), blob.as_ptr(), offsets.as_ptr(), n as u64, row_off.as_ptr(), rows.len() as u32,
+                                   tblob.as_ptr(), tick_off.as_ptr(), fblob.as_ptr(), foffs.as_ptr(), rform_off.as_ptr(),
+                                   mask.as_mut_ptr(), order.as_mut_ptr(), about.as_mut_ptr())
+    })?;
+    Ok(rows
+        .iter()
+        .enumerate()
+        .map(|(r, _)| {
+            (row_off[r] as usize..row_off[r + 1] as usize)
+                .map(|i| TitleScan {
+                    hits: (0..mask[i].count_ones()).map(|j| ((order[i] >> (4 * j)) & 15) as usize).collect(),
+                    about_company: about[i] != 0,
+                })
+                .collect()
+        })
+        .collect())
+}
+
 /// One corpus shard in HBM (`oi_index`).  New API: the reference has no retrieval port.
 pub struct HipIndex {
     ctx: Arc<HipCtx>,
