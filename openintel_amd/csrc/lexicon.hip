@@ -423,7 +423,8 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
                                                               uint64_t n, uint64_t blob_bytes,
                                                               const LexEntry *table, const uint32_t *bloom,
                                                               uint32_t mult, double *pol_out, uint8_t *spec_out,
-                                                              const uint8_t *sources, double tau, SumPartial *partials) {
+                                                              const uint8_t *sources, double tau, SumPartial *partials,
+                                                              uint32_t ppt) {
     __shared__ __attribute__((aligned(16))) Lex2Shared s;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // the summary's running sums live in LDS, one set per wave (loop-carried registers cost the scan a wave of occupancy:
@@ -437,10 +438,10 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_kernel(const uint8_t *
 #pragma unroll
     for (int i = 0; i < 8; ++i) bl[i] = bloom[i];
 
-    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    const uint64_t n_tiles = (n + ppt - 1) / ppt; // ppt <= LX_PPT posts per tile: fewer for small batches (see the launcher)
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t p0 = tile * LX_PPT;
-        const uint32_t np = (uint32_t)((n - p0) < LX_PPT ? (n - p0) : LX_PPT);
+        const uint64_t p0 = tile * ppt;
+        const uint32_t np = (uint32_t)((n - p0) < ppt ? (n - p0) : ppt);
         __syncthreads(); // previous tile fully written out
         const uint64_t byte_begin = offsets[p0];
         for (uint32_t i = tid; i <= np; i += LEX_THREADS) s.off[i] = (uint32_t)(offsets[p0 + i] - byte_begin);
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_scan_kernel(const uint
                                                                    uint64_t blob_bytes, const LexEntry *table,
                                                                    const uint32_t *bloom, uint32_t mult, double *pol_out,
                                                                    uint8_t *spec_out, const uint8_t *sources, double tau,
-                                                                   SumPartial *partials) {
+                                                                   SumPartial *partials, uint32_t ppt) {
     __shared__ __attribute__((aligned(16))) Lex3Shared s;
     __shared__ uint32_t r_u[5][LEX_THREADS / 64]; // the summary's running sums, one set per wave (see lexicon_kernel)
     __shared__ double r_d[LEX_THREADS / 64];
@@ -707,10 +708,10 @@ __global__ __launch_bounds__(LEX_THREADS, 4) void lexicon_scan_kernel(const uint
     uint16_t *ab16 = reinterpret_cast<uint16_t *>(s.abits);
     const uint8_t *text8 = reinterpret_cast<const uint8_t *>(s.text);
 
-    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    const uint64_t n_tiles = (n + ppt - 1) / ppt; // ppt <= LX_PPT posts per tile: fewer for small batches (see the launcher)
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint64_t p0 = tile * LX_PPT;
-        const uint32_t np = (uint32_t)((n - p0) < LX_PPT ? (n - p0) : LX_PPT);
+        const uint64_t p0 = tile * ppt;
+        const uint32_t np = (uint32_t)((n - p0) < ppt ? (n - p0) : ppt);
         __syncthreads(); // previous tile fully written out
         const uint64_t byte_begin = offsets[p0];
         // this thread's post starts (tile-relative; the tile's end counts as one), kept for every sub-tile's bitmap
@@ -1015,7 +1016,12 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
     static const bool v1 = oi_ablation_env("OI_LEXICON_V1") != nullptr; // A/B switches: the first / second generation scans
     static const bool v2 = oi_ablation_env("OI_LEXICON_V2") != nullptr;
     (void)v2;
-    const uint64_t n_tiles = (n + LX_PPT - 1) / LX_PPT;
+    // Posts per tile: LX_PPT for a batch that fills the chip; a small batch -- the reference's own call is one ticker's
+    // <= 100 posts -- is cut into smaller tiles so that its sub-tiles run side by side on many CUs instead of one after the
+    // other on one (1000 posts: 2 workgroups x 5 sub-tiles -> 63 workgroups x 1).  Per-post results do not depend on it.
+    uint32_t ppt = LX_PPT;
+    while (ppt > 16u && (n + ppt - 1) / ppt < 2ull * (uint64_t)ctx->num_cus) ppt >>= 1;
+    const uint64_t n_tiles = (n + ppt - 1) / ppt;
     // (4 workgroups are resident per CU; 16 per CU over the tile loop balance the tail: 1.042 / 1.023 / 1.009 ms at 4 / 8 / 16)
     static const char *grid_s = oi_ablation_env("OI_LEX_GRID"); // A/B switch: workgroups per CU
     const uint32_t max_grid = (uint32_t)ctx->num_cus * (grid_s ? (uint32_t)atoi(grid_s) : 16u);
@@ -1038,7 +1044,7 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
             static const char *dbg_s = oi_ablation_env("OI_LEX_DBG");
             const int dbg = dbg_s ? atoi(dbg_s) : 0;
 #define LEX_GO(K, D, BL) hipLaunchKernelGGL(K<D>, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n, \
-                                            blob_bytes, d_table, BL, h_mult, d_pol, d_spec, d_sources, tau, d_partials)
+                                            blob_bytes, d_table, BL, h_mult, d_pol, d_spec, d_sources, tau, d_partials, ppt)
             if (v2) switch (dbg) { case 1: LEX_GO(lexicon_kernel, 1, d_bloom); break; case 2: LEX_GO(lexicon_kernel, 2, d_bloom); break;
                                    case 3: LEX_GO(lexicon_kernel, 3, d_bloom); break; case 4: LEX_GO(lexicon_kernel, 4, d_bloom); break;
                                    case 5: LEX_GO(lexicon_kernel, 5, d_bloom); break; default: LEX_GO(lexicon_kernel, 0, d_bloom); }
@@ -1047,7 +1053,7 @@ int oi_launch_lexicon_fused(oi_ctx *ctx, const uint8_t *d_blob, const uint64_t *
 #undef LEX_GO
 #else
             hipLaunchKernelGGL(lexicon_scan_kernel<0>, dim3(grid), dim3(LEX_THREADS), 0, ctx->stream, d_blob, d_offsets, n,
-                               blob_bytes, d_table, d_bloom + 8, h_mult, d_pol, d_spec, d_sources, tau, d_partials);
+                               blob_bytes, d_table, d_bloom + 8, h_mult, d_pol, d_spec, d_sources, tau, d_partials, ppt);
 #endif
         }
         OI_HIP_CHECK(hipGetLastError());
