@@ -727,6 +727,9 @@ int oi_launch_headline_scan_params(oi_ctx *ctx, const uint8_t *d_blob, const uin
     uint32_t tile = 8;
     for (uint32_t t : kTiles)
         if (avg * t <= (HL_WIN_BYTES * 7) / 8) { tile = t; break; }
+    // a small batch (the gate's own call is a ticker's handful of headlines) is spread over the chip instead: smaller tiles
+    // until they number twice the CUs
+    while (tile > 8u && (n + tile - 1) / tile < 2ull * (uint64_t)ctx->num_cus) tile >>= 1;
     if (forced >= 1 && forced <= HL_MAX_TILE) tile = forced;
     static const int dbg = oi_ablation_env("OI_HEADLINE_DBG") ? atoi(oi_ablation_env("OI_HEADLINE_DBG")) : 0; // ablations (wrong results)
     static const bool v1 = oi_ablation_env("OI_HEADLINE_V1") != nullptr; // one lane per title (kept for A/B runs)
