@@ -86,3 +86,8 @@ def test_null_handles_are_refused_without_touching_a_device():
     lib.oi_destroy(none)
     lib.oi_index_destroy(none)
     assert lib.oi_set_stream(none, none) == INVALID and lib.oi_synchronize(none) == INVALID
+    # the batch callers' entry points and the dip rows' scan
+    assert lib.oi_social_summary_segmented(none, none, none, none, 0, none, 1, 0.2, _lib.OI_HOST, none) == INVALID
+    assert lib.oi_lexicon_scan_segments_device(none, none, none, 0, 0, none, none, 1, 0.2, none, none, none) == INVALID
+    assert lib.oi_headline_scan_rows(none, none, none, 0, none, 1, none, none, none, none, none, none, none, none) == INVALID
+    assert b"null ctx" in lib.oi_last_error()

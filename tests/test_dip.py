@@ -186,6 +186,23 @@ def test_scan_rows_equals_row_by_row_and_the_oracle_gpu(scanner):
     assert scanner.scan_rows([]) == []
     one = scanner.scan_rows([([], "UCTT", ["ultra clean"])])
     assert len(one) == 1 and one[0][0].size == 0
+    # argument errors come back as errors, not as truncation: rows that do not cover the titles, descending row offsets,
+    # too many name forms for one row
+    from openintel_amd import _lib
+    blob, offs = pack_posts(["fda halt", "guidance cut"])
+    tk = np.frombuffer(b"UCTT\0", dtype=np.uint8)
+    m, o, a = np.zeros(2, np.uint16), np.zeros(2, np.uint64), np.zeros(2, np.uint8)
+
+    def rows_call(row_off):
+        return scanner.ctx.lib.oi_headline_scan_rows(
+            scanner.ctx.handle, _lib.ptr(blob), _lib.ptr(offs), 2, _lib.ptr(np.array(row_off, dtype=np.uint64)), len(row_off) - 1,
+            _lib.ptr(tk), _lib.ptr(np.array([0] + [4] * (len(row_off) - 1), dtype=np.uint32)), None, None,
+            _lib.ptr(np.zeros(len(row_off), np.uint32)), _lib.ptr(m), _lib.ptr(o), _lib.ptr(a))
+    assert rows_call([0, 2]) == 0 and int(m[0]) != 0 and int(m[1]) != 0
+    assert rows_call([0, 1]) == _lib.OI_ERR_INVALID_ARG       # the rows stop short of the titles
+    assert rows_call([0, 2, 1, 2]) == _lib.OI_ERR_INVALID_ARG  # descending
+    with pytest.raises(_lib.OiError):
+        scanner.scan_rows([(["a"], "UCTT", ["w%d" % i for i in range(40)])])
 
 
 @pytest_gpu
