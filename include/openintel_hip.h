@@ -400,6 +400,12 @@ int oi_screen_probe(oi_index *idx, const float *query_vecs, uint32_t n_queries, 
 int oi_profile_reset(oi_ctx *ctx, int enable);
 int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out);
 
+/* Memory this context holds right now: HBM of its workspaces (candidate pools, staging, lists -- INTEGRATION.md 5b: the
+ * BM25 pool of the wave kernel alone reserves ~5 GB per searching context at 10M docs) and page-locked host memory of
+ * its staging buffers.  Index buffers are not counted (oi_index owns them; a view borrows them).  Either output may be
+ * NULL.  (No reference counterpart: the reference allocates nothing on a device.) */
+int oi_workspace_bytes(oi_ctx *ctx, uint64_t *device_bytes_out, uint64_t *pinned_host_bytes_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,7 @@ extern "C" {
     pub fn oi_last_error() -> *const c_char; // thread-local
     pub fn oi_create(device_ordinal: c_int, out: *mut *mut OiCtx) -> c_int;
     pub fn oi_destroy(ctx: *mut OiCtx);
+    pub fn oi_workspace_bytes(ctx: *mut OiCtx, device_bytes_out: *mut u64, pinned_host_bytes_out: *mut u64) -> c_int;
     pub fn oi_set_stream(ctx: *mut OiCtx, hip_stream: *mut c_void) -> c_int;
     pub fn oi_synchronize(ctx: *mut OiCtx) -> c_int;
     pub fn oi_set_cosine_mode(ctx: *mut OiCtx, mode: c_int) -> c_int;

@@ -50,6 +50,12 @@ class HipContext:
         """(replays, captures) since the ctx was created."""
         return self.profile_read("graph_replays")[1], self.profile_read("graph_captures")[1]
 
+    def workspace_bytes(self):
+        """(HBM bytes of this context's workspaces, page-locked host bytes of its staging buffers) right now."""
+        d, h = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.oi_workspace_bytes(self.handle, C.byref(d), C.byref(h)))
+        return int(d.value), int(h.value)
+
     # ---- HIP-event kernel timing (bench.py)
     def profile_reset(self, enable=True) -> None:
         """enable: False/0 off, True/1 every tagged launch, 2 only the cosine scorer's launches."""

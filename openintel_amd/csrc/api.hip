@@ -307,6 +307,17 @@ extern "C" void oi_destroy(oi_ctx *ctx) {
     ctx_release(ctx);
 }
 
+extern "C" int oi_workspace_bytes(oi_ctx *ctx, uint64_t *device_bytes, uint64_t *pinned_bytes) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    uint64_t d = 0;
+    for (auto &kv : ctx->ws)
+        if (!kv.second.borrowed) d += kv.second.cap;
+    if (device_bytes) *device_bytes = d;
+    if (pinned_bytes) *pinned_bytes = (ctx->pin_in.pinned ? ctx->pin_in.cap : 0) + (ctx->pin_out.pinned ? ctx->pin_out.cap : 0);
+    return OI_OK;
+}
+
 extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -86,3 +86,37 @@ def test_interpreter_exit_with_a_leaked_index_whose_ctx_was_closed_first():
                        timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "ok" in r.stdout and "terminate called" not in r.stderr and "core dumped" not in r.stderr
+
+
+@pytest.mark.gpu
+def test_workspace_bytes_reports_what_a_searching_context_holds():
+    """oi_workspace_bytes: nothing before the first call, the query workspaces after a search (the BM25 pool of the wave
+    kernel dominates: one 32768-key segment per (query, doc block)), page-locked staging after an
+    OI_HOST call; a view's context brings its own workspaces, not the index."""
+    import numpy as np
+    import openintel_amd as oi
+    from openintel_amd import synth
+    ctx = oi.HipContext(0)
+    assert ctx.workspace_bytes() == (0, 0)
+    n, dim, B = 200_000, 64, 8
+    idx = oi.HybridIndex(ctx, n, dim, synth.VOCAB)
+    idx.set_embeddings(synth.embeddings_np(n, dim), normalize=False)
+    terms, offs = synth.forward_index_np(n)
+    idx.set_forward(terms, offs)
+    idx.set_max_query_terms(4)
+    idx.finalize()
+    built, _ = ctx.workspace_bytes()
+    qv = synth.embeddings_np(B, dim, seed=5)
+    qt, qo = synth.query_terms_np(B)
+    idx.search(qv, qt, qo, k=10, depth=100)          # host arrays: the OI_HOST entry point
+    dev, pinned = ctx.workspace_bytes()
+    n_blocks = (n + 32767) // 32768
+    assert dev - built >= B * n_blocks * 32768 * 8   # the BM25 wave pool alone
+    assert dev < 4 << 30 and 0 < pinned <= 2 << 20
+    ctx2 = oi.HipContext(0)
+    view = idx.view(ctx2)
+    assert ctx2.workspace_bytes()[0] == 0            # the view borrows the index buffers
+    view.search(qv, qt, qo, k=10, depth=100)
+    assert ctx2.workspace_bytes()[0] >= B * n_blocks * 32768 * 8
+    view.close(); ctx2.close(); idx.close(); ctx.close()
+
