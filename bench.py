@@ -307,7 +307,9 @@ def main():
     # every rank's own set-up and clock (rank 0 prints them all: a scaling number can be tied to the lanes that produced it)
     mine = {"rank": rank, "docs_per_gpu": n_local, "doc_id_base": lo, "own_elapsed_ms_per_step": float(tm_own) / args.steps * 1e3,
             "lane_calibration": pipe.calibration if pipe is not None else None,
-            "lanes": (len(pipe.lanes) if pipe is not None else 1)}
+            "lanes": (len(pipe.lanes) if pipe is not None else 1),
+            # HBM of the searching contexts' workspaces on this rank (the index itself not counted)
+            "workspace_GB": round(sum(c.workspace_bytes()[0] for c in [ctx] + lane_ctxs) / 1e9, 3)}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
