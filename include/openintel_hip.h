@@ -68,7 +68,8 @@ enum { OI_HOST = 0, OI_DEVICE = 1 };
 /* Limits of the kernels in this build. */
 #define OI_MAX_DEPTH 1024u      /* per-list depth k' and final k */
 #define OI_MAX_DIM 1024u        /* embedding dimension (multiple of 4) */
-#define OI_BM25_BLOCK_DOCS 32768u /* docs per BM25 LDS accumulator block */
+#define OI_BM25_BLOCK_DOCS 32768u /* docs per BM25 doc block (one pool segment, one seen/multi map) */
+#define OI_BM25_FINE_DOCS 16384u  /* docs per (term, window) cell of the inverted index: two windows per block */
 
 typedef struct oi_ctx oi_ctx;
 typedef struct oi_index oi_index;
@@ -289,10 +290,11 @@ int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df
 int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                       const uint32_t *global_df_host);
 
-/* BM25 kernel choice: 0 = default (= 3), 1 = term-at-a-time with one workgroup per doc block (bm25.hip, the
+/* BM25 kernel choice: 0 = default (= 4), 1 = term-at-a-time with one workgroup per doc block (bm25.hip, the
  * first-generation kernel), 2 = batch scan of the forward index (bm25_scan.hip), 3 = term-at-a-time with one wave
- * per (doc block, query) task (bm25_wave.hip).  All produce bit-identical lists.  OI_BM25_MODE=wave|taat|scan
- * selects the default process-wide. */
+ * per (doc block, query) task (bm25_wave.hip), 4 = term-at-a-time as a stream: every wave walks a weight-balanced
+ * range of (query, block) tasks with the postings ahead of it in flight through an LDS ring (bm25_stream.hip).
+ * All produce bit-identical lists.  OI_BM25_MODE=stream|wave|taat|scan selects the default process-wide. */
 int oi_index_set_bm25_mode(oi_index *idx, int mode);
 
 /* Contract for the batch BM25 scan (mode 2): no query of a batch has more

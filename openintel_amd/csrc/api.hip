@@ -745,7 +745,7 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     v->rows = src->rows; v->rows_bf16 = src->rows_bf16; // rows_owned / rows_bf16_owned stay false
     v->screen_ok = src->screen_ok;
     v->forward_set = src->forward_set; v->finalized = true;
-    v->total_tokens = src->total_tokens; v->n_postings = src->n_postings; v->n_blocks = src->n_blocks;
+    v->total_tokens = src->total_tokens; v->n_postings = src->n_postings; v->n_blocks = src->n_blocks; v->n_win = src->n_win;
     v->avgdl = src->avgdl; v->max_query_terms = src->max_query_terms; v->bm25_mode = src->bm25_mode;
     auto alias = [](DevBuf &dst, const DevBuf &from) { dst.p = from.p; dst.cap = from.cap; dst.borrowed = from.p != nullptr; };
     alias(v->max_row_norm, src->max_row_norm); alias(v->screen_copy, src->screen_copy);
@@ -882,7 +882,7 @@ extern "C" int oi_index_set_max_query_terms(oi_index *idx, uint32_t max_terms) {
 
 extern "C" int oi_index_set_bm25_mode(oi_index *idx, int mode) {
     if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(mode >= 0 && mode <= 3, "bm25 mode %d outside [0,3]", mode);
+    OI_REQUIRE(mode >= 0 && mode <= 4, "bm25 mode %d outside [0,4]", mode);
     std::lock_guard<std::mutex> g(idx->ctx->mu);
     idx->bm25_mode = mode;
     return OI_OK;
@@ -922,6 +922,16 @@ namespace {
 struct Pools {
     PoolView cos, bm;
 };
+
+// 1 term-at-a-time per workgroup (bm25.hip), 2 scan of the forward index, 3 one wave per task (bm25_wave.hip), 4 the stream
+// kernel (bm25_stream.hip: the default).  The index's own setting wins over the process-wide OI_BM25_MODE.
+int bm25_mode_of(const oi_index *idx) {
+    static const char *mode_env = getenv("OI_BM25_MODE");
+    int mode = idx->bm25_mode;
+    if (mode == 0 && mode_env)
+        mode = strcmp(mode_env, "scan") == 0 ? 2 : strcmp(mode_env, "taat") == 0 ? 1 : strcmp(mode_env, "wave") == 0 ? 3 : 4;
+    return mode == 0 ? 4 : mode;
+}
 
 // State of both pools in one block, zeroed with ONE memset per search:
 //   cosine: carry_cnt[B] tau[B] seg_cnt[B][CUs]      BM25: carry_cnt[B] seg_cnt[B][n_blocks]
@@ -1000,7 +1010,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // the bf16 screen's state words (carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][CUs]) ride in the same memset
     const size_t screen_words = (size_t)B * (4 + (size_t)ctx->num_cus) + 4;
     uint32_t *screen_state = nullptr;
-    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, idx->n_blocks, depth, &P, screen_words, &screen_state));
+    // (the depth-sized segments of P.bm belong to the workgroup-per-block kernel: no room is set aside for them otherwise)
+    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, bm25_mode_of(idx) == 1 ? idx->n_blocks : 0, depth, &P, screen_words, &screen_state));
 
     // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
@@ -1012,18 +1023,53 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         hipStream_t st = ctx->stream; // (the side stream when the legs overlap)
         (void)st;
         OI_REQUIRE(idx->finalized, "search: index not finalized");
-        // Which BM25 kernel.  Default: term-at-a-time with one WAVE per (block, query) task (bm25_wave.hip).  The
+        // Which BM25 kernel.  Default: the stream kernel (bm25_stream.hip).  The wave-per-task kernel (bm25_wave.hip), the
         // first-generation workgroup-per-block kernel (bm25.hip) and the batch scan of the forward index
         // (bm25_scan.hip) stay selectable per index (oi_index_set_bm25_mode) or process-wide with
-        // OI_BM25_MODE=wave|taat|scan; all three return bit-identical lists.
-        static const char *mode_env = getenv("OI_BM25_MODE");
-        int mode = idx->bm25_mode;
-        if (mode == 0 && mode_env) mode = strcmp(mode_env, "scan") == 0 ? 2 : strcmp(mode_env, "taat") == 0 ? 1 : 3;
-        if (mode == 0) mode = 3;
+        // OI_BM25_MODE=stream|wave|taat|scan; all four return bit-identical lists.
+        const int mode = bm25_mode_of(idx);
         const bool have_fwd = idx->fwd_terms.p && idx->total_tokens > 0;
         const bool scan = have_fwd && mode == 2;
-        if (!scan && mode != 1) {
-            // Two phases like the cosine chunks: the first eighth of the doc blocks is scored with no threshold
+        if (!scan && mode != 1 && mode != 3) {
+            // The STREAM kernel (bm25_stream.hip, the default).  Two phases like the cosine chunks: the first eighth of the doc
+            // blocks is scored with no threshold and fixes tau_q = the depth-th score so far, a lower bound of the final
+            // one; the remaining blocks emit only scores >= tau_q.  A task's pool segment is SMALL and fixed (4096 keys
+            // in the first phase, depth + 256 in the second): a segment that would overflow is pruned in place to its
+            // top `depth` keys, so nothing can overflow whatever the data, and the pool is ~3 MB per query at 10M docs.
+            const uint32_t nb = idx->n_blocks;
+            if (nb == 0 || idx->n_postings == 0) {
+                OI_HIP_CHECK(hipMemsetAsync(bm_c, 0, sizeof(uint32_t) * B, st));
+                return OI_OK;
+            }
+            const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / 8) : nb;
+            const uint32_t cap1 = oi_bm25_stream_seg_cap(depth, true), cap2 = oi_bm25_stream_seg_cap(depth, false);
+            const uint64_t sstride = (uint64_t)carry_cap + std::max<uint64_t>((uint64_t)first * cap1, (uint64_t)nb * cap2);
+            uint64_t pass = (2ull << 30) / 8 / sstride; // <= 2 GiB of pool (0.2 GB for 64 queries over 10M docs)
+            pass = std::max<uint64_t>(1, std::min<uint64_t>(pass, std::min<uint32_t>(B, oi_bm25_stream_pass_queries())));
+            DevBuf &sp = ctx->buf("pool_bm_stream"), &sc = ctx->buf("pool_bm_stream_state");
+            OI_CHECK(sp.ensure(sizeof(uint64_t) * (size_t)pass * sstride));
+            const size_t swords = (size_t)pass * (2 + nb);
+            OI_CHECK(sc.ensure(sizeof(uint32_t) * swords));
+            for (uint32_t q0 = 0; q0 < B; q0 += (uint32_t)pass) {
+                const uint32_t nq = std::min<uint32_t>((uint32_t)pass, B - q0);
+                uint32_t *w = sc.as<uint32_t>();
+                // (the plan launch also zeroes the pass's pool state: carry_cnt[pass] tau[pass] seg_cnt[pass][nb])
+                OI_CHECK(oi_launch_bm25_plan(idx, d_qt, d_qo, q0, nq, w, swords));
+                PoolView W1{sp.as<uint64_t>(), w, w + 2 * (size_t)pass, w + pass, sstride, carry_cap, cap1, first, nb, P.bm.overflow};
+                OI_CHECK(oi_launch_bm25_stream(idx, d_qt, d_qo, q0, nq, depth, W1, 0, first));
+                if (first < nb) {
+                    OI_CHECK(oi_launch_select(ctx, W1, nq, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth));
+                    PoolView W2 = W1;
+                    W2.seg_cap = cap2; W2.n_segs = nb; // the first phase's segments are empty again: the same memory, cut anew
+                    OI_CHECK(oi_launch_bm25_stream(idx, d_qt, d_qo, q0, nq, depth, W2, first, nb));
+                    OI_CHECK(oi_launch_select(ctx, W2, nq, depth, false, bm_s + (size_t)q0 * depth, bm_d + (size_t)q0 * depth, bm_c + q0, depth));
+                } else
+                    OI_CHECK(oi_launch_select(ctx, W1, nq, depth, false, bm_s + (size_t)q0 * depth, bm_d + (size_t)q0 * depth, bm_c + q0, depth));
+            }
+            return OI_OK;
+        }
+        if (!scan && mode == 3) {
+            // The wave-per-task kernel.  Two phases like the cosine chunks: the first eighth of the doc blocks is scored with no threshold
             // (every touched doc is a candidate) and fixes tau_q = the depth-th score so far, a lower bound of
             // the final one; the remaining blocks emit only scores >= tau_q.  A task's pool segment holds a whole
             // block, so nothing can overflow; the room is address space, not traffic (only emitted keys are

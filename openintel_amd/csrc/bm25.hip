@@ -8,9 +8,15 @@
 // Every f32 op is written with an explicit round-to-nearest intrinsic so no flag can
 // fuse or reorder it: scores are bit-identical to the CPU oracle's.
 //
-// Layout.  Docs are cut into blocks of R = 32768 consecutive ids.  Postings are sorted by
-// (block, term, doc) and stored as {doc_in_block u32, impact f32}; cell_start[block*V + term]
-// is where that (block, term) run begins.  A query workgroup owns one doc block: its R f32
+// Layout (round 4: TERM-major).  Postings are sorted by (term, doc) -- a term's posting list is one contiguous
+// array in doc order -- and stored as {doc_in_block u32, impact f32}, doc_in_block relative to the doc's block of
+// R = 32768 consecutive ids.  Docs are also cut into WINDOWS of F = 16384 ids (two per block), and
+// cell_start[term * n_windows + window] is where that (term, window) run begins; the next entry is where it
+// ends, because consecutive windows of a term -- and then the next term -- follow each other in the array.  So
+// the bounds of any run of consecutive windows or blocks of a term are ONE contiguous read, and a kernel that
+// walks a query's blocks reads its terms' lists as contiguous streams (bm25_stream.hip).  The (block, term) run
+// of the two older kernels is windows 2 blk and 2 blk + 1 of the term.
+// This file's query kernel: a workgroup owns one doc block: its R f32
 // accumulators live in LDS (128 KiB), each query term's run is streamed once with coalesced
 // 8-byte loads, and a doc appears at most once per run, so accumulation needs no atomics and
 // has a fixed order.  Candidates leave the block as 64-bit rank keys into the query's pool.
@@ -35,9 +41,12 @@ struct Posting {
     float impact;
 };
 
-// key = block (17 bits) | term (32 bits) | doc_in_block (15 bits)
+#define BM_F_LOG2 14 // log2(OI_BM25_FINE_DOCS)
+static_assert((1u << BM_F_LOG2) == OI_BM25_FINE_DOCS && OI_BM25_BLOCK_DOCS == 2 * OI_BM25_FINE_DOCS, "two windows per block");
+
+// key = term (32 bits) | local doc (32 bits): sorted keys = every term's posting list in doc order
 __device__ __forceinline__ uint64_t bm_key(uint64_t doc, uint32_t term) {
-    return ((doc >> BM_R_LOG2) << 47) | ((uint64_t)term << BM_R_LOG2) | (doc & (BM_R - 1));
+    return ((uint64_t)term << 32) | (doc & 0xFFFFFFFFull);
 }
 
 // ------------------------------------------------------------------ index build
@@ -55,16 +64,16 @@ __global__ void bm_make_keys_kernel(const uint32_t *terms, const uint64_t *offse
     }
 }
 
-// (block, term) cell histogram of the sorted unique keys.  Entries of one cell are consecutive, so a
+// (term, window) cell histogram of the sorted unique keys.  Entries of one cell are consecutive, so a
 // wave first folds its lanes' runs (ballot of run heads) and issues ONE atomic per run and wave: the
 // per-entry version serialised millions of adds on the cells of frequent terms (670 ms at 10M docs).
-__global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t vocab, uint32_t *cell_count) {
+__global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t n_win, uint32_t *cell_count) {
     const uint32_t lane = threadIdx.x & 63;
     for (uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(uint64_t)63; i0 < n;
          i0 += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = i0 + lane;
         const bool valid = i < n;
-        const uint64_t cell_key = valid ? (uniq[i] >> BM_R_LOG2) : ~0ull; // block << 32 | term
+        const uint64_t cell_key = valid ? (uniq[i] >> BM_F_LOG2) : ~0ull; // term << 18 | window
         const uint64_t prev = __shfl_up(cell_key, 1, OI_WAVE);
         const bool head = valid && (lane == 0 || prev != cell_key);
         const unsigned long long heads = __ballot(head);
@@ -73,20 +82,17 @@ __global__ void bm_count_kernel(const uint64_t *uniq, uint64_t n, uint32_t vocab
             // run = lanes [lane, next head or first invalid lane)
             const unsigned long long above = lane == 63 ? 0ull : ((heads | ~valids) >> (lane + 1));
             const uint32_t run = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
-            const uint64_t block = cell_key >> 32;
-            const uint32_t term = (uint32_t)cell_key;
-            atomicAdd(&cell_count[block * vocab + term], run);
+            const uint64_t term = cell_key >> (32 - BM_F_LOG2);
+            const uint32_t win = (uint32_t)cell_key & ((1u << (32 - BM_F_LOG2)) - 1u);
+            atomicAdd(&cell_count[term * n_win + win], run);
         }
     }
 }
 
-// df[t] = sum over blocks of the cell histogram (before it is scanned): no atomics, coalesced over terms
-__global__ void bm_df_kernel(const uint32_t *cell_count, uint32_t n_blocks, uint32_t vocab, uint32_t *df) {
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < vocab; t += gridDim.x * blockDim.x) {
-        uint32_t s = 0;
-        for (uint32_t b = 0; b < n_blocks; ++b) s += cell_count[(uint64_t)b * vocab + t];
-        df[t] = s;
-    }
+// df[t] = length of term t's posting list, read off the SCANNED cell array
+__global__ void bm_df_kernel(const uint32_t *cell_start, uint32_t n_win, uint32_t vocab, uint32_t *df) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < vocab; t += gridDim.x * blockDim.x)
+        df[t] = cell_start[(uint64_t)(t + 1) * n_win] - cell_start[(uint64_t)t * n_win];
 }
 
 __global__ void bm_impact_kernel(const uint64_t *uniq, const uint32_t *tf, uint64_t n,
@@ -94,8 +100,8 @@ __global__ void bm_impact_kernel(const uint64_t *uniq, const uint32_t *tf, uint6
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t k = uniq[i];
-        const uint32_t dib = (uint32_t)(k & (BM_R - 1));
-        const uint64_t doc = ((k >> 47) << BM_R_LOG2) | dib;
+        const uint64_t doc = k & 0xFFFFFFFFull;
+        const uint32_t dib = (uint32_t)(doc & (BM_R - 1));
         const float ratio = __fdiv_rn((float)doc_len[doc], avgdl);
         const float kd = __fmul_rn(BM_K1, __fadd_rn(1.0f - BM_B, __fmul_rn(BM_B, ratio)));
         const float ftf = (float)tf[i];
@@ -123,7 +129,8 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
     OI_HIP_CHECK(hipMemcpyAsync(idx->fwd_offsets.p, d_offsets, sizeof(uint64_t) * (n + 1), hipMemcpyDeviceToDevice, st));
     idx->n_blocks = (uint32_t)((n + BM_R - 1) / BM_R);
     OI_REQUIRE(idx->n_blocks < (1u << 17), "bm25: too many doc blocks");
-    OI_REQUIRE((uint64_t)idx->n_blocks * idx->vocab < 0xFFFFFFFFull, "bm25: blocks x vocab exceeds 2^32");
+    idx->n_win = 2 * idx->n_blocks; // windows of OI_BM25_FINE_DOCS docs; a block is windows 2 blk, 2 blk + 1
+    OI_REQUIRE((uint64_t)idx->n_win * idx->vocab < 0xFFFFFFFFull, "bm25: windows x vocab exceeds 2^32");
 
     OI_CHECK(idx->doc_len.ensure(sizeof(uint32_t) * (n ? n : 1)));
     OI_CHECK(idx->df_local.ensure(sizeof(uint32_t) * idx->vocab));
@@ -154,7 +161,7 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
     OI_CHECK(temp.ensure(temp_bytes ? temp_bytes : 16));
     OI_HIP_CHECK(rocprim::radix_sort_keys(temp.p, temp_bytes, keys.as<uint64_t>(), keys_sorted.as<uint64_t>(),
                                           (size_t)total, 0u, 64u, st));
-    // run-length encode: unique (block, term, doc) keys, run length = term frequency
+    // run-length encode: unique (term, doc) keys, run length = term frequency
     OI_CHECK(idx->uniq_keys.ensure(sizeof(uint64_t) * total));
     OI_CHECK(idx->tf.ensure(sizeof(uint32_t) * total));
     size_t temp2 = 0;
@@ -173,18 +180,15 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
     OI_REQUIRE(!h_bad, "bm25: a term id is >= vocab (%u)", idx->vocab);
     idx->n_postings = h_runs;
 
-    // local df and the (block, term) cell histogram
-    const uint64_t cells = (uint64_t)idx->n_blocks * idx->vocab;
+    // the (term, window) cell histogram, scanned into run starts; local df from it
+    const uint64_t cells = (uint64_t)idx->n_win * idx->vocab;
     OI_CHECK(idx->cell_start.ensure(sizeof(uint32_t) * (cells + 1)));
     OI_HIP_CHECK(hipMemsetAsync(idx->cell_start.p, 0, sizeof(uint32_t) * (cells + 1), st));
     {
         uint64_t blocks = (idx->n_postings + 255) / 256;
         if (blocks > 65535) blocks = 65535;
         hipLaunchKernelGGL(bm_count_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),
-                           idx->n_postings, idx->vocab, idx->cell_start.as<uint32_t>());
-        OI_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(bm_df_kernel, dim3((idx->vocab + 255) / 256), dim3(256), 0, st,
-                           idx->cell_start.as<uint32_t>(), idx->n_blocks, idx->vocab, idx->df_local.as<uint32_t>());
+                           idx->n_postings, idx->n_win, idx->cell_start.as<uint32_t>());
         OI_HIP_CHECK(hipGetLastError());
     }
     // exclusive scan in place -> cell_start[c] = first posting of cell c; last entry = n_postings
@@ -197,6 +201,9 @@ int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t
     OI_HIP_CHECK(rocprim::exclusive_scan(t3.p, temp3, idx->cell_start.as<uint32_t>(),
                                          idx->cell_start.as<uint32_t>(), 0u, (size_t)(cells + 1),
                                          rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(bm_df_kernel, dim3((idx->vocab + 255) / 256), dim3(256), 0, st, idx->cell_start.as<uint32_t>(),
+                       idx->n_win, idx->vocab, idx->df_local.as<uint32_t>());
+    OI_HIP_CHECK(hipGetLastError());
     OI_HIP_CHECK(hipStreamSynchronize(st));
     t3.release();
     idx->forward_set = true;
@@ -288,7 +295,7 @@ __device__ __forceinline__ uint32_t bm_wave_slot(bool pred, uint32_t *counter) {
 
 __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
     const Posting *__restrict__ postings, const uint32_t *__restrict__ cell_start,
-    const float *__restrict__ idf, uint32_t vocab, uint32_t doc_id_base, uint32_t block0,
+    const float *__restrict__ idf, uint32_t vocab, uint32_t n_win, uint32_t doc_id_base, uint32_t block0,
     const uint32_t *__restrict__ q_terms, const uint32_t *__restrict__ q_offsets, uint32_t n_queries,
     uint32_t depth, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride, const uint32_t *tau_keys,
     uint64_t pool_stride, uint32_t carry_cap) {
@@ -301,7 +308,8 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t blk = block0 + blockIdx.x;
-    const uint64_t cell0 = (uint64_t)blk * vocab;
+    // run of (term t, this block) = windows 2 blk, 2 blk + 1 of the term: [cell_start[c], cell_start[c + 2])
+    auto cell_of = [&](uint32_t t) { return (uint64_t)t * n_win + 2u * blk; };
     const uint32_t doc0 = doc_id_base + blk * BM_R;
     // term info records: [0],[1] = the pipeline's double buffer (first batch of a query), [2] = scratch
     // for the later batches of queries with more than BM_TB terms.  Record = s[TB] e[TB] w[TB] tb te.
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
             r_tb = q_offsets[qa]; r_te = q_offsets[qa + 1];
             if (r_tb + tid < r_te) {
                 const uint32_t t = q_terms[r_tb + tid];
-                if (t < vocab) { r_s = cell_start[cell0 + t]; r_e = cell_start[cell0 + t + 1]; r_w = idf[t]; }
+                if (t < vocab) { r_s = cell_start[cell_of(t)]; r_e = cell_start[cell_of(t) + 2]; r_w = idf[t]; }
             }
         }
     };
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                     float w0 = 0.f;
                     if (tb + tid < t_end) {
                         const uint32_t t = q_terms[tb + tid];
-                        if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; w0 = idf[t]; }
+                        if (t < vocab) { s0 = cell_start[cell_of(t)]; e0 = cell_start[cell_of(t) + 2]; w0 = idf[t]; }
                     }
                     t_s[tid] = s0; t_e[tid] = e0; t_w[tid] = w0;
                 }
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(BM_THREADS) void bm25_block_kernel(
                         uint32_t s0 = 0, e0 = 0;
                         if (tb + tid < t_end) {
                             const uint32_t t = q_terms[tb + tid];
-                            if (t < vocab) { s0 = cell_start[cell0 + t]; e0 = cell_start[cell0 + t + 1]; }
+                            if (t < vocab) { s0 = cell_start[cell_of(t)]; e0 = cell_start[cell_of(t) + 2]; }
                         }
                         t_s[tid] = s0; t_e[tid] = e0;
                     }
@@ -571,7 +579,7 @@ int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q
     ProfScope ps(ctx, "bm25");
     hipLaunchKernelGGL(bm25_block_kernel, dim3(nb, ysplit), dim3(BM_THREADS), BM_SMEM, ctx->stream,
                        idx->postings.as<Posting>(), idx->cell_start.as<uint32_t>(), idx->idf.as<float>(),
-                       idx->vocab, idx->doc_id_base, block_begin, d_q_terms, d_q_offsets, n_queries, depth,
+                       idx->vocab, idx->n_win, idx->doc_id_base, block_begin, d_q_terms, d_q_offsets, n_queries, depth,
                        pool.keys, pool.seg_cnt, pool.seg_cnt_stride, pool.tau_keys, pool.stride, pool.carry_cap);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;

@@ -70,7 +70,7 @@ __device__ __forceinline__ void bw_task(uint32_t t, uint32_t nb, const uint32_t 
 template <bool TIMING, int DBG = 0>
 __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
     const BwPosting *__restrict__ postings, const uint32_t *__restrict__ cell_start, const float *__restrict__ idf,
-    const uint32_t *__restrict__ df, uint32_t vocab, uint32_t doc_id_base, uint32_t block0, uint32_t n_blocks_here,
+    const uint32_t *__restrict__ df, uint32_t vocab, uint32_t n_win, uint32_t doc_id_base, uint32_t block0, uint32_t n_blocks_here,
     const uint32_t *__restrict__ q_terms, const uint32_t *__restrict__ q_offsets, uint32_t q_begin, uint32_t nq,
     uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride, const uint32_t *tau_keys, uint64_t pool_stride,
     uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow, unsigned long long *timing) {
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(BW_WAVES * 64, 3) void bm25_wave_kernel(
         uint32_t term = n_terms_pass == 0 ? 0u : (staged ? s_terms[ti] : q_terms[term0 + ti]);
         const bool ok = have && term < vocab;
         term = ok ? term : 0u;
-        const uint64_t cell = (uint64_t)(block0 + blk) * vocab + term;
+        const uint64_t cell = (uint64_t)term * n_win + 2u * (block0 + blk); // windows 2 blk, 2 blk + 1 of the term's list
         s = cell_start[cell];
-        e = cell_start[cell + 1];
+        e = cell_start[cell + 2];
         wt = idf[term];
         okm = ok ? 1u : 0u;
     };
@@ -515,7 +515,7 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
         OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(bm25_wave_kernel<true>, dim3((uint32_t)wgs), dim3(BW_WAVES * 64), BW_SMEM, ctx->stream,
                            reinterpret_cast<const BwPosting *>(idx->postings.p), idx->cell_start.as<uint32_t>(),
-                           idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,
+                           idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->n_win, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,
                            q_begin, nq, pool.keys, pool.seg_cnt, pool.seg_cnt_stride, pool.tau_keys, pool.stride,
                            pool.carry_cap, pool.seg_cap, pool.overflow, tb.as<unsigned long long>());
         OI_HIP_CHECK(hipGetLastError());
@@ -538,7 +538,7 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
         OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(bm25_wave_kernel<false, L>), (size_t)BW_SMEM));          \
         hipLaunchKernelGGL((bm25_wave_kernel<false, L>), dim3((uint32_t)wgs), dim3(BW_WAVES * 64), BW_SMEM, ctx->stream,  \
                            reinterpret_cast<const BwPosting *>(idx->postings.p), idx->cell_start.as<uint32_t>(),         \
-                           idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,  \
+                           idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->n_win, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,  \
                            q_begin, nq, pool.keys, pool.seg_cnt, pool.seg_cnt_stride, pool.tau_keys, pool.stride,        \
                            pool.carry_cap, pool.seg_cap, pool.overflow, (unsigned long long *)nullptr);                 \
         OI_HIP_CHECK(hipGetLastError());                                                                                 \
@@ -550,7 +550,7 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
 #endif
     hipLaunchKernelGGL(bm25_wave_kernel<false>, dim3((uint32_t)wgs), dim3(BW_WAVES * 64), BW_SMEM, ctx->stream,
                        reinterpret_cast<const BwPosting *>(idx->postings.p), idx->cell_start.as<uint32_t>(),
-                       idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,
+                       idx->idf.as<float>(), idx->df_local.as<uint32_t>(), idx->vocab, idx->n_win, idx->doc_id_base, block_begin, nb, d_q_terms, d_q_offsets,
                        q_begin, nq, pool.keys, pool.seg_cnt, pool.seg_cnt_stride, pool.tau_keys, pool.stride,
                        pool.carry_cap, pool.seg_cap, pool.overflow, (unsigned long long *)nullptr);
     OI_HIP_CHECK(hipGetLastError());

@@ -180,22 +180,24 @@ struct oi_index {
     uint64_t total_tokens = 0;  // local
     uint64_t n_postings = 0;    // unique (doc, term) pairs
     uint32_t n_blocks = 0;      // ceil(n_docs / OI_BM25_BLOCK_DOCS)
+    uint32_t n_win = 0;         // 2 * n_blocks: windows of OI_BM25_FINE_DOCS docs (the cells of a term's posting list)
     DevBuf uniq_keys;           // u64 (block | term | doc_in_block), sorted
     DevBuf tf;                  // u32 per unique key
     DevBuf doc_len;             // u32 per doc
     DevBuf df_local;            // u32 per term
 
     // finalized inverted index
-    DevBuf postings;   // {u32 doc_in_block, f32 impact} per unique key, (block, term, doc) order
-    DevBuf cell_start; // u32 [n_blocks * vocab + 1]
+    DevBuf postings;   // {u32 doc_in_block, f32 impact} per unique key, (term, doc) order: one contiguous list per term
+    DevBuf cell_start; // u32 [vocab * n_win + 1]: start of the (term, window) run; the next entry is its end
     DevBuf idf;        // f32 per term
     // forward index kept for the batch scan (bm25_scan.hip)
     DevBuf fwd_terms;   // u32 per token
     DevBuf fwd_offsets; // u64 per doc + 1
     float avgdl = 0.f;  // global average doc length fixed at finalize
     uint32_t max_query_terms = 16; // contract for the batch-scan path (oi_index_set_max_query_terms)
-    int bm25_mode = 0;             // 0 default (= 3 unless OI_BM25_MODE says otherwise), 1 term-at-a-time per workgroup (bm25.hip),
-                                   // 2 scan of the forward index (bm25_scan.hip), 3 term-at-a-time per wave (bm25_wave.hip)
+    int bm25_mode = 0;             // 0 default (= 4 unless OI_BM25_MODE says otherwise), 1 term-at-a-time per workgroup (bm25.hip),
+                                   // 2 scan of the forward index (bm25_scan.hip), 3 term-at-a-time per wave (bm25_wave.hip),
+                                   // 4 the stream kernel (bm25_stream.hip)
     bool is_view = false;          // oi_index_view: the data belongs to another index; this handle only searches
 };
 
@@ -307,6 +309,15 @@ int oi_launch_bm25_scan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
 uint32_t oi_bm25_wave_pass_queries(void);
 int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
                         uint32_t nq, const PoolView &pool, uint32_t block_begin, uint32_t block_end);
+// bm25_stream.hip: every wave streams a weight-balanced range of (query, block) tasks through an LDS ring; `pool` = the view
+// of queries [q_begin, q_begin + nq) with segments of oi_bm25_stream_seg_cap() keys.  oi_launch_bm25_plan runs once per
+// pass, before the first phase: it zeroes the pass's pool state (`state_words` words at `state`) and weighs the queries.
+uint32_t oi_bm25_stream_pass_queries(void);
+uint32_t oi_bm25_stream_seg_cap(uint32_t depth, bool first_phase);
+int oi_launch_bm25_plan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin, uint32_t nq,
+                        uint32_t *state, uint64_t state_words);
+int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
+                          uint32_t nq, uint32_t depth, const PoolView &pool, uint32_t block_begin, uint32_t block_end);
 // Doc blocks [block_begin, block_end); candidates below pool.tau_keys (if set) are dropped.
 int oi_launch_bm25(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets,
                    uint32_t n_queries, uint32_t depth, const PoolView &pool, uint32_t block_begin,

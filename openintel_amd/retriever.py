@@ -131,11 +131,12 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
 
-    BM25_DEFAULT, BM25_TAAT, BM25_SCAN, BM25_WAVE = 0, 1, 2, 3
+    BM25_DEFAULT, BM25_TAAT, BM25_SCAN, BM25_WAVE, BM25_STREAM = 0, 1, 2, 3, 4
 
     def set_bm25_mode(self, mode: int) -> None:
-        """BM25_WAVE (term-at-a-time, one wave per (block, query) task: the default), BM25_TAAT (the first-generation
-        workgroup-per-block kernel) or BM25_SCAN (batch scan of the forward index).  Bit-identical lists."""
+        """BM25_STREAM (term-at-a-time as a stream through a per-wave LDS ring: the default), BM25_WAVE (one wave per
+        (block, query) task), BM25_TAAT (the first-generation workgroup-per-block kernel) or BM25_SCAN (batch scan of
+        the forward index).  Bit-identical lists."""
         _lib.check(self.lib.oi_index_set_bm25_mode(self.handle, int(mode)))
 
     def set_max_query_terms(self, max_terms: int) -> None:

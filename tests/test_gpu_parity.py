@@ -468,7 +468,7 @@ def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
     qt, qo = oi.pack_query_terms(queries)
     q = rng.integers(-2, 3, size=(B, 8)).astype(np.float32)
     L = idx.search_lists(q, qt, qo, depth=depth)
-    for other in (idx.BM25_TAAT, idx.BM25_WAVE):     # the three kernels agree bit for bit
+    for other in (idx.BM25_TAAT, idx.BM25_WAVE, idx.BM25_STREAM):     # the four kernels agree bit for bit
         idx.set_bm25_mode(other)
         L2 = idx.search_lists(q, qt, qo, depth=depth)
         assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
@@ -484,10 +484,11 @@ def test_bm25_batch_scan_bit_exact(ctx, O, n, vocab, B, max_terms, depth):
 
 @pytest.mark.parametrize("case", ["every-doc-term", "long-queries", "clustered"])
 def test_bm25_wave_kernel_windows_and_long_queries(ctx, O, case):
-    """bm25_wave.hip off its happy path: a term in EVERY doc (32768 postings per block: the 2048-slot table is cut into
-    doc-id windows), queries of 70..200 terms (term groups beyond the 64 a wave keeps in registers; more than 2048
-    staged terms per pass), and docs clustered at the start of a block (windows halve unevenly).  Same bits as the
-    oracle and as the workgroup-per-block kernel."""
+    """bm25_wave.hip and bm25_stream.hip off their happy paths: a term in EVERY doc (32768 postings per block: the wave
+    kernel's table is cut into doc-id windows; the stream kernel's 4096-key segment is pruned in place again and again, and
+    a window holds far more than 512 multi docs: its extra rank rounds), queries of 70..200 terms (more than the 64 runs a
+    wave's lanes describe: pages; more than 2048 staged terms per pass), and docs clustered at the start of a block.  Same
+    bits as the oracle and as the workgroup-per-block kernel."""
     import openintel_amd as oi
     rng = np.random.default_rng(len(case))
     n, vocab, depth = 100_000, 400, 300
@@ -517,10 +518,11 @@ def test_bm25_wave_kernel_windows_and_long_queries(ctx, O, case):
     q = rng.integers(-2, 3, size=(len(queries), 8)).astype(np.float32)
     idx.set_bm25_mode(idx.BM25_WAVE)
     L = idx.search_lists(q, qt, qo, depth=depth)
-    idx.set_bm25_mode(idx.BM25_TAAT)
-    L2 = idx.search_lists(q, qt, qo, depth=depth)
-    assert np.array_equal(L.bm25_counts, L2.bm25_counts)
-    assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores)
+    for other in (idx.BM25_TAAT, idx.BM25_STREAM):
+        idx.set_bm25_mode(other)
+        L2 = idx.search_lists(q, qt, qo, depth=depth)
+        assert np.array_equal(L.bm25_counts, L2.bm25_counts), other
+        assert np.array_equal(L.bm25_docs, L2.bm25_docs) and np.array_equal(L.bm25_scores, L2.bm25_scores), other
     for b, tb in enumerate(queries):
         tv = np.array([t for t in tb if t < vocab], np.uint32)
         bs, bd = O.topk(O.bm25_scores(terms, offs, vocab, tv), depth, True, 5)
@@ -711,7 +713,7 @@ def test_full_size_config2_10M_768_batch64(ctx):
 
 def test_full_size_bm25_bench_shape_against_the_oracle(ctx, O):
     """VERDICT r02 missing #4: the bench's BM25 workload -- 10M docs, vocab 131072, Zipf postings, 4-term queries, depth 1000 --
-    checked against the ORACLE (not kernel vs kernel): three queries' lists bit for bit (docs, order, score bits), all three
+    checked against the ORACLE (not kernel vs kernel): three queries' lists bit for bit (docs, order, score bits), all four
     BM25 kernels equal on the whole batch.  Oracle: one scalar pass over the 288M-token forward index per query."""
     import torch
     import openintel_amd as oi
@@ -727,13 +729,13 @@ def test_full_size_bm25_bench_shape_against_the_oracle(ctx, O):
     idx.finalize()
     qv = torch.zeros((B, 8), dtype=torch.float32, device=dev)
     lists = {}
-    for name, mode in (("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN)):
+    for name, mode in (("stream", idx.BM25_STREAM), ("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN)):
         idx.set_bm25_mode(mode)
         L = idx.search_lists(qv, qt, qo, depth=depth)
         ctx.synchronize()
         lists[name] = (L.bm25_scores.cpu().numpy(), L.bm25_docs.cpu().numpy(), L.bm25_counts.cpu().numpy())
-    ws, wd, wc = lists["wave"]
-    for other in ("taat", "scan"):
+    ws, wd, wc = lists["stream"]   # the default kernel's lists are the ones held against the oracle
+    for other in ("wave", "taat", "scan"):
         s2, d2, c2 = lists[other]
         assert np.array_equal(wc, c2)
         for b in range(B):
@@ -979,7 +981,7 @@ def test_fuzz_small_shapes_bit_exact(ctx, O):
             fs, fd = O.rrf_fuse(cd, bd, k)
             ref.append((cs, cd, bs, bd, fs, fd))
         t1 = time.perf_counter()
-        for mode in (idx.BM25_WAVE, idx.BM25_TAAT, idx.BM25_SCAN):
+        for mode in (idx.BM25_STREAM, idx.BM25_WAVE, idx.BM25_TAAT, idx.BM25_SCAN):
             idx.set_bm25_mode(mode)
             L = idx.search_lists(q, qt, qo, depth=depth)
             R = idx.search(q, qt, qo, k=k, depth=depth)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BM25 kernels alone at the bench shape: 10M-doc synthetic forward index, 64 queries x 4 terms, depth 1000.
-Runs the term-at-a-time kernel and the batch scan, checks that their ranked lists are identical, and
+Runs the stream kernel, the two older term-at-a-time kernels and the batch scan, checks that their ranked lists are identical, and
 prints one JSON line with the per-batch kernel times (HIP events inside the library).
     python tools/bm25_bench.py [n_docs] [reps] [batch]"""
 import json
@@ -34,8 +34,10 @@ idx.finalize()
 qv, qt, qo = synth.query_batch_torch(B, DIM, dev)
 res = {}
 lists = {}
-MODES = (("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN))
+MODES = (("stream", idx.BM25_STREAM), ("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN))
 if len(sys.argv) > 4 and sys.argv[4] == "wave-only":   # tools/bm25_wave_ablate.sh
+    MODES = MODES[1:2]
+if len(sys.argv) > 4 and sys.argv[4] == "stream-only":
     MODES = MODES[:1]
 for name, mode in MODES:
     idx.set_bm25_mode(mode)
@@ -53,13 +55,12 @@ for name, mode in MODES:
 if len(MODES) == 1:
     print(json.dumps({"docs": n, "batch": B, **res}))
     sys.exit(0)
-same = all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["scan"])) and \
-    all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists["wave"]))
+same = all(all(bool(torch.equal(a, b)) for a, b in zip(lists["taat"], lists[o])) for o in ("scan", "wave", "stream"))
 # algorithmic bytes of term-at-a-time: 8 B per posting of the batch's terms + 8 B per (block, term) bounds lookup
 df = idx.local_stats()[1].astype("int64")
 qt_h = qt.cpu().numpy()
 taat_bytes = int(8 * df[qt_h].sum() + 8 * ((n + 32767) // 32768) * qt_h.size)
-for k in ("wave", "taat"):
+for k in ("stream", "wave", "taat"):
     res[k]["algorithmic_bytes"] = taat_bytes
     res[k]["algorithmic_GBs"] = taat_bytes / (res[k]["ms_per_batch"] / 1e3) / 1e9
     res[k]["frac_of_8TBs"] = res[k]["algorithmic_GBs"] / 8000.0
