@@ -359,7 +359,8 @@ int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_term
 /*
  * A host with no collective library of its own (the Rust composition root, src/main.rs:17-39, has none -- the reference
  * is single-process, src/domain/ports/mod.rs:1-8) gets the whole multi-GPU path from three calls.  RCCL is loaded on
- * first use (dlopen "librccl.so.1"; OI_ERR_UNSUPPORTED if absent).  A Python host that already runs torch.distributed
+ * first use (dlopen "librccl.so.1", or the library OI_RCCL_LIB names; OI_ERR_UNSUPPORTED with the loader's message if
+ * it cannot be loaded -- tests/test_abi.py takes that path).  A Python host that already runs torch.distributed
  * can keep using oi_search_lists_packed + its own all-gather + oi_fuse_packed (openintel_amd/sharded.py): same results.
  *
  *   rank 0:  oi_comm_unique_id(id)  -> ship the OI_COMM_ID_BYTES to every rank over the host's own channel (file, socket, env)
@@ -373,6 +374,9 @@ int oi_search(oi_index *idx, const float *query_vecs, const uint32_t *query_term
  *                                                                  top-depth per list -> RRF.  Identical output on every rank.
  * Collectives run on the ctx stream in call order: every rank must issue them in the same order (one host thread per
  * comm, or external ordering).  With OI_DEVICE buffers oi_search_sharded is asynchronous like oi_search.
+ * Executed so far with a communicator of ONE rank only (tests/test_gpu_native_comm.py): the build's GPU lease has one
+ * device and RCCL refuses two ranks on one device.  The same choreography over torch.distributed (sharded.py) has run
+ * with 2 and 8 gloo ranks; N > 1 through THESE entry points is unexecuted code.
  */
 #define OI_COMM_ID_BYTES 128
 int oi_comm_unique_id(uint8_t id_out[OI_COMM_ID_BYTES]);

@@ -233,7 +233,8 @@ int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, c
     const float avgdl = (float)((double)global_tokens / (double)global_n);
     idx->avgdl = avgdl;
     if (idx->n_postings) {
-        OI_CHECK(idx->postings.ensure(sizeof(Posting) * idx->n_postings));
+        // (+1 KiB: the stream kernel moves postings in 1 KiB chunks, and a run's last chunk may extend past the array)
+        OI_CHECK(idx->postings.ensure(sizeof(Posting) * idx->n_postings + 1024));
         uint64_t blocks = (idx->n_postings + 255) / 256;
         if (blocks > 65535) blocks = 65535;
         hipLaunchKernelGGL(bm_impact_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),

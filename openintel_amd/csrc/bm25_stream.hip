@@ -53,9 +53,8 @@
 #define BS_CAP 512u       // multi-doc accumulators per window and round
 #define BS_STAGE 192u     // staged keys (a chunk appends <= 128 to < 64 left over)
 #define BS_MAX_Q 128u     // queries per pass
-#define BS_FIX_COST 160u  // weight of a task beside its postings (windows, sweeps, run switches), in postings
-
-typedef uint32_t bs_u32x4 __attribute__((ext_vector_type(4)));
+#define BS_RUN_COST 64u   // weight of a run beside its postings (a run's last chunk is half empty on average; the sweep and the
+                          // task's own steps count as one more run), in postings: the cost of a task is its chunk visits
 
 struct BsArgs {
     const uint2 *postings;     // {doc_in_block, impact bits}, term-major
@@ -80,27 +79,6 @@ __device__ __forceinline__ uint32_t bs_lds_addr(const void *p) {
 __device__ __forceinline__ uint32_t bs_rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t bs_readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
-// One chunk: 64 lanes x 16 B from base + 16 * lane into the 1 KiB at lds_dst.  Bytes past `bytes_left` read as zero.
-// hipcc does not see this load: it is ordered by bs_wait_vm().
-__device__ __forceinline__ void bs_dma_chunk(const void *base, uint32_t bytes_left, uint32_t lds_dst, uint32_t lane16) {
-    const uint64_t b = (uint64_t)base;
-    bs_u32x4 srd;
-    srd[0] = bs_rfl((uint32_t)b);
-    srd[1] = bs_rfl((uint32_t)(b >> 32) & 0xFFFFu); // stride 0
-    srd[2] = bs_rfl(bytes_left);
-    srd[3] = 0x00020000u;
-    uint32_t keep;
-    const uint32_t d = bs_rfl(lds_dst);
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 4\n\t"
-        "buffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane16), "s"(srd), "s"(d)
-        : "memory");
-}
 // One dword per lane from each lane's own address into lds_dst + 4 * lane (the bounds of the next task).
 __device__ __forceinline__ void bs_dma_word(const uint32_t *gptr, uint32_t lds_dst) {
     uint32_t keep;
@@ -145,20 +123,29 @@ __device__ __forceinline__ uint32_t bs_incl_scan(uint32_t v) {
     return v;
 }
 
-enum { BS_CHUNK = 0, BS_END_A = 1, BS_END_B = 2, BS_START_TASK = 3, BS_END_TASK = 4 };
-
 // ---------------------------------------------------------------------------------------------------------------
 // Per-wave LDS (W docs per window, WORDS = W / 32):
 //   seen u32[WORDS] | multi u32[WORDS] | pref u16[WORDS] | acc f32[BS_CAP] | accdoc u32[BS_CAP] | stage u64[BS_STAGE] |
-//   desc u32[2][3][64] | (pad to 1 KiB) | ring [BS_RING][1 KiB]
+//   bounds u32[2][3][64] | (pad to 1 KiB) | ring [BS_RING][1 KiB];   head u32[64] lies over accdoc[0..64): a table is
+//   built between two windows, when no accumulator is live
 template <int W>
 struct BsLds {
     static constexpr uint32_t WORDS = W / 32;
     static constexpr uint32_t OFF_SEEN = 0, OFF_MULTI = WORDS * 4, OFF_PREF = WORDS * 8, OFF_ACC = WORDS * 10,
                               OFF_ACCDOC = OFF_ACC + BS_CAP * 4, OFF_STAGE = OFF_ACCDOC + BS_CAP * 4,
-                              OFF_DESC = OFF_STAGE + BS_STAGE * 8, OFF_RING = (OFF_DESC + 2 * 3 * 256 + 1023) & ~1023u,
-                              WAVE = OFF_RING + BS_RING * 1024;
-    static constexpr uint32_t TOTAL = BS_WPB * WAVE + (BS_MAX_Q + 2) * 8;
+                              OFF_DESC = OFF_STAGE + BS_STAGE * 8, OFF_HEAD = OFF_ACCDOC, // (head: see below)
+                              OFF_RING = (OFF_DESC + 2 * 3 * 256 + 1023) & ~1023u, WAVE = OFF_RING + BS_RING * 1024;
+    static constexpr uint32_t TOTAL = BS_WPB * WAVE + (BS_MAX_Q + 2) * 8 + BS_MAX_Q * 4; // + the plan's prefix and the thresholds
+};
+
+// The chunks of one window, one per lane (lane k = chunk k, in query order; a chunk never spans two runs): where its 128
+// postings start (an even index: 16-byte aligned), which of them belong to the run, the run's idf.
+struct BsTable {
+    uint32_t pos;   // posting index of the chunk's first slot
+    uint32_t lohi;  // first valid slot (0 or 1) | (one past the last valid slot, 1..128) << 8
+    uint32_t idf;   // f32 bits
+    uint32_t C;     // chunks of the window (uniform); 0 with slow = false: nothing to do
+    bool slow;      // more than 64 chunks, or a query of more than 64 terms: the window goes through the direct passes
 };
 
 template <int W>
@@ -167,23 +154,30 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     constexpr uint32_t WORDS = L::WORDS, WPL = WORDS / 64; // map words per lane in the sweep: 8 (W = 16384) or 16
     constexpr uint32_t NWB = BS_BLOCK / W;                  // windows per block: 2 or 1
     constexpr uint32_t WSTEP = W / BS_FINE;                 // cells per window: 1 or 2
+    constexpr uint32_t R = BS_RING;
+    static_assert((R & (R - 1)) == 0 && R >= 4, "ring slots: a power of two");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wv = bs_rfl(tid >> 6);
     unsigned char *wl = smem + wv * L::WAVE;
     uint32_t *seen = reinterpret_cast<uint32_t *>(wl + L::OFF_SEEN);
     uint32_t *multi = reinterpret_cast<uint32_t *>(wl + L::OFF_MULTI);
-    uint16_t *pref = reinterpret_cast<uint16_t *>(wl + L::OFF_PREF);
+    uint32_t *pref = reinterpret_cast<uint32_t *>(wl + L::OFF_PREF); // two 16-bit ranks per word
     float *acc = reinterpret_cast<float *>(wl + L::OFF_ACC);
     uint32_t *accdoc = reinterpret_cast<uint32_t *>(wl + L::OFF_ACCDOC);
     uint64_t *stage = reinterpret_cast<uint64_t *>(wl + L::OFF_STAGE);
     uint32_t *desc = reinterpret_cast<uint32_t *>(wl + L::OFF_DESC);
+    // (an explicit LDS pointer: a volatile access through a generic one becomes a FLAT instruction waited for with vmcnt(0))
+    typedef volatile __attribute__((address_space(3))) uint32_t bs_lds_vu32;
+    bs_lds_vu32 *head = (bs_lds_vu32 *)(__attribute__((address_space(3))) void *)(wl + L::OFF_HEAD);
     const uint4 *ring16 = reinterpret_cast<const uint4 *>(wl + L::OFF_RING);
     uint64_t *s_cum = reinterpret_cast<uint64_t *>(smem + BS_WPB * L::WAVE);
+    uint32_t *s_tau = reinterpret_cast<uint32_t *>(s_cum + BS_MAX_Q + 2); // the queries' thresholds (fixed for the launch)
     const uint32_t ring_w = bs_lds_addr(wl + L::OFF_RING), desc_w = bs_lds_addr(desc);
 
-    // ---- prologue: the plan's prefix in LDS, this wave's maps and accumulators zero
+    // ---- prologue: the plan's prefix and the thresholds in LDS, this wave's maps and accumulators zero
     for (uint32_t i = tid; i <= a.nq; i += BS_WPB * 64) s_cum[i] = a.cum[i];
+    for (uint32_t i = tid; i < a.nq; i += BS_WPB * 64) s_tau[i] = a.tau_keys ? a.tau_keys[i] : 0u;
     {
         uint4 *z = reinterpret_cast<uint4 *>(wl);
         for (uint32_t i = lane; i < (WORDS * 8) / 16; i += 64) z[i] = make_uint4(0u, 0u, 0u, 0u); // seen | multi
@@ -216,141 +210,9 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     const uint32_t lane16 = lane * 16;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    // ================================================================ producer state (all wave-uniform)
-    uint32_t p_r = r0, p_blk = b0, p_blk_hi = 0;      // current task; blocks [.., p_blk_hi) of query p_r are mine
-    uint32_t p_T = 0, p_tb = 0, p_page = 0xFFFFFFFFu; // the query's terms; which 64 of its runs the lanes describe
-    uint32_t d_cb = 0;                                // lane j: cell index of (term j of the page, window 0); 0 without a run
-    bool d_ok = false;                                // lane j: the page has a term j and it is inside the vocabulary
-    float d_idf = 0.f;                                // lane j: idf of that term
-    uint32_t c0 = 0, c1 = 0, c2 = 0;                  // lane j: cell_start words of the current block (windows 0, 1, end)
-    bool p_done = false, p_started = false, p_need_task = true, p_query_loaded = false;
-    uint32_t p_win = 0, p_pass = 0, p_j = 0, p_pos = 0, p_end = 0, p_chunks = 0;
-    float p_idf = 0.f;
-    uint32_t p_pf_blk = 0xFFFFFFFFu, p_pf_buf = 0, p_pf_seq = 0; // prefetched bounds: of which block, where, issued when
-    uint32_t vseq = 0;      // asm vector-memory operations issued so far (chunk and bounds DMAs)
-    uint32_t n_issued = 0;  // chunk DMAs issued (ring slot = n_issued % BS_RING)
-    uint32_t n_consumed = 0;
-    uint32_t f0 = 0, f1 = 0, f2 = 0, f_head = 0, f_tail = 0; // FIFO of descriptors in the lanes of three VGPRs
-    auto push = [&](uint32_t w0, uint32_t w1, uint32_t sq) {
-        const bool here = lane == (f_tail & 63u); // (this clang has no writelane builtin: one compare, three selects)
-        f0 = here ? w0 : f0;
-        f1 = here ? w1 : f1;
-        f2 = here ? sq : f2;
-        ++f_tail;
-    };
-    // cell words of block `blk` for the lanes' runs, by LDS-DMA into bounds buffer `buf` (no VGPR destination)
-    auto issue_bounds = [&](uint32_t blk, uint32_t buf) {
-        const uint32_t *src = a.cells + d_cb + 2u * (a.block0 + blk); // (lanes without a run: d_cb = 0, any valid word)
-        bs_dma_word(src, desc_w + (buf * 3u + 0u) * 256u);
-        bs_dma_word(src + 1, desc_w + (buf * 3u + 1u) * 256u);
-        bs_dma_word(src + 2, desc_w + (buf * 3u + 2u) * 256u);
-        vseq += 3;
-    };
-    auto read_bounds = [&](uint32_t buf) {
-        c0 = desc[(buf * 3u + 0u) * 64u + lane];
-        c1 = desc[(buf * 3u + 1u) * 64u + lane];
-        c2 = desc[(buf * 3u + 2u) * 64u + lane];
-    };
-    // the lanes' runs = terms [64 page, 64 page + 64) of query p_r (plain loads: once per query in the common case)
-    auto load_page = [&](uint32_t page) {
-        const uint32_t j = 64u * page + lane;
-        uint32_t term = 0xFFFFFFFFu;
-        if (j < p_T) term = a.q_terms[p_tb + j];
-        d_ok = term < a.vocab;
-        d_cb = d_ok ? term * a.n_win : 0u;
-        d_idf = d_ok ? a.idf[term] : 0.f;
-        p_page = page;
-    };
-    auto fix_bounds = [&]() { // lanes without a run: an empty one
-        c0 = d_ok ? c0 : 0u; c1 = d_ok ? c1 : 0u; c2 = d_ok ? c2 : 0u;
-    };
-    auto bounds_now = [&](uint32_t blk) { // synchronously (query switch, page switch)
-        issue_bounds(blk, 0);
-        bs_wait_vm(0);
-        read_bounds(0);
-        fix_bounds();
-        p_pf_blk = 0xFFFFFFFFu;
-    };
-    auto run_of = [&](uint32_t j, uint32_t win, uint32_t &s, uint32_t &e, float &wt) { // run j of the current page
-        const uint32_t l = j & 63u;
-        if (NWB == 1) { s = bs_readlane(c0, l); e = bs_readlane(c2, l); }
-        else if (win == 0) { s = bs_readlane(c0, l); e = bs_readlane(c1, l); }
-        else { s = bs_readlane(c1, l); e = bs_readlane(c2, l); }
-        wt = __uint_as_float(bs_readlane(__float_as_uint(d_idf), l));
-    };
-
-    // One step of the sequence generator: pushes exactly ONE descriptor (or sets p_done).
-    auto produce = [&]() {
-        for (;;) {
-            if (p_need_task) {
-                if (p_r > r1 || (p_r == r1 && p_blk >= b1) || p_r >= nq) { p_done = true; return; }
-                if (!p_query_loaded) {
-                    const uint32_t q = a.q_begin + p_r;
-                    p_tb = bs_rfl(a.q_offsets[q]);
-                    p_T = bs_rfl(a.q_offsets[q + 1]) - p_tb;
-                    p_blk_hi = p_r == r1 ? b1 : nbh;
-                    load_page(0);
-                    p_query_loaded = true;
-                    p_pf_blk = 0xFFFFFFFFu;
-                }
-                if (p_page != 0u) { load_page(0); p_pf_blk = 0xFFFFFFFFu; }
-                if (p_pf_blk == p_blk) { // the bounds were prefetched while the previous block was produced
-                    bs_wait_vm(vseq - p_pf_seq - 3u);
-                    read_bounds(p_pf_buf);
-                    fix_bounds();
-                } else bounds_now(p_blk);
-                if (p_blk + 1 < p_blk_hi) { // the next block's bounds, in flight while this one is produced
-                    p_pf_buf ^= 1u;
-                    p_pf_seq = vseq;
-                    issue_bounds(p_blk + 1, p_pf_buf);
-                    p_pf_blk = p_blk + 1;
-                } else p_pf_blk = 0xFFFFFFFFu;
-                p_need_task = false;
-                p_started = false;
-                p_win = 0; p_pass = 0; p_j = 0xFFFFFFFFu; p_pos = p_end = 0; p_chunks = 0;
-            }
-            if (p_pos < p_end) { // ---- one chunk of the current run: 128 postings from an even index
-                if (!p_started) { p_started = true; push(BS_START_TASK, p_r | (p_blk << 8), 0); return; }
-                const uint32_t cs = p_pos & ~1u;
-                const uint32_t lo = p_pos - cs, hi = p_end - cs < 128u ? p_end - cs : 128u;
-                const uint64_t left = (a.n_postings - cs) * 8ull;
-                const uint32_t slot = n_issued % BS_RING;
-                bs_dma_chunk(a.postings + cs, left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)left, ring_w + slot * 1024u, lane16);
-                push(BS_CHUNK | (p_pass << 3) | (lo << 4) | (hi << 8) | (slot << 16), __float_as_uint(p_idf), vseq);
-                ++vseq; ++n_issued; ++p_chunks;
-                p_pos = cs + 128u;
-                return;
-            }
-            // ---- next run of this (window, pass)
-            ++p_j;
-            if (p_j < p_T) {
-                if ((p_j >> 6) != p_page) { load_page(p_j >> 6); bounds_now(p_blk); } // a query of more than 64 terms
-                run_of(p_j, p_win, p_pos, p_end, p_idf);
-                continue;
-            }
-            // ---- end of the pass
-            if (p_pass == 0 && p_chunks) { // its postings again, as pass B
-                push(BS_END_A, p_win, 0);
-                p_pass = 1; p_j = 0xFFFFFFFFu; p_pos = p_end = 0;
-                return;
-            }
-            const bool was_b = p_pass == 1;
-            p_pass = 0; p_j = 0xFFFFFFFFu; p_pos = p_end = 0; p_chunks = 0;
-            ++p_win;
-            if (p_win == NWB) { // ---- end of the task
-                p_need_task = true;
-                ++p_blk;
-                if (p_blk >= p_blk_hi) { ++p_r; p_blk = 0; p_query_loaded = false; }
-                if (was_b) { push(BS_END_B | (1u << 3), 0, 0); return; } // (bit 3: the task ends with this window)
-                if (p_started) { push(BS_END_TASK, 0, 0); return; }
-                continue;
-            }
-            if (was_b) { push(BS_END_B, 0, 0); return; }
-        }
-    };
-
-    // ================================================================ consumer state
-    uint32_t t_q = 0, t_blk = 0, t_doc0 = 0, t_tau = 0, t_tau_q = 0, out_n = 0, st_n = 0, t_M = 0, t_win = 0;
+    // ================================================================ the task being scored
+    uint32_t t_q = 0, t_blk = 0, t_doc0 = 0, t_tau = 0, t_tau_q = 0, out_n = 0, st_n = 0, t_M = 0;
+    uint32_t q_tb = 0, q_T = 0; // the query's terms
     uint64_t *t_seg = a.pools;
     const uint32_t seg_cap = a.seg_cap;
 
@@ -424,6 +286,13 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             if (st_n >= 64u) flush64();
         }
     };
+    auto start_task = [&](uint32_t blk) {
+        t_blk = blk;
+        t_doc0 = a.doc_id_base + (a.block0 + blk) * BS_BLOCK;
+        t_tau = t_tau_q;
+        t_seg = a.pools + (uint64_t)t_q * a.pool_stride + a.carry_cap + (uint64_t)(a.block0 + blk) * seg_cap;
+        out_n = 0;
+    };
     auto end_task = [&]() {
         if (st_n) {
             if (out_n + st_n > seg_cap) prune();
@@ -450,129 +319,266 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     // a multi doc's posting: acc[rank - lo] += x, in call order (ranks outside [lo, lo + BS_CAP) belong to another round)
     auto add_multi = [&](bool mul, uint32_t word, uint32_t mw, uint32_t bit, uint32_t dib, float x, uint32_t lo) {
         if (mul) {
-            const uint32_t rr = (uint32_t)pref[word] + (uint32_t)__popc(mw & (bit - 1u)) - lo;
+            const uint32_t pw = pref[word >> 1];
+            const uint32_t rr = ((word & 1u) ? pw >> 16 : pw & 0xFFFFu) + (uint32_t)__popc(mw & (bit - 1u)) - lo;
             if (rr < BS_CAP) {
                 acc[rr] = __fadd_rn(acc[rr], x);
                 accdoc[rr] = dib;
             }
         }
     };
-    // Rounds beyond the first (more than BS_CAP multi docs in the window): the window's runs again, straight from
-    // global memory, adding only the multi docs of ranks [lo, lo + BS_CAP).  Exact for any data, rare.
-    auto slow_rounds = [&]() {
-        const uint32_t q = a.q_begin + t_q;
-        const uint32_t tb = bs_rfl(a.q_offsets[q]), te = bs_rfl(a.q_offsets[q + 1]);
-        for (uint32_t lo = BS_CAP; lo < t_M; lo += BS_CAP) {
-            for (uint32_t j = tb; j < te; ++j) {
-                const uint32_t term = bs_rfl(a.q_terms[j]);
-                if (term >= a.vocab) continue;
-                const uint64_t cell = (uint64_t)term * a.n_win + 2u * (a.block0 + t_blk) + t_win * WSTEP;
-                const uint32_t s = bs_rfl(a.cells[cell]), e = bs_rfl(a.cells[cell + WSTEP]);
-                const float wt = a.idf[term];
-                for (uint32_t i0 = s; i0 < e; i0 += 64) {
-                    const bool ok = i0 + lane < e;
-                    const uint2 p = a.postings[ok ? i0 + lane : s];
-                    const uint32_t ix = p.x & (W - 1u), bit = 1u << (ix & 31u), mw = multi[ix >> 5];
-                    add_multi(ok && (mw & bit), ix >> 5, mw, bit, p.x, __fmul_rn(wt, __uint_as_float(p.y)), lo);
-                }
+    // pass A on two postings per lane (bit = 0: not a posting of the run): seen, then multi for the docs seen before
+    auto pass_a = [&](uint32_t i0, uint32_t bit0, uint32_t i1, uint32_t bit1) {
+        const uint32_t o0 = atomicOr(&seen[i0 >> 5], bit0);
+        const uint32_t o1 = atomicOr(&seen[i1 >> 5], bit1);
+        const uint32_t again0 = o0 & bit0, again1 = o1 & bit1; // the doc was in an earlier run
+        if (again0) atomicOr(&multi[i0 >> 5], again0);
+        if (again1) atomicOr(&multi[i1 >> 5], again1);
+    };
+    // pass B on two postings per lane, ranks [lo, lo + BS_CAP) of the multi docs; single-run docs are emitted iff `singles`
+    auto pass_b = [&](uint32_t i0, uint32_t bit0, uint32_t d0, float x0, uint32_t i1, uint32_t bit1, uint32_t d1, float x1,
+                      uint32_t lo, bool singles) {
+        const uint32_t mw0 = multi[i0 >> 5], mw1 = multi[i1 >> 5];
+        const bool mul0 = (mw0 & bit0) != 0u, mul1 = (mw1 & bit1) != 0u;
+        if (singles) {
+            const bool k0 = bit0 && !mul0 && x0 > 0.0f && oi_f32_key(x0) >= t_tau; // (BM25 lists hold scores > 0 only)
+            const bool k1 = bit1 && !mul1 && x1 > 0.0f && oi_f32_key(x1) >= t_tau;
+            emit2(k0, oi_rank_key(x0, t_doc0 + d0), k1, oi_rank_key(x1, t_doc0 + d1));
+        }
+        if (__ballot(mul0 || mul1)) { // a lane's two postings are one run: distinct docs
+            add_multi(mul0, i0 >> 5, mw0, bit0, d0, x0, lo);
+            add_multi(mul1, i1 >> 5, mw1, bit1, d1, x1, lo);
+        }
+    };
+    // the sweep between the passes: ranks of the multi docs (exclusive popcount prefix per map word), seen cleared
+    auto sweep = [&]() {
+        const uint4 *m4 = reinterpret_cast<const uint4 *>(multi) + lane * (WPL / 4);
+        uint4 *s4 = reinterpret_cast<uint4 *>(seen) + lane * (WPL / 4);
+        uint32_t mwd[WPL], run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < WPL / 4; ++k) {
+            const uint4 m = m4[k];
+            mwd[4 * k] = m.x; mwd[4 * k + 1] = m.y; mwd[4 * k + 2] = m.z; mwd[4 * k + 3] = m.w;
+        }
+        uint32_t ex[WPL];
+#pragma unroll
+        for (uint32_t k = 0; k < WPL; ++k) { ex[k] = run; run += (uint32_t)__popc(mwd[k]); }
+        const uint32_t incl = bs_incl_scan(run);
+        const uint32_t base = incl - run;
+        t_M = bs_readlane(incl, 63);
+        if (t_M) {
+            uint4 *p4 = reinterpret_cast<uint4 *>(pref) + lane * (WPL / 8);
+#pragma unroll
+            for (uint32_t k = 0; k < WPL / 8; ++k) {
+                uint4 o;
+                o.x = (base + ex[8 * k]) | ((base + ex[8 * k + 1]) << 16);
+                o.y = (base + ex[8 * k + 2]) | ((base + ex[8 * k + 3]) << 16);
+                o.z = (base + ex[8 * k + 4]) | ((base + ex[8 * k + 5]) << 16);
+                o.w = (base + ex[8 * k + 6]) | ((base + ex[8 * k + 7]) << 16);
+                p4[k] = o;
             }
-            emit_multi(lo);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < WPL / 4; ++k) s4[k] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    // Window `win` of the task straight from global memory, run by run in query order, 64 postings per step: the rounds
+    // beyond the first of a window with more than BS_CAP multi docs, and whole windows the tables cannot describe.
+    auto direct_runs = [&](uint32_t win, auto &&f) {
+        for (uint32_t j = q_tb; j < q_tb + q_T; ++j) {
+            const uint32_t term = bs_rfl(a.q_terms[j]);
+            if (term >= a.vocab) continue;
+            const uint64_t cell = (uint64_t)term * a.n_win + 2u * (a.block0 + t_blk) + win * WSTEP;
+            const uint32_t s = bs_rfl(a.cells[cell]), e = bs_rfl(a.cells[cell + WSTEP]);
+            const float wt = a.idf[term];
+            for (uint32_t i0 = s; i0 < e; i0 += 64) {
+                const bool ok = i0 + lane < e;
+                const uint2 p = a.postings[ok ? i0 + lane : s];
+                const uint32_t ix = p.x & (W - 1u);
+                f(ix, ok ? 1u << (ix & 31u) : 0u, p.x, __fmul_rn(wt, __uint_as_float(p.y)));
+            }
+        }
+    };
+    auto direct_pass_b = [&](uint32_t win, uint32_t lo, bool singles) {
+        direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t dib, float x) { pass_b(ix, bit, dib, x, 0u, 0u, 0u, 0.f, lo, singles); });
+    };
+    auto finish_window = [&](uint32_t win) { // after pass B's first round: the multi docs out, further rounds, maps clean
+        if (t_M) {
+            emit_multi(0u);
+            for (uint32_t lo = BS_CAP; lo < t_M; lo += BS_CAP) {
+                direct_pass_b(win, lo, false);
+                emit_multi(lo);
+            }
+            uint4 *m4 = reinterpret_cast<uint4 *>(multi) + lane * (WPL / 4);
+#pragma unroll
+            for (uint32_t k = 0; k < WPL / 4; ++k) m4[k] = make_uint4(0u, 0u, 0u, 0u);
+            t_M = 0;
         }
     };
 
-    // ================================================================ the stream
-    for (;;) {
-        while (!p_done && n_issued - n_consumed < BS_RING && f_tail - f_head < 56u) produce();
-        if (f_head == f_tail) break; // (p_done, nothing queued)
-        const uint32_t at = f_head & 63u;
-        const uint32_t e0 = bs_readlane(f0, at), e1 = bs_readlane(f1, at), e2 = bs_readlane(f2, at);
-        ++f_head;
-        const uint32_t kind = e0 & 7u;
-        if (kind == BS_CHUNK) {
-            const uint32_t lo = (e0 >> 4) & 1u, hi = (e0 >> 8) & 255u, slot = (e0 >> 16) & 15u;
-            bs_wait_vm(vseq - e2 - 1u);
-            const uint4 v = ring16[slot * 64u + lane];
-            const uint32_t i0 = v.x & (W - 1u), i1 = v.z & (W - 1u);
-            const bool ok0 = 2u * lane >= lo && 2u * lane < hi, ok1 = 2u * lane + 1u < hi; // (2 lane + 1 >= lo always)
-            const uint32_t bit0 = ok0 ? 1u << (i0 & 31u) : 0u, bit1 = ok1 ? 1u << (i1 & 31u) : 0u;
-            if (!(e0 & 8u)) { // ---- pass A
-                const uint32_t o0 = atomicOr(&seen[i0 >> 5], bit0);
-                const uint32_t o1 = atomicOr(&seen[i1 >> 5], bit1);
-                const uint32_t again0 = o0 & bit0, again1 = o1 & bit1; // the doc was in an earlier run
-                if (again0) atomicOr(&multi[i0 >> 5], again0);
-                if (again1) atomicOr(&multi[i1 >> 5], again1);
-            } else { // ---- pass B
-                const uint32_t mw0 = multi[i0 >> 5], mw1 = multi[i1 >> 5];
-                const float wt = __uint_as_float(e1);
-                const float x0 = __fmul_rn(wt, __uint_as_float(v.y)), x1 = __fmul_rn(wt, __uint_as_float(v.w));
-                const bool mul0 = (mw0 & bit0) != 0u, mul1 = (mw1 & bit1) != 0u;
-                const bool k0 = ok0 && !mul0 && x0 > 0.0f && oi_f32_key(x0) >= t_tau; // (BM25 lists hold scores > 0 only)
-                const bool k1 = ok1 && !mul1 && x1 > 0.0f && oi_f32_key(x1) >= t_tau;
-                emit2(k0, oi_rank_key(x0, t_doc0 + v.x), k1, oi_rank_key(x1, t_doc0 + v.z));
-                if (__ballot(mul0 || mul1)) { // a lane's two postings are one run: distinct docs
-                    add_multi(mul0, i0 >> 5, mw0, bit0, v.x, x0, 0u);
-                    add_multi(mul1, i1 >> 5, mw1, bit1, v.z, x1, 0u);
+    // ================================================================ bounds and chunk tables
+    uint32_t d_cb = 0;   // lane j: cell index of (term j of the query, window 0); 0 without a run
+    bool d_ok = false;   // lane j: the query has a term j (< 64) and it is inside the vocabulary
+    float d_idf = 0.f;   // lane j: idf of that term
+    uint32_t c0 = 0, c1 = 0, c2 = 0; // lane j: cell_start words of a block (windows 0, 1, end)
+    uint32_t vseq = 0;   // LDS-DMA operations issued so far (chunks and bounds)
+    // cell words of block `blk` for the lanes' runs, by LDS-DMA into bounds buffer `buf` (no VGPR destination)
+    auto issue_bounds = [&](uint32_t blk, uint32_t buf) {
+        const uint32_t *src = a.cells + d_cb + 2u * (a.block0 + blk); // (lanes without a run: d_cb = 0, any valid word)
+        bs_dma_word(src, desc_w + (buf * 3u + 0u) * 256u);
+        bs_dma_word(src + 1, desc_w + (buf * 3u + 1u) * 256u);
+        bs_dma_word(src + 2, desc_w + (buf * 3u + 2u) * 256u);
+        vseq += 3;
+    };
+    auto read_bounds = [&](uint32_t buf) { // (lanes without a run: an empty one)
+        c0 = desc[(buf * 3u + 0u) * 64u + lane];
+        c1 = desc[(buf * 3u + 1u) * 64u + lane];
+        c2 = desc[(buf * 3u + 2u) * 64u + lane];
+        c0 = d_ok ? c0 : 0u; c1 = d_ok ? c1 : 0u; c2 = d_ok ? c2 : 0u;
+    };
+    auto build_table = [&](uint32_t win, bool long_query) {
+        BsTable t;
+        const uint32_t s = (NWB == 1 || win == 0) ? c0 : c1, e = NWB == 1 ? c2 : (win == 0 ? c1 : c2);
+        const uint32_t cs = s & ~1u;
+        const uint32_t n = e > s ? (e - cs + 127u) >> 7 : 0u; // chunks of run `lane`
+        const uint32_t incl = bs_incl_scan(n), excl = incl - n;
+        t.C = bs_readlane(incl, 63);
+        t.slow = long_query || t.C > 64u;
+        t.pos = 0; t.lohi = 0; t.idf = 0;
+        if (t.slow) { t.C = 0; return t; }
+        if (t.C == 0u) return t;
+        // chunk k -> its run: every run with chunks marks the lane of its first chunk, a max-scan spreads the marks.
+        // VOLATILE: lanes talk to each other through these words.  With plain accesses hipcc forwards a lane's own
+        // "head[lane] = 0" to its read below (legal for unsynchronised threads) and the marks of the other lanes are lost:
+        // chunks land in the wrong run, positions run past the end of a posting list -- a memory fault (round 4, found in the ISA).
+        head[lane] = 0u;
+        if (n) head[excl] = lane + 1u;
+        uint32_t h = head[lane];
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x111, 0xf, 0xf, false));
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x112, 0xf, 0xf, false));
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x114, 0xf, 0xf, false));
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x118, 0xf, 0xf, false));
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x142, 0xa, 0xf, false));
+        h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x143, 0xc, 0xf, false));
+        const int j = lane < t.C ? (int)h - 1 : 0; // (lane 0 carries a mark whenever C > 0)
+        const uint32_t cs_j = (uint32_t)__shfl((int)cs, j, OI_WAVE), s_j = (uint32_t)__shfl((int)s, j, OI_WAVE);
+        const uint32_t e_j = (uint32_t)__shfl((int)e, j, OI_WAVE), ex_j = (uint32_t)__shfl((int)excl, j, OI_WAVE);
+        t.idf = (uint32_t)__shfl((int)__float_as_uint(d_idf), j, OI_WAVE);
+        t.pos = cs_j + 128u * (lane - ex_j);
+        const uint32_t lo = lane == ex_j ? s_j - cs_j : 0u, left = e_j - t.pos;
+        t.lohi = lo | ((left < 128u ? left : 128u) << 8);
+        return t;
+    };
+    uint32_t g_issue = 0, g_consume = 0; // chunk DMAs issued / consumed so far: ring slot = counter % R
+    uint32_t ahead = 0;                  // issued and not yet consumed (<= R)
+    auto issue = [&](const BsTable &t, uint32_t k) {
+        const uint32_t pos = bs_readlane(t.pos, k);
+        const uint2 *src = a.postings + pos; // (the array is padded: a chunk may run 1 KiB past its run)
+        const uint32_t dst = ring_w + (g_issue & (R - 1u)) * 1024u;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(lane16), "s"(src), "s"(dst)
+            : "memory");
+        ++g_issue; ++ahead; ++vseq;
+    };
+    // the oldest chunk in flight has landed (chunks complete in issue order; `ahead - 1` younger ones may stay in flight)
+    auto wait_oldest = [&]() {
+        if (ahead >= R) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 1) : "memory");
+        else if (ahead >= R / 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R / 2 - 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto consume = [&](const BsTable &t, uint32_t k, bool pass_b_now) {
+        const uint32_t lohi = bs_readlane(t.lohi, k);
+        const uint32_t lo = lohi & 1u, hi = lohi >> 8;
+        const uint4 v = ring16[(g_consume & (R - 1u)) * 64u + lane];
+        const uint32_t i0 = v.x & (W - 1u), i1 = v.z & (W - 1u);
+        const bool ok0 = 2u * lane >= lo && 2u * lane < hi, ok1 = 2u * lane + 1u < hi; // (2 lane + 1 >= lo always)
+        const uint32_t bit0 = ok0 ? 1u << (i0 & 31u) : 0u, bit1 = ok1 ? 1u << (i1 & 31u) : 0u;
+        if (!pass_b_now) pass_a(i0, bit0, i1, bit1);
+        else {
+            const float wt = __uint_as_float(bs_readlane(t.idf, k));
+            pass_b(i0, bit0, v.x, __fmul_rn(wt, __uint_as_float(v.y)), i1, bit1, v.z, __fmul_rn(wt, __uint_as_float(v.w)), 0u, true);
+        }
+        ++g_consume; --ahead;
+    };
+
+    // ================================================================ the stream: query by query, block by block
+    for (uint32_t r = r0; r <= r1 && r < nq; ++r) {
+        const uint32_t bA = r == r0 ? b0 : 0u, bB = r == r1 ? b1 : nbh;
+        if (bA >= bB) continue;
+        // ---- the query (plain loads: nothing is in flight here)
+        t_q = r;
+        t_tau_q = bs_rfl(s_tau[r]);
+        q_tb = bs_rfl(a.q_offsets[a.q_begin + r]);
+        q_T = bs_rfl(a.q_offsets[a.q_begin + r + 1]) - q_tb;
+        const bool long_query = q_T > 64u;
+        {
+            uint32_t term = 0xFFFFFFFFu;
+            if (lane < q_T) term = a.q_terms[q_tb + lane];
+            d_ok = term < a.vocab;
+            d_cb = d_ok ? term * a.n_win : 0u;
+            d_idf = d_ok ? a.idf[term] : 0.f;
+            // Retire these loads HERE: hipcc's s_waitcnt pass otherwise carries "d_idf may be in flight" around the whole
+            // stream loop and drains the DMA ring with a vmcnt(0) wherever it is used.
+            asm volatile("" : "+v"(d_idf), "+v"(d_cb));
+        }
+        uint32_t pf_buf = 0, pf_seq = 0;
+        issue_bounds(bA, 0);
+        bs_wait_vm(0);
+        read_bounds(0);
+        if (bA + 1 < bB) { pf_buf = 1; pf_seq = vseq; issue_bounds(bA + 1, 1); }
+        BsTable cur = build_table(0, long_query);
+        uint32_t icur = 0; // visits of `cur` issued so far
+        uint32_t blk = bA, win = 0;
+        for (;;) {
+            // ---- the next window and its table (its block's bounds were prefetched a block ago)
+            uint32_t nblk = blk, nwin = win + 1;
+            if (nwin == NWB) { nwin = 0; ++nblk; }
+            const bool has_nxt = nblk < bB;
+            BsTable nxt;
+            nxt.pos = nxt.lohi = nxt.idf = nxt.C = 0; nxt.slow = false;
+            if (has_nxt) {
+                if (nwin == 0) {
+                    bs_wait_vm(vseq - pf_seq - 3u);
+                    read_bounds(pf_buf);
+                    if (nblk + 1 < bB) { pf_buf ^= 1u; pf_seq = vseq; issue_bounds(nblk + 1, pf_buf); }
                 }
+                nxt = build_table(nwin, long_query);
             }
-            ++n_consumed;
-        } else if (kind == BS_END_A) {
-            // ---- sweep: ranks of the multi docs (exclusive popcount prefix per map word), seen cleared
-            t_win = e1;
-            const uint4 *m4 = reinterpret_cast<const uint4 *>(multi) + lane * (WPL / 4);
-            uint4 *s4 = reinterpret_cast<uint4 *>(seen) + lane * (WPL / 4);
-            uint32_t mwd[WPL], run = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < WPL / 4; ++k) {
-                const uint4 m = m4[k];
-                mwd[4 * k] = m.x; mwd[4 * k + 1] = m.y; mwd[4 * k + 2] = m.z; mwd[4 * k + 3] = m.w;
-            }
-            uint32_t ex[WPL];
-#pragma unroll
-            for (uint32_t k = 0; k < WPL; ++k) { ex[k] = run; run += (uint32_t)__popc(mwd[k]); }
-            const uint32_t incl = bs_incl_scan(run);
-            const uint32_t base = incl - run;
-            t_M = bs_readlane(incl, 63);
-            if (t_M) {
-                uint4 *p4 = reinterpret_cast<uint4 *>(pref) + lane * (WPL / 8);
-#pragma unroll
-                for (uint32_t k = 0; k < WPL / 8; ++k) {
-                    uint4 o;
-                    o.x = (base + ex[8 * k]) | ((base + ex[8 * k + 1]) << 16);
-                    o.y = (base + ex[8 * k + 2]) | ((base + ex[8 * k + 3]) << 16);
-                    o.z = (base + ex[8 * k + 4]) | ((base + ex[8 * k + 5]) << 16);
-                    o.w = (base + ex[8 * k + 6]) | ((base + ex[8 * k + 7]) << 16);
-                    p4[k] = o;
+            uint32_t inxt = 0;
+            if (win == 0) start_task(blk);
+            if (cur.slow) { // (nothing of this window is in the ring)
+                direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t, float) { pass_a(ix, bit, 0u, 0u); });
+                sweep();
+                direct_pass_b(win, 0u, true);
+                finish_window(win);
+            } else if (cur.C) {
+                const uint32_t C = cur.C, V = 2u * C; // visits: the chunks as pass A, then again as pass B
+                while (ahead < R && icur < V) { issue(cur, icur < C ? icur : icur - C); ++icur; }
+                for (uint32_t v = 0; v < V; ++v) {
+                    wait_oldest();
+                    if (v == C) sweep();
+                    consume(cur, v < C ? v : v - C, v >= C);
+                    if (icur < V) { issue(cur, icur < C ? icur : icur - C); ++icur; }
+                    else if (inxt < 2u * nxt.C) { issue(nxt, inxt < nxt.C ? inxt : inxt - nxt.C); ++inxt; }
                 }
+                finish_window(win);
             }
-#pragma unroll
-            for (uint32_t k = 0; k < WPL / 4; ++k) s4[k] = make_uint4(0u, 0u, 0u, 0u);
-        } else if (kind == BS_END_B) {
-            if (t_M) {
-                emit_multi(0u);
-                if (t_M > BS_CAP) slow_rounds();
-                uint4 *m4 = reinterpret_cast<uint4 *>(multi) + lane * (WPL / 4);
-#pragma unroll
-                for (uint32_t k = 0; k < WPL / 4; ++k) m4[k] = make_uint4(0u, 0u, 0u, 0u);
-                t_M = 0;
-            }
-            if (e0 & 8u) end_task();
-        } else if (kind == BS_START_TASK) {
-            t_q = e1 & 255u;
-            t_blk = e1 >> 8;
-            t_doc0 = a.doc_id_base + (a.block0 + t_blk) * BS_BLOCK;
-            t_tau_q = a.tau_keys ? bs_rfl(a.tau_keys[t_q]) : 0u;
-            t_tau = t_tau_q;
-            t_seg = a.pools + (uint64_t)t_q * a.pool_stride + a.carry_cap + (uint64_t)(a.block0 + t_blk) * seg_cap;
-            out_n = 0;
-        } else { // BS_END_TASK
-            end_task();
+            if (win == NWB - 1) end_task();
+            if (!has_nxt) break;
+            cur = nxt; icur = inxt; blk = nblk; win = nwin;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Plan of a pass (one launch, before the first phase): zero the pass's pool state and weigh the queries.
-//   unit[r] = postings of ONE block of query r on average (sum of its terms' local df / blocks) + a fixed cost;
+//   unit[r] = postings of ONE block of query r on average (sum of its terms' local df / blocks) + a cost per run;
 //   cum = its exclusive prefix.  The stream kernel cuts cum[nq] * (blocks of the launch) into equal parts.
 __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restrict__ q_terms, const uint32_t *__restrict__ q_offsets,
                                                         const uint32_t *__restrict__ df, uint32_t vocab, uint32_t n_blocks,
@@ -582,12 +588,13 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restri
     if (blockIdx.x != 0) return;
     __shared__ uint32_t s_unit[BS_MAX_Q];
     for (uint32_t r = threadIdx.x; r < nq; r += 256) {
-        uint64_t wsum = 0;
+        uint64_t wsum = 0, runs = 1;
         for (uint32_t i = q_offsets[q_begin + r]; i < q_offsets[q_begin + r + 1]; ++i) {
             const uint32_t term = q_terms[i];
             wsum += term < vocab ? df[term] : 0u;
+            runs += term < vocab && df[term] ? 1u : 0u;
         }
-        uint64_t u = wsum / (n_blocks ? n_blocks : 1u) + BS_FIX_COST;
+        uint64_t u = wsum / (n_blocks ? n_blocks : 1u) + BS_RUN_COST * runs;
         if (u > (1u << 24)) u = 1u << 24; // keeps cum[nq] * blocks * waves inside 64 bits
         s_unit[r] = (uint32_t)u;
         unit[r] = (uint32_t)u;

@@ -31,11 +31,18 @@ Rccl *rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        // OI_RCCL_LIB names the library to load instead (a deployment with RCCL outside the loader's path; the tests use it
+        // to take the "no RCCL on this host" path).  dlerror() hands its message out ONCE and clears it: read it once.
+        const char *override_name = getenv("OI_RCCL_LIB");
+        std::string why;
+        for (const char *name : {override_name, override_name ? nullptr : "librccl.so.1", override_name ? nullptr : "librccl.so"}) {
+            if (!name) continue;
             r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
+            const char *e = dlerror();
+            if (why.empty()) why = e ? e : "dlopen failed";
         }
-        if (!r.h) { r.why = dlerror() ? dlerror() : "dlopen failed"; return; }
+        if (!r.h) { r.why = why.empty() ? "dlopen failed" : why; return; }
         auto sym = [&](const char *n) -> void * {
             void *p = dlsym(r.h, n);
             if (!p && r.why.empty()) r.why = std::string("missing symbol ") + n;

@@ -91,3 +91,24 @@ def test_null_handles_are_refused_without_touching_a_device():
     assert lib.oi_lexicon_scan_segments_device(none, none, none, 0, 0, none, none, 1, 0.2, none, none, none) == INVALID
     assert lib.oi_headline_scan_rows(none, none, none, 0, none, 1, none, none, none, none, none, none, none, none) == INVALID
     assert b"null ctx" in lib.oi_last_error()
+
+
+def test_a_host_without_rccl_gets_unsupported_not_a_crash():
+    """ADVICE r03: the RCCL-missing path used to call dlerror() twice (the second call returns NULL: std::string(NULL) inside
+    call_once aborts the process).  OI_RCCL_LIB points the loader at a library that does not exist; oi_comm_unique_id must come
+    back with OI_ERR_UNSUPPORTED and the loader's message.  (A subprocess: the load is a process-wide one-shot.)"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "from openintel_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "rc = lib.oi_comm_unique_id(buf)\n"
+        "msg = lib.oi_last_error() or b''\n"
+        "print(rc, msg.decode(errors='replace'))\n"
+        "rc2 = lib.oi_comm_unique_id(buf)\n"          # the one-shot stays failed, still no crash
+        "sys.exit(0 if rc == _lib.OI_ERR_UNSUPPORTED and rc2 == rc and b'RCCL is not usable' in msg and b'no_such_rccl' in msg else 3)\n")
+    env = dict(os.environ, OI_RCCL_LIB="/nonexistent/libno_such_rccl.so", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])
