@@ -49,12 +49,17 @@
 #define BS_BLOCK OI_BM25_BLOCK_DOCS
 #define BS_FINE OI_BM25_FINE_DOCS
 #define BS_WPB 2          // waves per workgroup (they never meet after the prologue)
-#define BS_RING 8         // 1 KiB slots per wave
-#define BS_CAP 512u       // multi-doc accumulators per window and round
-#define BS_STAGE 192u     // staged keys (a chunk appends <= 128 to < 64 left over)
+#ifndef BS_RING
+#define BS_RING 4         // 1 KiB slots per wave (measured: 4 slots x 8 waves per CU beats 8 slots x 6 waves, 0.149 vs 0.176 ms)
+#endif
+#ifndef BS_CAP
+#define BS_CAP 256u       // multi-doc accumulators per window and round
+#endif
+#define BS_STAGE 128u     // staged keys (a lane's two postings are appended one after the other: <= 64 to < 64 left over)
 #define BS_MAX_Q 128u     // queries per pass
-#define BS_RUN_COST 64u   // weight of a run beside its postings (a run's last chunk is half empty on average; the sweep and the
-                          // task's own steps count as one more run), in postings: the cost of a task is its chunk visits
+#define BS_RUN_COST 64u   // weight of a run beside its postings (its last chunk is half empty on average), in postings: the cost
+                          // of a task is its chunk visits
+#define BS_TASK_COST 384u // weight of a task beside its runs: table, sweep, multi docs, end of task (measured: ~7 visits)
 
 struct BsArgs {
     const uint2 *postings;     // {doc_in_block, impact bits}, term-major
@@ -71,6 +76,7 @@ struct BsArgs {
     uint64_t pool_stride;
     uint32_t n_win, vocab, doc_id_base, block0, nbh, q_begin, nq;
     uint32_t seg_cnt_stride, carry_cap, seg_cap, depth;
+    unsigned long long *timing; // TIMING instantiation only: per-section cycle sums over all waves
 };
 
 __device__ __forceinline__ uint32_t bs_lds_addr(const void *p) {
@@ -148,9 +154,17 @@ struct BsTable {
     bool slow;      // more than 64 chunks, or a query of more than 64 terms: the window goes through the direct passes
 };
 
-template <int W>
+// TIMING (a diagnostic instantiation, never the product's launch): s_memtime stamps around the sections of a wave's life,
+// summed over the waves into a.timing[0..9] = wait, pass A, sweep, pass B, table + bounds, finish + end of task, issue,
+// query setup, whole wave, waves; [10] = the longest wave.
+template <int W, bool TIMING = false>
 __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a) {
     using L = BsLds<W>;
+    unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_big = 0, t_big_n = 0, t_first = 0, t_n_wait = 0, t_b_wait = 0; // long waits; a window's first wait; pass-B waits
+    uint32_t t_stores = 0, t_tasks = 0; // (TIMING) 64-key stores and tasks so far
+    auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long { return TIMING ? __builtin_amdgcn_s_memtime() : 0ull; };
+    const unsigned long long t_wave0 = stamp();
     constexpr uint32_t WORDS = L::WORDS, WPL = WORDS / 64; // map words per lane in the sweep: 8 (W = 16384) or 16
     constexpr uint32_t NWB = BS_BLOCK / W;                  // windows per block: 2 or 1
     constexpr uint32_t WSTEP = W / BS_FINE;                 // cells per window: 1 or 2
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     const uint32_t nq = a.nq, nbh = a.nbh;
     const uint32_t G = gridDim.x * BS_WPB, w = blockIdx.x * BS_WPB + wv;
     const uint64_t total = s_cum[nq] * nbh;
-    auto locate = [&](uint64_t P, uint32_t &r_out, uint32_t &b_out) { // first task (r, b) with start >= P
+    auto locate = [&](uint64_t P, uint32_t &r_out, uint32_t &b_out) __attribute__((always_inline)) { // first task (r, b) with start >= P
         if (P >= total) { r_out = nq; b_out = 0; return; }
         uint32_t lo = 0, hi = nq; // s_cum[lo] * nbh <= P < s_cum[hi] * nbh
         while (hi - lo > 1) {
@@ -209,6 +223,17 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
 
     const uint32_t lane16 = lane * 16;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    auto sample = [&](unsigned long long dur, uint32_t pass, uint32_t v, uint32_t C, uint32_t gcons, uint32_t ah) __attribute__((always_inline)) {
+        if (TIMING && dur >= 2000 && a.timing && lane == 0) {
+            const unsigned long long at = atomicAdd(&a.timing[16], 1ull);
+            if (at < 2048) {
+                unsigned long long *o = a.timing + 32 + at * 4;
+                o[0] = dur; o[1] = ((unsigned long long)pass << 48) | ((unsigned long long)v << 32) | C;
+                o[2] = ((unsigned long long)gcons << 32) | ((unsigned long long)t_stores << 16) | t_tasks;
+                o[3] = ((unsigned long long)(stamp() - t_wave0) << 8) | ah;
+            }
+        }
+    };
 
     // ================================================================ the task being scored
     uint32_t t_q = 0, t_blk = 0, t_doc0 = 0, t_tau = 0, t_tau_q = 0, out_n = 0, st_n = 0, t_M = 0;
@@ -217,7 +242,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     const uint32_t seg_cap = a.seg_cap;
 
     // The segment is full: keep its top `depth` keys (exact: only those can reach the global top `depth`).
-    auto prune = [&]() {
+    auto prune = [&]() __attribute__((always_inline)) {
         uint32_t *hist = seen; // zero and unused between a sweep and the next window's pass A
         bs_wait_vm(0);         // this wave's stores have landed
         const uint32_t n = out_n, kprime = a.depth;
@@ -263,37 +288,33 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         const uint32_t thr = (uint32_t)((prefix << shift) >> 32); // every kept key is >= prefix << shift
         t_tau = thr > t_tau ? thr : t_tau;
     };
-    auto flush64 = [&]() { // 64 staged keys leave for the segment
+    auto flush64 = [&]() __attribute__((always_inline)) { // 64 staged keys leave for the segment
         if (out_n + 64u > seg_cap) prune();
         t_seg[out_n + lane] = stage[lane];
         out_n += 64u;
-        const uint32_t rem = st_n - 64u; // < 128
-        uint64_t k0 = 0, k1 = 0;
+        if (TIMING) ++t_stores;
+        const uint32_t rem = st_n - 64u; // < 64
+        uint64_t k0 = 0;
         if (lane < rem) k0 = stage[64u + lane];
-        if (64u + lane < rem) k1 = stage[128u + lane];
         if (lane < rem) stage[lane] = k0;
-        if (64u + lane < rem) stage[64u + lane] = k1;
         st_n = rem;
     };
-    auto emit2 = [&](bool k0, uint64_t key0, bool k1, uint64_t key1) { // all lanes call
-        const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-        if (m0 | m1) {
-            const uint32_t n0 = (uint32_t)__popcll(m0);
-            if (k0) stage[st_n + (uint32_t)__popcll(m0 & lt_mask)] = key0;
-            if (k1) stage[st_n + n0 + (uint32_t)__popcll(m1 & lt_mask)] = key1;
-            st_n += n0 + (uint32_t)__popcll(m1);
-            if (st_n >= 64u) flush64();
+    auto emit1 = [&](bool k, uint32_t score_bits, uint32_t doc) __attribute__((always_inline)) { // all lanes call; score > 0: its key is bits | sign
+        const unsigned long long m = __ballot(k);
+        if (m) {
+            if (k) stage[st_n + (uint32_t)__popcll(m & lt_mask)] = ((uint64_t)(score_bits | 0x80000000u) << 32) | (uint64_t)(~doc);
+            st_n += (uint32_t)__popcll(m);
             if (st_n >= 64u) flush64();
         }
     };
-    auto start_task = [&](uint32_t blk) {
+    auto start_task = [&](uint32_t blk) __attribute__((always_inline)) {
         t_blk = blk;
         t_doc0 = a.doc_id_base + (a.block0 + blk) * BS_BLOCK;
         t_tau = t_tau_q;
         t_seg = a.pools + (uint64_t)t_q * a.pool_stride + a.carry_cap + (uint64_t)(a.block0 + blk) * seg_cap;
         out_n = 0;
     };
-    auto end_task = [&]() {
+    auto end_task = [&]() __attribute__((always_inline)) {
         if (st_n) {
             if (out_n + st_n > seg_cap) prune();
             if (lane < st_n) t_seg[out_n + lane] = stage[lane];
@@ -305,7 +326,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         out_n = 0;
     };
     // ranks [lo, lo + BS_CAP) of the window's multi docs: emit and clear their accumulators
-    auto emit_multi = [&](uint32_t lo) {
+    auto emit_multi = [&](uint32_t lo) __attribute__((always_inline)) {
         const uint32_t cnt = t_M - lo < BS_CAP ? t_M - lo : BS_CAP;
         for (uint32_t b = 0; b < cnt; b += 64) {
             const uint32_t r = b + lane;
@@ -313,11 +334,11 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             const float v = acc[ok ? r : 0u];
             const uint32_t d = accdoc[ok ? r : 0u];
             if (ok) acc[r] = 0.0f;
-            emit2(ok && v > 0.0f && oi_f32_key(v) >= t_tau, oi_rank_key(v, t_doc0 + d), false, 0ull);
+            emit1(ok && v > 0.0f && (__float_as_uint(v) | 0x80000000u) >= t_tau, __float_as_uint(v), t_doc0 + d);
         }
     };
     // a multi doc's posting: acc[rank - lo] += x, in call order (ranks outside [lo, lo + BS_CAP) belong to another round)
-    auto add_multi = [&](bool mul, uint32_t word, uint32_t mw, uint32_t bit, uint32_t dib, float x, uint32_t lo) {
+    auto add_multi = [&](bool mul, uint32_t word, uint32_t mw, uint32_t bit, uint32_t dib, float x, uint32_t lo) __attribute__((always_inline)) {
         if (mul) {
             const uint32_t pw = pref[word >> 1];
             const uint32_t rr = ((word & 1u) ? pw >> 16 : pw & 0xFFFFu) + (uint32_t)__popc(mw & (bit - 1u)) - lo;
@@ -328,7 +349,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         }
     };
     // pass A on two postings per lane (bit = 0: not a posting of the run): seen, then multi for the docs seen before
-    auto pass_a = [&](uint32_t i0, uint32_t bit0, uint32_t i1, uint32_t bit1) {
+    auto pass_a = [&](uint32_t i0, uint32_t bit0, uint32_t i1, uint32_t bit1) __attribute__((always_inline)) {
         const uint32_t o0 = atomicOr(&seen[i0 >> 5], bit0);
         const uint32_t o1 = atomicOr(&seen[i1 >> 5], bit1);
         const uint32_t again0 = o0 & bit0, again1 = o1 & bit1; // the doc was in an earlier run
@@ -337,13 +358,16 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     };
     // pass B on two postings per lane, ranks [lo, lo + BS_CAP) of the multi docs; single-run docs are emitted iff `singles`
     auto pass_b = [&](uint32_t i0, uint32_t bit0, uint32_t d0, float x0, uint32_t i1, uint32_t bit1, uint32_t d1, float x1,
-                      uint32_t lo, bool singles) {
+                      uint32_t lo, bool singles) __attribute__((always_inline)) {
         const uint32_t mw0 = multi[i0 >> 5], mw1 = multi[i1 >> 5];
         const bool mul0 = (mw0 & bit0) != 0u, mul1 = (mw1 & bit1) != 0u;
-        if (singles) {
-            const bool k0 = bit0 && !mul0 && x0 > 0.0f && oi_f32_key(x0) >= t_tau; // (BM25 lists hold scores > 0 only)
-            const bool k1 = bit1 && !mul1 && x1 > 0.0f && oi_f32_key(x1) >= t_tau;
-            emit2(k0, oi_rank_key(x0, t_doc0 + d0), k1, oi_rank_key(x1, t_doc0 + d1));
+        if (singles) { // (BM25 lists hold scores > 0 only; the key of a score > 0 is its bits with the sign bit set)
+            const bool k0 = bit0 && !mul0 && x0 > 0.0f && (__float_as_uint(x0) | 0x80000000u) >= t_tau;
+            const bool k1 = bit1 && !mul1 && x1 > 0.0f && (__float_as_uint(x1) | 0x80000000u) >= t_tau;
+            if (__ballot(k0 || k1)) {
+                emit1(k0, __float_as_uint(x0), t_doc0 + d0);
+                emit1(k1, __float_as_uint(x1), t_doc0 + d1);
+            }
         }
         if (__ballot(mul0 || mul1)) { // a lane's two postings are one run: distinct docs
             add_multi(mul0, i0 >> 5, mw0, bit0, d0, x0, lo);
@@ -351,7 +375,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         }
     };
     // the sweep between the passes: ranks of the multi docs (exclusive popcount prefix per map word), seen cleared
-    auto sweep = [&]() {
+    auto sweep = [&]() __attribute__((always_inline)) {
         const uint4 *m4 = reinterpret_cast<const uint4 *>(multi) + lane * (WPL / 4);
         uint4 *s4 = reinterpret_cast<uint4 *>(seen) + lane * (WPL / 4);
         uint32_t mwd[WPL], run = 0;
@@ -383,7 +407,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     };
     // Window `win` of the task straight from global memory, run by run in query order, 64 postings per step: the rounds
     // beyond the first of a window with more than BS_CAP multi docs, and whole windows the tables cannot describe.
-    auto direct_runs = [&](uint32_t win, auto &&f) {
+    auto direct_runs = [&](uint32_t win, auto &&f) __attribute__((always_inline)) {
         for (uint32_t j = q_tb; j < q_tb + q_T; ++j) {
             const uint32_t term = bs_rfl(a.q_terms[j]);
             if (term >= a.vocab) continue;
@@ -398,10 +422,10 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             }
         }
     };
-    auto direct_pass_b = [&](uint32_t win, uint32_t lo, bool singles) {
-        direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t dib, float x) { pass_b(ix, bit, dib, x, 0u, 0u, 0u, 0.f, lo, singles); });
+    auto direct_pass_b = [&](uint32_t win, uint32_t lo, bool singles) __attribute__((always_inline)) {
+        direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t dib, float x) __attribute__((always_inline)) { pass_b(ix, bit, dib, x, 0u, 0u, 0u, 0.f, lo, singles); });
     };
-    auto finish_window = [&](uint32_t win) { // after pass B's first round: the multi docs out, further rounds, maps clean
+    auto finish_window = [&](uint32_t win) __attribute__((always_inline)) { // after pass B's first round: the multi docs out, further rounds, maps clean
         if (t_M) {
             emit_multi(0u);
             for (uint32_t lo = BS_CAP; lo < t_M; lo += BS_CAP) {
@@ -422,20 +446,20 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     uint32_t c0 = 0, c1 = 0, c2 = 0; // lane j: cell_start words of a block (windows 0, 1, end)
     uint32_t vseq = 0;   // LDS-DMA operations issued so far (chunks and bounds)
     // cell words of block `blk` for the lanes' runs, by LDS-DMA into bounds buffer `buf` (no VGPR destination)
-    auto issue_bounds = [&](uint32_t blk, uint32_t buf) {
+    auto issue_bounds = [&](uint32_t blk, uint32_t buf) __attribute__((always_inline)) {
         const uint32_t *src = a.cells + d_cb + 2u * (a.block0 + blk); // (lanes without a run: d_cb = 0, any valid word)
         bs_dma_word(src, desc_w + (buf * 3u + 0u) * 256u);
         bs_dma_word(src + 1, desc_w + (buf * 3u + 1u) * 256u);
         bs_dma_word(src + 2, desc_w + (buf * 3u + 2u) * 256u);
         vseq += 3;
     };
-    auto read_bounds = [&](uint32_t buf) { // (lanes without a run: an empty one)
+    auto read_bounds = [&](uint32_t buf) __attribute__((always_inline)) { // (lanes without a run: an empty one)
         c0 = desc[(buf * 3u + 0u) * 64u + lane];
         c1 = desc[(buf * 3u + 1u) * 64u + lane];
         c2 = desc[(buf * 3u + 2u) * 64u + lane];
         c0 = d_ok ? c0 : 0u; c1 = d_ok ? c1 : 0u; c2 = d_ok ? c2 : 0u;
     };
-    auto build_table = [&](uint32_t win, bool long_query) {
+    auto build_table = [&](uint32_t win, bool long_query) __attribute__((always_inline)) {
         BsTable t;
         const uint32_t s = (NWB == 1 || win == 0) ? c0 : c1, e = NWB == 1 ? c2 : (win == 0 ? c1 : c2);
         const uint32_t cs = s & ~1u;
@@ -470,10 +494,10 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     };
     uint32_t g_issue = 0, g_consume = 0; // chunk DMAs issued / consumed so far: ring slot = counter % R
     uint32_t ahead = 0;                  // issued and not yet consumed (<= R)
-    auto issue = [&](const BsTable &t, uint32_t k) {
+    auto issue = [&](const BsTable &t, uint32_t k) __attribute__((always_inline)) {
         const uint32_t pos = bs_readlane(t.pos, k);
         const uint2 *src = a.postings + pos; // (the array is padded: a chunk may run 1 KiB past its run)
-        const uint32_t dst = ring_w + (g_issue & (R - 1u)) * 1024u;
+        const uint32_t dst = bs_rfl(ring_w + (g_issue & (R - 1u)) * 1024u);
         uint32_t keep;
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
@@ -487,12 +511,12 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         ++g_issue; ++ahead; ++vseq;
     };
     // the oldest chunk in flight has landed (chunks complete in issue order; `ahead - 1` younger ones may stay in flight)
-    auto wait_oldest = [&]() {
+    auto wait_oldest = [&]() __attribute__((always_inline)) {
         if (ahead >= R) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 1) : "memory");
         else if (ahead >= R / 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R / 2 - 1) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    auto consume = [&](const BsTable &t, uint32_t k, bool pass_b_now) {
+    auto consume = [&](const BsTable &t, uint32_t k, bool pass_b_now) __attribute__((always_inline)) {
         const uint32_t lohi = bs_readlane(t.lohi, k);
         const uint32_t lo = lohi & 1u, hi = lohi >> 8;
         const uint4 v = ring16[(g_consume & (R - 1u)) * 64u + lane];
@@ -512,6 +536,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         const uint32_t bA = r == r0 ? b0 : 0u, bB = r == r1 ? b1 : nbh;
         if (bA >= bB) continue;
         // ---- the query (plain loads: nothing is in flight here)
+        const unsigned long long t_qs = stamp();
         t_q = r;
         t_tau_q = bs_rfl(s_tau[r]);
         q_tb = bs_rfl(a.q_offsets[a.q_begin + r]);
@@ -533,6 +558,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         read_bounds(0);
         if (bA + 1 < bB) { pf_buf = 1; pf_seq = vseq; issue_bounds(bA + 1, 1); }
         BsTable cur = build_table(0, long_query);
+        if (TIMING) t_acc[7] += stamp() - t_qs;
         uint32_t icur = 0; // visits of `cur` issued so far
         uint32_t blk = bA, win = 0;
         for (;;) {
@@ -542,6 +568,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             const bool has_nxt = nblk < bB;
             BsTable nxt;
             nxt.pos = nxt.lohi = nxt.idf = nxt.C = 0; nxt.slow = false;
+            const unsigned long long t_tb = stamp();
             if (has_nxt) {
                 if (nwin == 0) {
                     bs_wait_vm(vseq - pf_seq - 3u);
@@ -550,29 +577,75 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
                 }
                 nxt = build_table(nwin, long_query);
             }
+            if (TIMING) t_acc[4] += stamp() - t_tb;
             uint32_t inxt = 0;
-            if (win == 0) start_task(blk);
+            if (win == 0) { start_task(blk); if (TIMING) ++t_tasks; }
             if (cur.slow) { // (nothing of this window is in the ring)
-                direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t, float) { pass_a(ix, bit, 0u, 0u); });
+                direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t, float) __attribute__((always_inline)) { pass_a(ix, bit, 0u, 0u); });
                 sweep();
                 direct_pass_b(win, 0u, true);
                 finish_window(win);
             } else if (cur.C) {
                 const uint32_t C = cur.C, V = 2u * C; // visits: the chunks as pass A, then again as pass B
                 while (ahead < R && icur < V) { issue(cur, icur < C ? icur : icur - C); ++icur; }
-                for (uint32_t v = 0; v < V; ++v) {
-                    wait_oldest();
-                    if (v == C) sweep();
-                    consume(cur, v < C ? v : v - C, v >= C);
-                    if (icur < V) { issue(cur, icur < C ? icur : icur - C); ++icur; }
-                    else if (inxt < 2u * nxt.C) { issue(nxt, inxt < nxt.C ? inxt : inxt - nxt.C); ++inxt; }
+                // (a macro, not a lambda: with icur / inxt captured by reference hipcc kept them in SCRATCH memory and waited for
+                // every reload with vmcnt(0) -- the whole ring drained once per visit; found with in-kernel stamps, round 4)
+#define BS_REFILL()                                                                           \
+    do {                                                                                      \
+        if (icur < V) { issue(cur, icur < C ? icur : icur - C); ++icur; }                     \
+        else if (inxt < 2u * nxt.C) { issue(nxt, inxt < nxt.C ? inxt : inxt - nxt.C); ++inxt; } \
+    } while (0)
+                if (!TIMING) {
+                    for (uint32_t v = 0; v < C; ++v) { wait_oldest(); consume(cur, v, false); BS_REFILL(); }
+                    sweep();
+                    for (uint32_t v = 0; v < C; ++v) { wait_oldest(); consume(cur, v, true); BS_REFILL(); }
+                } else {
+                    for (uint32_t v = 0; v < C; ++v) {
+                        const unsigned long long t0 = stamp(); wait_oldest();
+                        const unsigned long long t1 = stamp(); consume(cur, v, false);
+                        const unsigned long long t2 = stamp(); BS_REFILL();
+                        const unsigned long long t3 = stamp();
+                        t_acc[0] += t1 - t0; t_acc[1] += t2 - t1; t_acc[6] += t3 - t2;
+                        if (t1 - t0 >= 2000) { t_big += t1 - t0; ++t_big_n; }
+                        sample(t1 - t0, 0, v, C, g_consume, ahead);
+                        if (v == 0) t_first += t1 - t0;
+                        ++t_n_wait;
+                    }
+                    const unsigned long long ts = stamp();
+                    sweep();
+                    t_acc[2] += stamp() - ts;
+                    for (uint32_t v = 0; v < C; ++v) {
+                        const unsigned long long t0 = stamp(); wait_oldest();
+                        const unsigned long long t1 = stamp(); consume(cur, v, true);
+                        const unsigned long long t2 = stamp(); BS_REFILL();
+                        const unsigned long long t3 = stamp();
+                        t_acc[0] += t1 - t0; t_acc[3] += t2 - t1; t_acc[6] += t3 - t2;
+                        if (t1 - t0 >= 2000) { t_big += t1 - t0; ++t_big_n; }
+                        sample(t1 - t0, 1, v, C, g_consume, ahead);
+                        t_b_wait += t1 - t0;
+                        ++t_n_wait;
+                    }
                 }
+#undef BS_REFILL
+                const unsigned long long tf = stamp();
                 finish_window(win);
+                if (TIMING) t_acc[5] += stamp() - tf;
             }
+            const unsigned long long te = stamp();
             if (win == NWB - 1) end_task();
+            if (TIMING) t_acc[5] += stamp() - te;
             if (!has_nxt) break;
             cur = nxt; icur = inxt; blk = nblk; win = nwin;
         }
+    }
+    if (TIMING && lane == 0 && a.timing) {
+        const unsigned long long whole = stamp() - t_wave0;
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.timing[i], t_acc[i]);
+        atomicAdd(&a.timing[8], whole);
+        atomicAdd(&a.timing[9], 1ull);
+        atomicMax(&a.timing[10], whole);
+        atomicAdd(&a.timing[11], t_big); atomicAdd(&a.timing[12], t_big_n); atomicAdd(&a.timing[13], t_first);
+        atomicAdd(&a.timing[14], t_n_wait); atomicAdd(&a.timing[15], t_b_wait);
     }
 }
 
@@ -588,13 +661,13 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restri
     if (blockIdx.x != 0) return;
     __shared__ uint32_t s_unit[BS_MAX_Q];
     for (uint32_t r = threadIdx.x; r < nq; r += 256) {
-        uint64_t wsum = 0, runs = 1;
+        uint64_t wsum = 0, runs = 0;
         for (uint32_t i = q_offsets[q_begin + r]; i < q_offsets[q_begin + r + 1]; ++i) {
             const uint32_t term = q_terms[i];
             wsum += term < vocab ? df[term] : 0u;
             runs += term < vocab && df[term] ? 1u : 0u;
         }
-        uint64_t u = wsum / (n_blocks ? n_blocks : 1u) + BS_RUN_COST * runs;
+        uint64_t u = wsum / (n_blocks ? n_blocks : 1u) + BS_RUN_COST * runs + BS_TASK_COST;
         if (u > (1u << 24)) u = 1u << 24; // keeps cum[nq] * blocks * waves inside 64 bits
         s_unit[r] = (uint32_t)u;
         unit[r] = (uint32_t)u;
@@ -654,14 +727,55 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
     a.n_win = idx->n_win; a.vocab = idx->vocab; a.doc_id_base = idx->doc_id_base;
     a.block0 = block_begin; a.nbh = block_end - block_begin; a.q_begin = q_begin; a.nq = nq;
     a.seg_cnt_stride = pool.seg_cnt_stride; a.carry_cap = pool.carry_cap; a.seg_cap = pool.seg_cap; a.depth = depth;
-    using L = BsLds<BS_BLOCK>;
-    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(bm25_stream_kernel<BS_BLOCK>), (size_t)L::TOTAL));
+    a.timing = nullptr;
     const uint64_t n_tasks = (uint64_t)a.nbh * nq;
-    uint64_t per_cu = (160u * 1024u) / L::TOTAL; // resident workgroups per CU (LDS)
-    if (const char *e = oi_ablation_env("OI_BM25_STREAM_WGS")) per_cu = std::max(1, atoi(e));
-    uint64_t wgs = std::min<uint64_t>((n_tasks + BS_WPB - 1) / BS_WPB, per_cu * (uint64_t)ctx->num_cus);
+    // A/B switches of the -DOI_ABLATION build (tools/): 16384-doc windows (10 waves per CU, a third more chunk visits: measured
+    // slower, 0.157 vs 0.143 ms), resident workgroups per CU, the stamped instantiation
+    static const bool half_windows = oi_ablation_env("OI_BM25_STREAM_W") && atoi(oi_ablation_env("OI_BM25_STREAM_W")) == 16384;
     ProfScope ps(ctx, "bm25");
-    hipLaunchKernelGGL(bm25_stream_kernel<BS_BLOCK>, dim3((uint32_t)wgs), dim3(BS_WPB * 64), L::TOTAL, ctx->stream, a);
+    auto launch = [&](auto kernel, uint32_t lds_total) -> int {
+        OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(kernel), (size_t)lds_total));
+        uint64_t per_cu = (160u * 1024u) / lds_total; // resident workgroups per CU (LDS)
+        if (const char *e = oi_ablation_env("OI_BM25_STREAM_WGS")) per_cu = std::max(1, atoi(e));
+        const uint64_t wgs = std::min<uint64_t>((n_tasks + BS_WPB - 1) / BS_WPB, per_cu * (uint64_t)ctx->num_cus);
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)wgs), dim3(BS_WPB * 64), lds_total, ctx->stream, a);
+        return OI_OK;
+    };
+#ifdef OI_ABLATION
+    if (oi_ablation_env("OI_BM25_STREAM_TIMING")) { // the stamped instantiation, sums and the first long waits printed per launch
+        DevBuf &tb = ctx->buf("bm25_stream_timing");
+        const size_t tbytes = (32 + 2048 * 4) * sizeof(unsigned long long);
+        OI_CHECK(tb.ensure(tbytes));
+        OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, tbytes, ctx->stream));
+        a.timing = tb.as<unsigned long long>();
+        OI_CHECK(launch(bm25_stream_kernel<BS_BLOCK, true>, BsLds<BS_BLOCK>::TOTAL));
+        unsigned long long h[16];
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        OI_HIP_CHECK(hipMemcpy(h, tb.p, sizeof(h), hipMemcpyDeviceToHost));
+        const double wv = h[9] ? (double)h[9] : 1.0;
+        fprintf(stderr, "[bm25 stream timing] blocks %u tasks %llu waves %llu | cycles per wave: wait %.0f passA %.0f sweep %.0f "
+                        "passB %.0f table %.0f finish %.0f issue %.0f query %.0f | whole %.0f longest %llu\n",
+                a.nbh, (unsigned long long)n_tasks, h[9], h[0] / wv, h[1] / wv, h[2] / wv, h[3] / wv, h[4] / wv, h[5] / wv, h[6] / wv,
+                h[7] / wv, h[8] / wv, h[10]);
+        {
+            std::vector<unsigned long long> smp(32 + 2048 * 4);
+            OI_HIP_CHECK(hipMemcpy(smp.data(), tb.p, smp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            const unsigned long long ns = std::min<unsigned long long>(smp[16], 2048);
+            fprintf(stderr, "[bm25 stream sample] %llu samples\n", smp[16]);
+            for (unsigned long long i = 0; i < ns && i < 40; ++i) {
+                const unsigned long long *o = &smp[32 + i * 4];
+                fprintf(stderr, "[bm25 stream sample] dur %llu pass %llu v %llu C %llu | visit# %llu stores %llu task# %llu | at cycle %llu ahead %llu\n", o[0],
+                        o[1] >> 48, (o[1] >> 32) & 0xFFFF, o[1] & 0xFFFFFFFF, o[2] >> 32, (o[2] >> 16) & 0xFFFF, o[2] & 0xFFFF, o[3] >> 8, o[3] & 255);
+            }
+        }
+        fprintf(stderr, "[bm25 stream timing]   waits per wave %.0f, of them >= 2000 cycles: %.1f (sum %.0f); first wait of a window: sum %.0f; pass-B waits: sum %.0f\n",
+                h[14] / wv, h[12] / wv, h[11] / wv, h[13] / wv, h[15] / wv);
+        return OI_OK;
+    }
+    if (half_windows) { OI_CHECK(launch(bm25_stream_kernel<BS_FINE>, BsLds<BS_FINE>::TOTAL)); OI_HIP_CHECK(hipGetLastError()); return OI_OK; }
+#endif
+    (void)half_windows;
+    OI_CHECK(launch(bm25_stream_kernel<BS_BLOCK>, BsLds<BS_BLOCK>::TOTAL));
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
