@@ -263,7 +263,7 @@ def main():
                 c.set_cosine_mode(MODES[args.cosine])
                 return c
             pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4)
-            lane_ctxs = [index.ctx for index, _ in pipe.lanes[1:]]
+        lane_ctxs = [index.ctx for index, _ in pipe.lanes]   # every lane scores on a context of its own (lane 0 too)
 
     def step():
         qv, qt, qo = batches[step_no[0] % NB]
@@ -493,11 +493,11 @@ def main():
         roof["step_level"] = {"achieved": bytes_step * passes * args.steps / elapsed / 1e9, "unit": "GB/s",
                               "frac": bytes_step * passes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS,
                               "note": "this rank's corpus bytes streamed / the whole timed region (everything else included)"}
-        if lane_ctxs and pipe is not None:
+        if len(lane_ctxs) > 1 and pipe is not None:
             # two batches' screens share the chip: each launch's duration includes the time it ran beside the other lane's,
             # so the per-launch figure above understates the rate the corpus is streamed at; the step-level figure does not
             roof["overlapped_launches"] = ("%d batches in flight per rank: launch durations overlap and are summed as measured "
-                                           "(frac understates the kernel); see step_level and isolated" % (1 + len(lane_ctxs)))
+                                           "(frac understates the kernel); see step_level and isolated" % len(lane_ctxs))
         roof["isolated"] = {"avg_launch_ms": iso_ms / max(1, iso_launches),
                             "frac": (flops_step if roof["bound"] == "mfma" else bytes_step) * iso_steps / (iso_ms / 1e3)
                             / (1e12 if roof["bound"] == "mfma" else 1e9) / roof["peak"],
@@ -525,8 +525,8 @@ def main():
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
-                                      ("; %d batches' lists in flight per rank, each through its own view of the shard" % (1 + len(lane_ctxs))
-                                       if lane_ctxs else ""),
+                                      ("; %d batches' lists in flight per rank, each through its own view of the shard" % len(lane_ctxs)
+                                       if len(lane_ctxs) > 1 else ""),
                        "backend": (backend if (world > 1 or force_dist) else None),
                        "forced_process_group_of_one": force_dist,
                        "per_rank": per_rank},

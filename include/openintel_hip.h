@@ -79,6 +79,10 @@ int oi_abi_version(void);
 const char *oi_last_error(void);
 
 int oi_create(int device_ordinal, oi_ctx **out);
+/* A NEW context on `like`'s device with `like`'s settings (cosine mode, overlap of the legs, graph replay) and nothing
+ * else of it: its own default stream, its own (still empty) workspaces.  For a host that scores several batches at once
+ * through views of one index (oi_index_view): every lane gets a context of its own and the caller's is never rebound. */
+int oi_create_like(oi_ctx *like, oi_ctx **out);
 /* Lifetime: handles are reference-counted inside the library, so destruction is safe in ANY order.  oi_destroy gives up
  * the caller's handle (which must not be used again); if indexes created on -- or viewed through -- the ctx are still
  * alive, its stream, workspaces and mutex stay until the last of them is destroyed (those indexes remain fully usable

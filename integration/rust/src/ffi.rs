@@ -45,6 +45,7 @@ extern "C" {
     pub fn oi_abi_version() -> c_int;
     pub fn oi_last_error() -> *const c_char; // thread-local
     pub fn oi_create(device_ordinal: c_int, out: *mut *mut OiCtx) -> c_int;
+    pub fn oi_create_like(like: *mut OiCtx, out: *mut *mut OiCtx) -> c_int;
     pub fn oi_destroy(ctx: *mut OiCtx);
     pub fn oi_workspace_bytes(ctx: *mut OiCtx, device_bytes_out: *mut u64, pinned_host_bytes_out: *mut u64) -> c_int;
     pub fn oi_set_stream(ctx: *mut OiCtx, hip_stream: *mut c_void) -> c_int;

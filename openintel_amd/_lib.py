@@ -58,6 +58,7 @@ SIGNATURES = {
     "oi_abi_version": (_I, []),
     "oi_last_error": (C.c_char_p, []),
     "oi_create": (_I, [_I, C.POINTER(_P)]),
+    "oi_create_like": (_I, [_P, C.POINTER(_P)]),
     "oi_destroy": (None, [_P]),
     "oi_set_stream": (_I, [_P, _P]),
     "oi_synchronize": (_I, [_P]),

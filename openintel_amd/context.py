@@ -19,6 +19,18 @@ class HipContext:
         if stream is not None:
             self.set_stream(stream)
 
+    @classmethod
+    def like(cls, other: "HipContext") -> "HipContext":
+        """A new context on `other`'s device with its settings (cosine mode, overlap, graph replay) and nothing else of it:
+        its own stream and workspaces (oi_create_like).  What a pipeline lane or a calibration trial wants."""
+        self = cls.__new__(cls)
+        self.lib = other.lib
+        h = C.c_void_p()
+        _lib.check(self.lib.oi_create_like(other.handle, C.byref(h)))
+        self.handle = h
+        self.device = other.device
+        return self
+
     def set_stream(self, stream) -> None:
         """`stream`: a hipStream_t as int, or a torch.cuda.Stream (its .cuda_stream is used)."""
         raw = getattr(stream, "cuda_stream", stream)

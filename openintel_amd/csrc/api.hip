@@ -279,6 +279,18 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     return OI_OK;
 }
 
+extern "C" int oi_create_like(oi_ctx *like, oi_ctx **out) {
+    if (!out) { oi_set_error("oi_create_like: out is null"); return OI_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!like) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    OI_CHECK(oi_create(like->device, out));
+    std::lock_guard<std::mutex> g(like->mu);
+    (*out)->cosine_mode = like->cosine_mode;
+    (*out)->overlap_legs = like->overlap_legs;
+    (*out)->use_graphs = like->use_graphs;
+    return OI_OK;
+}
+
 // The teardown proper: runs when the last reference goes (the caller's handle, or the last index that outlived it).
 static void ctx_release(oi_ctx *ctx) {
     if (ctx->refs.fetch_sub(1) != 1) return;
@@ -795,6 +807,9 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
+    // captured query calls (oi_set_graph_replay) hold the OLD rows pointer -- on this ctx and on every view's: stale from here
+    // on (the epoch is process-wide; a raw hipMalloc / hipFree or a caller's pointer does not bump it by itself)
+    g_oi_ws_epoch.fetch_add(1);
     if (idx->rows_owned && idx->rows) { (void)hipFree(idx->rows); idx->rows = nullptr; idx->rows_owned = false; }
     if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
     idx->rows_bf16 = nullptr; idx->rows_bf16_owned = false;
@@ -830,6 +845,9 @@ extern "C" int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows,
     oi_ctx *ctx = idx->ctx;
     std::lock_guard<std::mutex> g(ctx->mu);
     OI_HIP_CHECK(hipSetDevice(ctx->device));
+    // captured query calls (oi_set_graph_replay) hold the OLD rows pointer -- on this ctx and on every view's: stale from here
+    // on (the epoch is process-wide; a raw hipMalloc / hipFree or a caller's pointer does not bump it by itself)
+    g_oi_ws_epoch.fetch_add(1);
     OI_REQUIRE(oi_cosine_bf16_supported(idx->dim), "index: a bf16 corpus needs dim 384, 768 or 1024 (got %u)", idx->dim);
     if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
     idx->rows = nullptr; idx->rows_owned = false;

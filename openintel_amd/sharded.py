@@ -164,12 +164,20 @@ class ShardedPipeline:
         self.stage = {}
         for c in [retriever.local.ctx, fuse_ctx, *lane_ctxs]:
             c.set_graph_replay(self.graphs)
-        # lane 0 = the retriever's own index, lane j > 0 = a view of it; EVERY lane scores on a stream of its own.  (Round 2
-        # ran lane 0 on the caller's stream: `lane_stream.wait_stream(main)` -- "the queries are ready" -- then made every
-        # batch of lane 1 wait for the whole previous batch of lane 0, which sat in front of it on that stream: consecutive
-        # batches overlapped only every other time.  rocprofv3 timeline, profiles/r03_shard_timeline_before.txt.)
-        self.main_ctx_stream = None       # set while lane 0's context runs on its lane stream (restored by drain())
-        self.lanes = [(retriever.local, torch.cuda.Stream(device=dev))]
+        # EVERY lane is a view of the retriever's index on a context and a stream of its own -- lane 0 too, on a context the
+        # pipeline makes like the retriever's (HipContext.like).  The retriever's OWN context is never touched: round 3 moved it
+        # onto a private stream at the first submit() and back at drain(), so a direct retriever.search between the two (or
+        # after an exception skipped the drain) ran on the lane stream, unordered against the caller's, and a stream the caller
+        # had set was lost.  (Round 2 ran lane 0 on the caller's stream: `lane_stream.wait_stream(main)` -- "the
+        # queries are ready" -- then made every batch of lane 1 wait for the whole previous batch of lane 0, which sat in front
+        # of it on that stream: consecutive batches overlapped only every other time.  rocprofv3 timeline,
+        # profiles/r03_shard_timeline_before.txt.)
+        from .context import HipContext
+        self.lane0_ctx = HipContext.like(retriever.local.ctx)
+        self.lane0_ctx.set_graph_replay(self.graphs)
+        st0 = torch.cuda.Stream(device=dev)
+        self.lane0_ctx.set_stream(st0)
+        self.lanes = [(retriever.local.view(self.lane0_ctx), st0)]
         for c in lane_ctxs:
             st = torch.cuda.Stream(device=dev)
             c.set_stream(st)
@@ -194,9 +202,6 @@ class ShardedPipeline:
         slot = self.n % self.n_slots
         index, st = self.lanes[self.n % len(self.lanes)]
         main = torch.cuda.current_stream(self.dev)
-        if self.main_ctx_stream is None:               # lane 0's context: onto its lane stream until drain()
-            self.main_ctx_stream = main
-            self.lanes[0][0].ctx.set_stream(self.lanes[0][1])
         st.wait_stream(main)                           # the queries were produced on the caller's stream (which carries
         for t in (qv, qt, qo):                         # nothing of the pipeline's own: no false dependency between batches)
             if hasattr(t, "record_stream"):            # ... and are read on the lane's: the allocator must know
@@ -277,7 +282,7 @@ class ShardedPipeline:
             c.set_graph_replay(self.graphs)
             lane = (self.r.local.view(c), st)
             self.lanes = [lane0, lane]
-            ms = period()                              # (period() ends in drain(): lane 0 is re-bound at the next submit)
+            ms = period()
             tried.append({"lanes": 2, "placement": p, "ms": ms})
             if ms < 0.97 * best_ms:            # a second lane has to earn its keep
                 if best_lane is not None:
@@ -300,24 +305,21 @@ class ShardedPipeline:
         self.fctx.synchronize()
         for index, _ in self.lanes:
             index.ctx.synchronize()                    # raises if an engine flagged a pool overflow
-        if self.main_ctx_stream is not None:           # lane 0's context back onto the caller's stream
-            self.lanes[0][0].ctx.set_stream(self.main_ctx_stream)
-            self.main_ctx_stream = None
         self.r.check()
 
     def close(self) -> None:
-        """Drain, then close every lane the pipeline holds beyond the retriever's own index: the view AND its context
-        (each lane context owns a full set of search workspaces -- candidate pools, screen pool, BM25 pools: HBM that would
-        otherwise wait for the garbage collector).  `fuse_ctx` and the retriever stay the caller's."""
+        """Drain, then close every lane: the view AND its context (each lane context owns a full set of search workspaces --
+        candidate pools, screen pool, BM25 pools: HBM that would otherwise wait for the garbage collector).  `fuse_ctx` and
+        the retriever (its index and its own context) stay the caller's."""
         import torch
         if self.n:
             self.drain()
         torch.cuda.synchronize(self.dev)
-        for index, _ in self.lanes[1:]:
+        for index, _ in self.lanes:
             c = index.ctx
             index.close()
             c.close()
-        self.lanes = self.lanes[:1]
+        self.lanes = []
 
 
 class ShardedAnalyzer:

@@ -140,3 +140,43 @@ def test_pipeline_with_staged_batches_and_graph_replay_returns_the_same_results(
     assert replays >= 6, replays
     pipe.close()
     ref.close(); ref_ctx.close(); fctx.close(); idx.close(); ctx.close()
+
+
+def test_new_rows_between_replays_are_seen_by_the_replayed_call():
+    """a captured call bakes in the index's rows pointer.  oi_index_set_embeddings with ANOTHER buffer (a caller's
+    pointer: no workspace moves) must invalidate the capture -- the next call with the same arguments scores the new rows."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib
+    dev = torch.device("cuda:0")
+    rows, terms, offs = _data(n=60_000)
+    n, dim = rows.shape
+    B, DEPTH, K = 64, 200, 30
+    rows_a = torch.from_numpy(rows).to(dev)
+    rows_b = torch.from_numpy(np.ascontiguousarray(rows[::-1])).to(dev)    # the same rows in reverse order: other docs win
+    c = oi.HipContext(0)
+    c.set_stream(torch.cuda.Stream(device=dev))
+    c.set_cosine_mode(_lib.OI_COSINE_EXACT)
+    c.set_graph_replay(True)
+    ix = oi.HybridIndex(c, n, dim, 500)
+    ix.set_embeddings(rows_a, normalize=False)
+    ix.set_forward(terms, offs)
+    ix.finalize()
+    rng = np.random.default_rng(5)
+    q, t, o = _batch(rng, B, dim, 500)
+    qv, qt, qo = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev), torch.from_numpy(o).to(dev)
+    out = oi.SearchResult(torch.zeros((B, K), dtype=torch.float32, device=dev), torch.zeros((B, K), dtype=torch.int32, device=dev),
+                          torch.zeros(B, dtype=torch.int32, device=dev))
+    lists_a = None
+    for _ in range(3):                                     # eager, capture, replay
+        lists_a = ix.search_lists(qv, qt, qo, depth=DEPTH)
+        ix.search(qv, qt, qo, k=K, depth=DEPTH, out=out)
+    c.synchronize()
+    cos_a = lists_a.cos_docs.clone()
+    ix.set_embeddings(rows_b, normalize=False)            # a caller's pointer again: nothing of the library's moves
+    lists_b = ix.search_lists(qv, qt, qo, depth=DEPTH)
+    c.synchronize()
+    # row r of the new matrix is row n-1-r of the old one: the cosine list is the old one mirrored
+    assert torch.equal(lists_b.cos_docs[:, 0], (n - 1) - cos_a[:, 0])
+    assert torch.equal(lists_b.cos_scores[:, 0], lists_a.cos_scores[:, 0])
+    ix.close(); c.close()
