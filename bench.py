@@ -134,8 +134,9 @@ def main():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--depth", type=int, default=1000)
     ap.add_argument("--vocab", type=int, default=131072)
-    ap.add_argument("--bm25", choices=["wave", "taat", "scan"], default="wave",
-                    help="BM25 kernel (default wave: term-at-a-time, one wave per task; taat: the first-generation workgroup kernel)")
+    ap.add_argument("--bm25", choices=["stream", "wave", "taat", "scan"], default="stream",
+                    help="BM25 kernel (default stream: term-at-a-time through a per-wave LDS ring; wave: one wave per task; "
+                         "taat: the first-generation workgroup kernel)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
     ap.add_argument("--cosine", choices=["screen", "exact", "split", "screen-copy"], default="screen",
@@ -220,7 +221,7 @@ def main():
         idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
     idx.set_forward(terms, offs)
     idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
-    idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE}[args.bm25])
+    idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE, "stream": idx.BM25_STREAM}[args.bm25])
     n_tokens_local = int(offs[-1].item())
     del terms, offs
     torch.cuda.empty_cache()
@@ -237,9 +238,10 @@ def main():
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
     bm25_bytes = None
-    if args.bm25 != "scan":   # mean over the rotated batches of 8 B x (postings of the batch's terms) + 8 B x blocks x terms
-        n_blocks = (n_local + 32767) // 32768
-        per = [8.0 * float(df_local[b[1].cpu().numpy()].astype("int64").sum()) + 8.0 * n_blocks * int(b[1].numel()) for b in batches]
+    if args.bm25 != "scan":   # mean over the rotated batches of 8 B x (postings of the batch's terms) + bounds x blocks x terms
+        n_blocks = (n_local + 32767) // 32768   # (bounds: 8 B per (block, term); the stream kernel reads three cell words, 12 B)
+        per = [8.0 * float(df_local[b[1].cpu().numpy()].astype("int64").sum()) +
+               (12.0 if args.bm25 == "stream" else 8.0) * n_blocks * int(b[1].numel()) for b in batches]
         bm25_bytes = sum(per) / len(per)
     else:
         bm25_bytes = 4.0 * n_tokens_local + 8.0 * (n_local + 1)
@@ -553,10 +555,12 @@ def main():
             line["bm25_roofline"] = {"bound": "hbm", "achieved": bm25_bytes / (bm_ms / 1e3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": bm25_bytes / (bm_ms / 1e3) / 1e9 / PEAK_HBM_GBS, "kernel_ms_per_step": bm_ms,
                                      "launches_per_step": other["bm25"][1] / iso_steps, "algorithmic_bytes_per_step": bm25_bytes,
-                                     "kernel": "bm25_wave_kernel (term-at-a-time, one wave per (doc block, query) task)" if args.bm25 == "wave"
-                                               else "bm25 (%s)" % args.bm25,
-                                     "note": "algorithmic bytes = 8 B x postings of the batch's terms + 8 B x (blocks x terms); at this "
-                                             "batch size the kernel is latency/issue-bound, not byte-bound (DESIGN 4.3)"}
+                                     "kernel": {"stream": "bm25_stream_kernel (term-at-a-time; every wave streams a weight-balanced range of "
+                                                          "(query, block) tasks through its LDS ring) + bm25_plan_kernel",
+                                                "wave": "bm25_wave_kernel (term-at-a-time, one wave per (doc block, query) task)"}.get(
+                                                    args.bm25, "bm25 (%s)" % args.bm25),
+                                     "note": "algorithmic bytes = 8 B x postings of the batch's terms + 12 B (stream; 8 B wave) x (blocks x "
+                                             "terms); at this batch size the kernel is latency/issue-bound, not byte-bound (DESIGN 4.3)"}
         if exact_side is not None:
             line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring, bound hbm; "
                                      "round 2: error bound re-derived from measured rounding errors and adversarially tested, "

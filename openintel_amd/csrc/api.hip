@@ -954,7 +954,7 @@ int bm25_mode_of(const oi_index *idx) {
 // State of both pools in one block, zeroed with ONE memset per search:
 //   cosine: carry_cnt[B] tau[B] seg_cnt[B][CUs]      BM25: carry_cnt[B] seg_cnt[B][n_blocks]
 // `extra_words` more zeroed words follow them (*extra): the bf16 screen's state, so that one memset kernel does both.
-int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_cap, uint32_t bm_blocks,
+int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_alloc_stride, uint64_t cos_stride, uint32_t carry_cap, uint32_t bm_blocks,
                   uint32_t depth, Pools *out, size_t extra_words = 0, uint32_t **extra = nullptr) {
     DevBuf &flag = ctx->buf("state_flag");
     if (!flag.p) {
@@ -970,7 +970,7 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_stride, uint32_t carry_c
     if (extra) *extra = st.as<uint32_t>() + words;
     const uint64_t bm_stride = (uint64_t)carry_cap + (uint64_t)bm_segs * depth;
     DevBuf &pc = ctx->buf("pool_cos"), &pb = ctx->buf("pool_bm");
-    OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_stride));
+    OI_CHECK(pc.ensure(sizeof(uint64_t) * (size_t)B * cos_alloc_stride)); // (room for the widest view of it: the screen's)
     OI_CHECK(pb.ensure(sizeof(uint64_t) * (size_t)B * bm_stride));
     uint32_t *s = st.as<uint32_t>();
     uint32_t *cos_carry = s, *cos_tau = s + B, *cos_seg = s + 2 * (size_t)B;
@@ -998,9 +998,12 @@ static uint64_t oi_chunk_growth(uint32_t B) {
 
 // End of the corpus chunk that starts at row r: `chunk` rows, but a tail shorter than a quarter of the chunk is taken along
 // (a 2.5M-row shard: 32K, 256K, 2.2M rows instead of 32K, 256K, 2M and a fourth launch + select for 0.2M).
+// And when what is left after this chunk would not fit ONE more chunk but fits two, this chunk grows so that the last one is
+// exactly the largest the pool takes (10M rows, 6.8M-row pool: 32K, 256K, 2.9M, 6.8M instead of 32K, 256K, 2M, 6.8M, 0.9M).
 static uint64_t oi_chunk_end(uint64_t r, uint64_t chunk, uint64_t n, uint64_t max_chunk) {
     uint64_t e = std::min(n, r + chunk);
     if (e < n && (n - e) * 4 <= (e - r) && n - r <= max_chunk) e = n;
+    if (e < n && n - e > max_chunk && n - r <= 2 * max_chunk) e = n - max_chunk;
     return e;
 }
 
@@ -1017,19 +1020,30 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // to handle, no data-dependent sizing).  BM25: every doc block contributes <= depth entries.
     const uint32_t carry_cap = OI_MAX_DEPTH;
     const uint64_t slack = (idx->rows_bf16 ? 128ull : 32ull) * ((uint64_t)ctx->num_cus + 1);
-    // Large pools = few launches: at 10M rows the schedule is 32K, 256K, 2M, rest (4 launches).
-    // The room is address space, not traffic: only entries that pass the threshold are written.
+    // Large pools = few launches: at 10M rows the schedule is 32K, 256K, 3.2M, 6.5M rows (4 launches).  The room is worst
+    // case (every row of a chunk passes the threshold), only entries that pass are written.  Round 4: an f32 corpus gets
+    // 3.25 GiB of pool instead of 8 (the last two chunks are balanced so that the launch count stays), and the screen's pool
+    // and the exact fallback's pool are ONE buffer (they are never live together: the gated exact pipeline starts after the
+    // rescoring has consumed the screen's survivors).  A bf16 corpus (configs[4]: 256 queries) keeps 8 GiB.
     uint64_t cos_stride = 1ull << 24;
-    const uint64_t budget = (8ull << 30) / 8 / B; // <= 8 GiB of cosine pools (288 GB HBM)
+    const uint64_t budget = (idx->rows_bf16 ? (8ull << 30) : (13ull << 28)) / 8 / B;
     if (cos_stride > budget) cos_stride = budget;
     if (cos_stride < carry_cap + 4 * slack) cos_stride = carry_cap + 4 * slack;
     if (cos_stride > carry_cap + n + slack) cos_stride = carry_cap + n + slack;
+    // the screen's view of the same buffer keeps up to 4096 keys per query between chunks and rounds its segments to 4 tiles
+    const uint32_t pf_carry = 4096;
+    const uint64_t pf_slack = 128ull * ((uint64_t)ctx->num_cus + 1);
+    uint64_t pf_stride = 1ull << 24;
+    if (pf_stride > budget) pf_stride = budget;
+    if (pf_stride < pf_carry + 4 * pf_slack) pf_stride = pf_carry + 4 * pf_slack;
+    if (pf_stride > pf_carry + n + pf_slack) pf_stride = pf_carry + n + pf_slack;
     Pools P;
     // the bf16 screen's state words (carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][CUs]) ride in the same memset
     const size_t screen_words = (size_t)B * (4 + (size_t)ctx->num_cus) + 4;
     uint32_t *screen_state = nullptr;
     // (the depth-sized segments of P.bm belong to the workgroup-per-block kernel: no room is set aside for them otherwise)
-    OI_CHECK(prepare_pools(ctx, B, cos_stride, carry_cap, bm25_mode_of(idx) == 1 ? idx->n_blocks : 0, depth, &P, screen_words, &screen_state));
+    OI_CHECK(prepare_pools(ctx, B, std::max<uint64_t>(cos_stride, idx->rows_bf16 ? 0ull : pf_stride), cos_stride, carry_cap,
+                           bm25_mode_of(idx) == 1 ? idx->n_blocks : 0, depth, &P, screen_words, &screen_state));
 
     // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
@@ -1255,18 +1269,12 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
 
             // ---- bf16 screen -> margin selects -> exact rescoring -> sorted selection; then the gated exact pipeline
             // (cosine_prefilter.hip).  Its pool keeps up to 4096 keys per query between chunks.
-            const uint32_t pf_carry = 4096;
-            const uint64_t pf_slack = 128ull * ((uint64_t)ctx->num_cus + 1); // segments round up to 4 tiles per workgroup
-            uint64_t pf_stride = 1ull << 24;
-            if (pf_stride > budget) pf_stride = budget;
-            if (pf_stride < pf_carry + 4 * pf_slack) pf_stride = pf_carry + 4 * pf_slack;
-            if (pf_stride > pf_carry + n + pf_slack) pf_stride = pf_carry + n + pf_slack;
             const uint32_t segs = (uint32_t)ctx->num_cus;
             // state, zeroed with one memset: carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][segs]
             const size_t words = (size_t)B * (4 + segs) + 4;
-            DevBuf &pk = ctx->buf("screen_pool"), &rk = ctx->buf("screen_rescored"), &qb = ctx->buf("screen_q_bf16");
+            DevBuf &pk = ctx->buf("pool_cos"), &rk = ctx->buf("screen_rescored"), &qb = ctx->buf("screen_q_bf16");
             OI_REQUIRE(words <= screen_words, "search: screen state does not fit its reservation");
-            OI_CHECK(pk.ensure(sizeof(uint64_t) * (size_t)B * pf_stride));
+            OI_REQUIRE(pk.cap >= sizeof(uint64_t) * (size_t)B * pf_stride, "search: the shared cosine pool is too small for the screen's view");
             OI_CHECK(rk.ensure(sizeof(uint64_t) * (size_t)B * pf_carry));
             const uint32_t n_padded = (B + 31u) & ~31u;
             OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 64) * idx->dim));
