@@ -1000,10 +1000,12 @@ static uint64_t oi_chunk_growth(uint32_t B) {
 // (a 2.5M-row shard: 32K, 256K, 2.2M rows instead of 32K, 256K, 2M and a fourth launch + select for 0.2M).
 // And when what is left after this chunk would not fit ONE more chunk but fits two, this chunk grows so that the last one is
 // exactly the largest the pool takes (10M rows, 6.8M-row pool: 32K, 256K, 2.9M, 6.8M instead of 32K, 256K, 2M, 6.8M, 0.9M).
-static uint64_t oi_chunk_end(uint64_t r, uint64_t chunk, uint64_t n, uint64_t max_chunk) {
+// (only where the chunk AFTER this one would be cut by the pool anyway -- `next_chunk`, its planned size, reaches max_chunk --
+// never for the small first chunks, which run without a threshold).
+static uint64_t oi_chunk_end(uint64_t r, uint64_t chunk, uint64_t n, uint64_t max_chunk, uint64_t next_chunk) {
     uint64_t e = std::min(n, r + chunk);
     if (e < n && (n - e) * 4 <= (e - r) && n - r <= max_chunk) e = n;
-    if (e < n && n - e > max_chunk && n - r <= 2 * max_chunk) e = n - max_chunk;
+    if (e < n && next_chunk >= max_chunk && n - e > max_chunk && n - r <= 2 * max_chunk) e = n - max_chunk;
     return e;
 }
 
@@ -1214,7 +1216,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > max_chunk) chunk = max_chunk;
-                const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk);
+                const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk, chunk * oi_chunk_growth(B));
                 OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->rows_bf16, r, e, idx->dim, d_qv, B, idx->doc_id_base, P.cos));
                 const bool last = e == n;
                 OI_CHECK(oi_launch_select(ctx, P.cos, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
@@ -1249,7 +1251,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 uint64_t r = 0;
                 while (r < n) {
                     if (chunk > max_chunk) chunk = max_chunk;
-                    const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk);
+                    const uint64_t e = oi_chunk_end(r, chunk, n, max_chunk, chunk * oi_chunk_growth(B));
                     OI_CHECK(oi_launch_cosine_chunk(ctx, idx->rows, r, e, idx->dim, q, B, Bp, idx->doc_id_base, X));
                     const bool last = e == n;
                     OI_CHECK(oi_launch_select(ctx, X, B, depth, /*compact=*/!last, last ? cos_s : nullptr,
@@ -1298,7 +1300,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
-                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk);
+                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, chunk * oi_chunk_growth(B));
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
                 if (want_copy) OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, d_qv, B, idx->doc_id_base, PF));
