@@ -646,6 +646,15 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         atomicMax(&a.timing[10], whole);
         atomicAdd(&a.timing[11], t_big); atomicAdd(&a.timing[12], t_big_n); atomicAdd(&a.timing[13], t_first);
         atomicAdd(&a.timing[14], t_n_wait); atomicAdd(&a.timing[15], t_b_wait);
+        if (w < 4096) { // per-wave record: whole | wait | visits, tasks | hardware ids, start time
+            unsigned long long *o = a.timing + 32 + 2048 * 4 + (unsigned long long)w * 4;
+            uint32_t xcc = 0, hwid = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[0] = whole; o[1] = t_acc[0];
+            o[2] = ((unsigned long long)t_n_wait << 32) | t_tasks;
+            o[3] = ((unsigned long long)(xcc & 0xF) << 56) | ((unsigned long long)(hwid & 0xFFFFFF) << 32) | (uint32_t)(t_wave0 & 0xFFFFFFFFull);
+        }
     }
 }
 
@@ -744,7 +753,7 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
 #ifdef OI_ABLATION
     if (oi_ablation_env("OI_BM25_STREAM_TIMING")) { // the stamped instantiation, sums and the first long waits printed per launch
         DevBuf &tb = ctx->buf("bm25_stream_timing");
-        const size_t tbytes = (32 + 2048 * 4) * sizeof(unsigned long long);
+        const size_t tbytes = (32 + 2048 * 4 + 4096 * 4) * sizeof(unsigned long long);
         OI_CHECK(tb.ensure(tbytes));
         OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, tbytes, ctx->stream));
         a.timing = tb.as<unsigned long long>();
@@ -758,11 +767,35 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
                 a.nbh, (unsigned long long)n_tasks, h[9], h[0] / wv, h[1] / wv, h[2] / wv, h[3] / wv, h[4] / wv, h[5] / wv, h[6] / wv,
                 h[7] / wv, h[8] / wv, h[10]);
         {
-            std::vector<unsigned long long> smp(32 + 2048 * 4);
+            std::vector<unsigned long long> smp(32 + 2048 * 4 + 4096 * 4);
             OI_HIP_CHECK(hipMemcpy(smp.data(), tb.p, smp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             const unsigned long long ns = std::min<unsigned long long>(smp[16], 2048);
             fprintf(stderr, "[bm25 stream sample] %llu samples\n", smp[16]);
-            for (unsigned long long i = 0; i < ns && i < 40; ++i) {
+            { // per-wave records: by XCC, and the ten longest waves
+                const unsigned long long nw = std::min<unsigned long long>(h[9], 4096);
+                double xs[16] = {0}, xw[16] = {0}, xv[16] = {0}; unsigned xn[16] = {0};
+                std::vector<std::pair<unsigned long long, unsigned>> order;
+                unsigned long long t0min = ~0ull;
+                for (unsigned i = 0; i < nw; ++i) { const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)i * 4]; if (o[0]) t0min = std::min<unsigned long long>(t0min, o[3] & 0xFFFFFFFFull); }
+                for (unsigned i = 0; i < nw; ++i) {
+                    const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)i * 4];
+                    if (!o[0]) continue;
+                    const unsigned x = (unsigned)(o[3] >> 56) & 15u;
+                    xs[x] += (double)o[0]; xw[x] += (double)o[1]; xv[x] += (double)(o[2] >> 32); ++xn[x];
+                    order.push_back({o[0], i});
+                }
+                for (unsigned x = 0; x < 16; ++x) if (xn[x]) fprintf(stderr, "[bm25 stream xcc %u] waves %u whole %.0f wait %.0f visits %.1f\n", x, xn[x], xs[x] / xn[x], xw[x] / xn[x], xv[x] / xn[x]);
+                std::sort(order.begin(), order.end());
+                for (size_t k = 0; k < order.size(); k += std::max<size_t>(1, order.size() / 12)) {
+                    const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)order[k].second * 4];
+                    fprintf(stderr, "[bm25 stream wave pct %2.0f] wave %u whole %llu wait %llu visits %llu tasks %llu xcc %llu hwid %06llx start +%llu\n", 100.0 * k / order.size(),
+                            order[k].second, o[0], o[1], o[2] >> 32, o[2] & 0xFFFFFFFF, o[3] >> 56, (o[3] >> 32) & 0xFFFFFF, (o[3] & 0xFFFFFFFFull) - t0min);
+                }
+                const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)order.back().second * 4];
+                fprintf(stderr, "[bm25 stream wave longest] wave %u whole %llu wait %llu visits %llu tasks %llu xcc %llu start +%llu\n", order.back().second, o[0], o[1], o[2] >> 32,
+                        o[2] & 0xFFFFFFFF, o[3] >> 56, (o[3] & 0xFFFFFFFFull) - t0min);
+            }
+            for (unsigned long long i = 0; i < ns && i < 6; ++i) {
                 const unsigned long long *o = &smp[32 + i * 4];
                 fprintf(stderr, "[bm25 stream sample] dur %llu pass %llu v %llu C %llu | visit# %llu stores %llu task# %llu | at cycle %llu ahead %llu\n", o[0],
                         o[1] >> 48, (o[1] >> 32) & 0xFFFF, o[1] & 0xFFFFFFFF, o[2] >> 32, (o[2] >> 16) & 0xFFFF, o[2] & 0xFFFF, o[3] >> 8, o[3] & 255);

@@ -143,15 +143,17 @@ def test_bench_self_launcher_two_gloo_ranks_sharing_the_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1100)
-def test_bench_self_launcher_five_gloo_ranks_sharing_the_gpu():
+def test_bench_self_launcher_four_gloo_ranks_sharing_the_gpu():
     """the multi-rank code path beyond two ranks on hardware -- shard_bounds, the all_gather_object of the
-    per-rank records, calibrate() under several ranks, oi_fuse_packed fed by a real 5-way gather.  FIVE ranks, not eight:
-    the GPU box admits six processes on its card and this pytest process is one of them (profiles/r04_launcher_gloo6_*.json
-    is the same run with six ranks, started outside pytest; N = 8 is the driver's to launch)."""
-    line = _run_bench({"OI_BENCH_BACKEND": "gloo", "OI_BENCH_SINGLE_DEVICE": "1"}, ["--gpus", "5"] + SMALL)
-    assert line["n_gpus"] == 5 and line["value"] > 0
+    per-rank records, calibrate() under several ranks, oi_fuse_packed fed by a real 4-way gather.  FOUR ranks, not eight:
+    the GPU box admits six processes on its card, this pytest process is one of them and five ranks were counted as seven
+    (the run was killed by the box's process guard, round 4).  profiles/r04_launcher_gloo5_*.json is the same run with
+    five ranks started outside pytest; eight ranks meet on the CPU (tests/test_sharded_gloo.py); N = 8 on hardware is the
+    driver's to launch."""
+    line = _run_bench({"OI_BENCH_BACKEND": "gloo", "OI_BENCH_SINGLE_DEVICE": "1"}, ["--gpus", "4"] + SMALL)
+    assert line["n_gpus"] == 4 and line["value"] > 0
     pr = line["config"]["per_rank"]
-    assert [p["rank"] for p in pr] == [0, 1, 2, 3, 4] and sum(p["docs_per_gpu"] for p in pr) == 200000
+    assert [p["rank"] for p in pr] == [0, 1, 2, 3] and sum(p["docs_per_gpu"] for p in pr) == 200000
     assert all(p["doc_id_base"] == sum(q["docs_per_gpu"] for q in pr[:i]) for i, p in enumerate(pr))
     assert all(p["lane_calibration"] is not None for p in pr)
     assert line["roofline"]["step_level"]["frac"] > 0
