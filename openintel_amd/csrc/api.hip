@@ -1076,8 +1076,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 return OI_OK;
             }
             // (the share of the blocks scored without a threshold: 1/8 and 1/16 measure the same, 1/32 is 5 % slower)
-            static const uint32_t first_div = oi_ablation_env("OI_BM25_FIRST_DIV") ? std::max(2, atoi(oi_ablation_env("OI_BM25_FIRST_DIV"))) : 8;
-            const uint32_t first = nb > 16 ? std::max<uint32_t>(8, nb / first_div) : nb;
+            static const uint32_t first_div = oi_ablation_env("OI_BM25_FIRST_DIV") ? std::max(1, atoi(oi_ablation_env("OI_BM25_FIRST_DIV"))) : 8;
+            // Up to 48 blocks (1.5M docs: a shard of configs[3]) ONE phase: every touched doc is a candidate (~30K keys per query,
+            // the select's register path), one launch and one select fewer -- 0.052 vs 0.081 ms of kernels at 1.25M docs.
+            const uint32_t first = nb > 48 ? std::max<uint32_t>(8, nb / first_div) : nb;
             const uint32_t cap1 = oi_bm25_stream_seg_cap(depth, true), cap2 = oi_bm25_stream_seg_cap(depth, false);
             const uint64_t sstride = (uint64_t)carry_cap + std::max<uint64_t>((uint64_t)first * cap1, (uint64_t)nb * cap2);
             uint64_t pass = (2ull << 30) / 8 / sstride; // <= 2 GiB of pool (0.2 GB for 64 queries over 10M docs)

@@ -77,6 +77,9 @@ struct BsArgs {
     uint32_t n_win, vocab, doc_id_base, block0, nbh, q_begin, nq;
     uint32_t seg_cnt_stride, carry_cap, seg_cap, depth;
     unsigned long long *timing; // TIMING instantiation only: per-section cycle sums over all waves
+    const uint2 *qctx;          // [nq][64] per query and lane j: {cell index of (term j, window 0) or ~0 without a run, idf bits} (plan)
+    uint32_t *queue;            // the launch's hand-out counter (zeroed by the plan kernel)
+    uint32_t n_chunks;          // the weight axis is cut into this many ranges: wave w starts with range w, then draws
 };
 
 __device__ __forceinline__ uint32_t bs_lds_addr(const void *p) {
@@ -215,12 +218,12 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         if (b >= nbh) { ++lo; b = 0; }
         r_out = lo; b_out = b;
     };
-    uint32_t r0, b0, r1, b1;
-    locate(total / G * w + total % G * w / G, r0, b0);
-    if (w + 1 == G) { r1 = nq; b1 = 0; } else locate(total / G * (w + 1) + total % G * (w + 1) / G, r1, b1);
-    r0 = bs_rfl(r0); b0 = bs_rfl(b0); r1 = bs_rfl(r1); b1 = bs_rfl(b1);
-    if (r0 > r1 || (r0 == r1 && b0 >= b1)) return;
-
+    // Ranges are handed out DYNAMICALLY (round 4b): the weight axis is cut into n_chunks ranges (4 per wave), wave w takes
+    // range w first and then draws the next free one from a.queue.  A static cut, one range per wave, ended with its
+    // longest wave at 1.75x the average: waves with the same number of visits took 140K..805K cycles and XCDs 0, 1, 6, 7
+    // ran ~40 % slower than 2..5 (per-wave records of the stamped build).
+    const uint32_t NCH = a.n_chunks;
+    auto cut = [&](uint32_t c) __attribute__((always_inline)) { return total / NCH * c + total % NCH * c / NCH; };
     const uint32_t lane16 = lane * 16;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     auto sample = [&](unsigned long long dur, uint32_t pass, uint32_t v, uint32_t C, uint32_t gcons, uint32_t ah) __attribute__((always_inline)) {
@@ -531,7 +534,12 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         ++g_consume; --ahead;
     };
 
-    // ================================================================ the stream: query by query, block by block
+    // ================================================================ the stream: range by range, query by query, block by block
+    for (uint32_t ch = w; ch < NCH;) {
+    uint32_t r0, b0, r1, b1;
+    locate(cut(ch), r0, b0);
+    if (ch + 1 == NCH) { r1 = nq; b1 = 0; } else locate(cut(ch + 1), r1, b1);
+    r0 = bs_rfl(r0); b0 = bs_rfl(b0); r1 = bs_rfl(r1); b1 = bs_rfl(b1);
     for (uint32_t r = r0; r <= r1 && r < nq; ++r) {
         const uint32_t bA = r == r0 ? b0 : 0u, bB = r == r1 ? b1 : nbh;
         if (bA >= bB) continue;
@@ -542,13 +550,13 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         q_tb = bs_rfl(a.q_offsets[a.q_begin + r]);
         q_T = bs_rfl(a.q_offsets[a.q_begin + r + 1]) - q_tb;
         const bool long_query = q_T > 64u;
-        {
-            uint32_t term = 0xFFFFFFFFu;
-            if (lane < q_T) term = a.q_terms[q_tb + lane];
-            d_ok = term < a.vocab;
-            d_cb = d_ok ? term * a.n_win : 0u;
-            d_idf = d_ok ? a.idf[term] : 0.f;
-            // Retire these loads HERE: hipcc's s_waitcnt pass otherwise carries "d_idf may be in flight" around the whole
+        {   // the lanes' runs: ONE coalesced load of what the plan kernel prepared (round 4b: term id -> idf / list base was a
+            // chain of dependent loads at every range and query start, ~2.5 us each under load)
+            const uint2 qc = a.qctx[(uint64_t)r * 64u + lane];
+            d_ok = qc.x != 0xFFFFFFFFu;
+            d_cb = d_ok ? qc.x : 0u;
+            d_idf = d_ok ? __uint_as_float(qc.y) : 0.f;
+            // Retire this load HERE: hipcc's s_waitcnt pass otherwise carries "d_idf may be in flight" around the whole
             // stream loop and drains the DMA ring with a vmcnt(0) wherever it is used.
             asm volatile("" : "+v"(d_idf), "+v"(d_cb));
         }
@@ -638,6 +646,12 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             cur = nxt; icur = inxt; blk = nblk; win = nwin;
         }
     }
+    {   // the next free range (nothing is in flight here; the result is used at once: no load left pending for hipcc's waits)
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(a.queue, 1u);
+        ch = G + bs_rfl(nx);
+    }
+    }
     if (TIMING && lane == 0 && a.timing) {
         const unsigned long long whole = stamp() - t_wave0;
         for (int i = 0; i < 8; ++i) atomicAdd(&a.timing[i], t_acc[i]);
@@ -665,8 +679,18 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
 __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restrict__ q_terms, const uint32_t *__restrict__ q_offsets,
                                                         const uint32_t *__restrict__ df, uint32_t vocab, uint32_t n_blocks,
                                                         uint32_t q_begin, uint32_t nq, uint32_t *unit, uint64_t *cum,
-                                                        uint32_t *state, uint64_t state_words) {
+                                                        uint32_t *state, uint64_t state_words, const float *__restrict__ idf,
+                                                        uint32_t n_win, uint2 *qctx) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < state_words; i += (uint64_t)gridDim.x * 256) state[i] = 0u;
+    // every query's first 64 runs as the stream kernel's lanes want them: {term * n_win, idf} or {~0, 0} (all workgroups)
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq * 64u; i += gridDim.x * 256) {
+        const uint32_t r = i >> 6, j = i & 63u;
+        const uint32_t tb = q_offsets[q_begin + r], te = q_offsets[q_begin + r + 1];
+        uint32_t term = 0xFFFFFFFFu;
+        if (tb + j < te) term = q_terms[tb + j];
+        const bool ok = term < vocab;
+        qctx[i] = ok ? make_uint2(term * n_win, __float_as_uint(idf[term])) : make_uint2(0xFFFFFFFFu, 0u);
+    }
     if (blockIdx.x != 0) return;
     __shared__ uint32_t s_unit[BS_MAX_Q];
     for (uint32_t r = threadIdx.x; r < nq; r += 256) {
@@ -681,6 +705,7 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restri
         s_unit[r] = (uint32_t)u;
         unit[r] = (uint32_t)u;
     }
+    if (threadIdx.x < 2) unit[BS_MAX_Q + threadIdx.x] = 0u; // the two phases' hand-out counters
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t c = 0;
@@ -700,13 +725,15 @@ int oi_launch_bm25_plan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     oi_ctx *ctx = idx->ctx;
     OI_REQUIRE(nq >= 1 && nq <= BS_MAX_Q, "bm25 (stream): %u queries in one pass (limit %u)", nq, BS_MAX_Q);
     DevBuf &pb = ctx->buf("bm25_stream_plan");
-    OI_CHECK(pb.ensure(sizeof(uint64_t) * (BS_MAX_Q + 2) + sizeof(uint32_t) * BS_MAX_Q));
+    OI_CHECK(pb.ensure(sizeof(uint64_t) * (BS_MAX_Q + 2) + sizeof(uint32_t) * (BS_MAX_Q + 2) + sizeof(uint2) * BS_MAX_Q * 64)); // cum | unit | two hand-out counters | qctx
     uint64_t *cum = pb.as<uint64_t>();
     uint32_t *unit = reinterpret_cast<uint32_t *>(cum + BS_MAX_Q + 2);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (state_words + 4095) / 4096));
+    uint2 *qctx = reinterpret_cast<uint2 *>(unit + BS_MAX_Q + 2);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>((nq * 64u + 255u) / 256u, (state_words + 4095) / 4096));
     ProfScope ps(ctx, "bm25");
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_q_terms, d_q_offsets,
-                       idx->df_local.as<uint32_t>(), idx->vocab, idx->n_blocks, q_begin, nq, unit, cum, state, state_words);
+                       idx->df_local.as<uint32_t>(), idx->vocab, idx->n_blocks, q_begin, nq, unit, cum, state, state_words,
+                       idx->idf.as<float>(), idx->n_win, qctx);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
@@ -738,6 +765,8 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
     a.seg_cnt_stride = pool.seg_cnt_stride; a.carry_cap = pool.carry_cap; a.seg_cap = pool.seg_cap; a.depth = depth;
     a.timing = nullptr;
     const uint64_t n_tasks = (uint64_t)a.nbh * nq;
+    a.queue = reinterpret_cast<uint32_t *>(const_cast<uint32_t *>(a.unit) + BS_MAX_Q) + (block_begin ? 1 : 0); // one counter per phase
+    a.qctx = reinterpret_cast<const uint2 *>(a.unit + BS_MAX_Q + 2);
     // A/B switches of the -DOI_ABLATION build (tools/): 16384-doc windows (10 waves per CU, a third more chunk visits: measured
     // slower, 0.157 vs 0.143 ms), resident workgroups per CU, the stamped instantiation
     static const bool half_windows = oi_ablation_env("OI_BM25_STREAM_W") && atoi(oi_ablation_env("OI_BM25_STREAM_W")) == 16384;
@@ -747,6 +776,9 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
         uint64_t per_cu = (160u * 1024u) / lds_total; // resident workgroups per CU (LDS)
         if (const char *e = oi_ablation_env("OI_BM25_STREAM_WGS")) per_cu = std::max(1, atoi(e));
         const uint64_t wgs = std::min<uint64_t>((n_tasks + BS_WPB - 1) / BS_WPB, per_cu * (uint64_t)ctx->num_cus);
+        uint64_t per_wave = 1; // ranges per wave (measured: 1 / 2 / 4 / 8 give 0.152 / 0.157 / 0.179 / 0.262 ms -- a range START costs more than the balance returns)
+        if (const char *e = oi_ablation_env("OI_BM25_STREAM_CHUNKS")) per_wave = std::max(1, atoi(e));
+        a.n_chunks = (uint32_t)std::max<uint64_t>(wgs * BS_WPB, std::min<uint64_t>(n_tasks, per_wave * wgs * BS_WPB));
         hipLaunchKernelGGL(kernel, dim3((uint32_t)wgs), dim3(BS_WPB * 64), lds_total, ctx->stream, a);
         return OI_OK;
     };

@@ -64,7 +64,7 @@ def test_product_build_has_no_ablation_switches():
                  b"OI_FIRST_CHUNK_MULT", b"OI_KS_SHAPE", b"OI_BF16_SOLO", b"OI_HEADLINE_TILE", b"OI_HEADLINE_TIMING",
                  b"OI_LEXICON_V2", b"OI_LEX_DBG", b"OI_LEX_GRID", b"OI_SCREEN_CUS", b"OI_QUAD_DBG", b"OI_BF16_NO_QUAD",
                  b"OI_BM25_WAVE_DBG", b"OI_BM25_WAVE_TIMING", b"OI_BM25_WAVE_WGS", b"OI_SEG_DBG",
-                 b"OI_BM25_STREAM_W", b"OI_BM25_STREAM_WGS", b"OI_BM25_STREAM_TIMING", b"OI_BM25_FIRST_DIV"):
+                 b"OI_BM25_STREAM_W", b"OI_BM25_STREAM_CHUNKS", b"OI_BM25_STREAM_WGS", b"OI_BM25_STREAM_TIMING", b"OI_BM25_FIRST_DIV"):
         assert name not in blob, name
     assert b"OI_COSINE_MODE" in blob and b"OI_BM25_MODE" in blob   # the two documented mode selectors stay
 
