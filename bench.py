@@ -264,7 +264,7 @@ def main():
                 c = oi.HipContext(local_rank)
                 c.set_cosine_mode(MODES[args.cosine])
                 return c
-            pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4)
+            pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4, max_lanes=args.lanes)
         lane_ctxs = [index.ctx for index, _ in pipe.lanes]   # every lane scores on a context of its own (lane 0 too)
 
     def step():

@@ -562,9 +562,20 @@ extern "C" int oi_headline_scan_rows(oi_ctx *ctx, const uint8_t *blob, const uin
     DevBuf &si = ctx->buf("hl_rows_in"), &so = ctx->buf("hl_rows_out");
     OI_CHECK(si.ensure(in_bytes + 64));
     OI_CHECK(so.ensure(out_bytes));
-    OI_CHECK(ctx->pin_in.ensure(in_bytes));
-    OI_CHECK(ctx->pin_out.ensure(out_bytes));
-    uint8_t *h = ctx->pin_in.as<uint8_t>();
+    // page-locked staging for the calls it pays for (one ticker's or a dip scan's rows); a large scan packs into pageable
+    // memory and copies its results straight into the caller's arrays -- PinBuf never shrinks, and one big call would leave
+    // tens of MB page-locked for the life of the ctx (the other OI_HOST entry points follow the same rule)
+    const bool pin = in_bytes <= OI_PINNED_STAGE_MAX && out_bytes <= OI_PINNED_STAGE_MAX;
+    std::vector<uint8_t> pageable_in;
+    uint8_t *h;
+    if (pin) {
+        OI_CHECK(ctx->pin_in.ensure(in_bytes));
+        OI_CHECK(ctx->pin_out.ensure(out_bytes));
+        h = ctx->pin_in.as<uint8_t>();
+    } else {
+        pageable_in.resize(in_bytes);
+        h = pageable_in.data();
+    }
     if (bytes) memcpy(h, blob, bytes);
     memcpy(h + off_o, offsets, sizeof(uint64_t) * (n + 1));
     for (uint32_t r = 0; r < n_rows; ++r)
@@ -581,6 +592,13 @@ extern "C" int oi_headline_scan_rows(oi_ctx *ctx, const uint8_t *blob, const uin
         OI_CHECK(oi_launch_headline_scan_params(ctx, d, d_offs + t0, t1 - t0, bytes, offsets[t1] - offsets[t0], d + off_p + pb * r,
                                                 reinterpret_cast<uint16_t *>(o + out_m) + t0,
                                                 reinterpret_cast<uint64_t *>(o) + t0, o + out_a + t0));
+    }
+    if (!pin) {
+        OI_HIP_CHECK(hipMemcpyAsync(order_out, o, out_m, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipMemcpyAsync(mask_out, o + out_m, sizeof(uint16_t) * n, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipMemcpyAsync(about_out, o + out_a, n, hipMemcpyDeviceToHost, st));
+        OI_HIP_CHECK(hipStreamSynchronize(st)); // (before pageable_in goes out of scope)
+        return OI_OK;
     }
     OI_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, so.p, out_bytes, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));

@@ -183,7 +183,7 @@ class ShardedPipeline:
             c.set_stream(st)
             self.lanes.append((retriever.local.view(c), st))
         self.n_shards = retriever.world
-        self.n_slots = max(4, 2 * len(self.lanes))   # (4: room for a second lane added by calibrate())
+        self.n_slots = max(6, 2 * len(self.lanes))   # (6: room for a second and a third lane added by calibrate())
         self.calibration = None
         words = packed_words(self.B, self.depth)
         mk = lambda n, dt: torch.zeros(n, dtype=dt, device=dev)
@@ -245,15 +245,16 @@ class ShardedPipeline:
         import torch
         torch.cuda.current_stream(self.dev).wait_event(self.fused[slot])
 
-    def calibrate(self, batches, make_ctx: Callable, reps: int = 16, placements: int = 4) -> dict:
-        """Choose between one lane and two EMPIRICALLY, and the second lane's stream with it.
+    def calibrate(self, batches, make_ctx: Callable, reps: int = 16, placements: int = 4, max_lanes: int = 2) -> dict:
+        """Choose the number of lanes EMPIRICALLY, and each added lane's stream with it.
 
-        Whether a second lane pays depends on which hardware queue its stream lands on (HIP streams share a handful of
+        Whether another lane pays depends on which hardware queue its stream lands on (HIP streams share a handful of
         queues, handed out round-robin at creation; measured at a 1.25M-row shard, same code: 0.745-0.82 ms per batch
         when the two lanes' streams do not share a queue with each other's corpus passes, 0.88-0.92 -- no gain -- or worse
-        when they do).  So: time `reps` batches with lane 0 alone, then with each of `placements`
-        freshly created (context, stream, view) as the second lane, keep the best set-up and close the others.  Every rank
-        runs the same number of batches (the collectives stay in step); the choice itself is local to the rank.
+        when they do).  So: time `reps` batches with lane 0 alone, then -- lane by lane up to
+        `max_lanes` -- with each of `placements` freshly created (context, stream, view) as the next lane; a lane is kept if
+        its best placement is at least 3 % faster than the set-up without it, the search stops at the first lane that is not.
+        Every rank runs the same number of batches (the collectives stay in step); the choice itself is local to the rank.
         `make_ctx()` returns a new HipContext of this device, configured like the retriever's."""
         import time
 
@@ -272,27 +273,34 @@ class ShardedPipeline:
             torch.cuda.synchronize(self.dev)
             return (time.perf_counter() - t0) / reps * 1e3
 
-        lane0 = self.lanes[0]
+        kept = [self.lanes[0]]
         tried = [{"lanes": 1, "ms": period()}]
-        best_ms, best_lane = tried[0]["ms"], None
-        for p in range(max(0, placements)):
-            c = make_ctx()
-            st = torch.cuda.Stream(device=self.dev)
-            c.set_stream(st)
-            c.set_graph_replay(self.graphs)
-            lane = (self.r.local.view(c), st)
-            self.lanes = [lane0, lane]
-            ms = period()
-            tried.append({"lanes": 2, "placement": p, "ms": ms})
-            if ms < 0.97 * best_ms:            # a second lane has to earn its keep
-                if best_lane is not None:
-                    best_lane[0].close()
-                    best_lane[0].ctx.close()
-                best_ms, best_lane = ms, lane
+        best_ms = tried[0]["ms"]
+        searching = True
+        for n_lanes in range(2, max(2, int(max_lanes)) + 1):
+            best_lane = None
+            for p in range(max(0, placements) if searching else 0):   # (a rank that stopped still runs no further trials: every
+                c = make_ctx()                                        # rank's collectives are its own batches', nothing is shared)
+                st = torch.cuda.Stream(device=self.dev)
+                c.set_stream(st)
+                c.set_graph_replay(self.graphs)
+                lane = (self.r.local.view(c), st)
+                self.lanes = kept + [lane]
+                ms = period()
+                tried.append({"lanes": n_lanes, "placement": p, "ms": ms})
+                if ms < 0.97 * best_ms:            # another lane has to earn its keep
+                    if best_lane is not None:
+                        best_lane[0].close()
+                        best_lane[0].ctx.close()
+                    best_ms, best_lane = ms, lane
+                else:
+                    lane[0].close()
+                    c.close()
+            if best_lane is None:
+                searching = False
             else:
-                lane[0].close()
-                c.close()
-        self.lanes = [lane0] if best_lane is None else [lane0, best_lane]
+                kept.append(best_lane)
+        self.lanes = kept
         self.calibration = {"chosen_lanes": len(self.lanes), "period_ms": best_ms, "tried": tried}
         return self.calibration
 

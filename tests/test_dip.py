@@ -184,6 +184,15 @@ def test_scan_rows_equals_row_by_row_and_the_oracle_gpu(scanner):
         sm, so_, sa = scanner.scan(titles, ticker, forms)
         assert np.array_equal(m, sm) and np.array_equal(o, so_) and np.array_equal(a, sa)
     assert scanner.scan_rows([]) == []
+    # a call too large for the page-locked staging (> 1 MB of titles): pageable path, same results, nothing stays pinned
+    pinned_before = scanner.ctx.workspace_bytes()[1]
+    big_titles = synth.headlines_np(30_000, seed=5)
+    big = scanner.scan_rows([(big_titles[:20_000], "UCTT", ["ultra clean"]), (big_titles[20_000:], "VIK", ["viking"])])
+    for (titles, ticker, forms), (m, o, a) in zip([(big_titles[:20_000], "UCTT", ["ultra clean"]), (big_titles[20_000:], "VIK", ["viking"])], big):
+        blob, offs = pack_posts(titles)
+        rm, ro, ra = lib.headline_scan(blob, offs, ticker, forms)
+        assert np.array_equal(m, rm) and np.array_equal(o, ro) and np.array_equal(a, ra), ticker
+    assert scanner.ctx.workspace_bytes()[1] == pinned_before
     one = scanner.scan_rows([([], "UCTT", ["ultra clean"])])
     assert len(one) == 1 and one[0][0].size == 0
     # argument errors come back as errors, not as truncation: rows that do not cover the titles, descending row offsets,
