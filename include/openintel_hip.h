@@ -294,6 +294,13 @@ int oi_index_local_stats(oi_index *idx, uint64_t *total_tokens_out, uint32_t *df
 int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_total_tokens,
                       const uint32_t *global_df_host);
 
+/* How many rows the screened cosine scorer sets aside (diagnostics, tests).  When the largest row norms of an f32 corpus
+ * stand out from the rest (> 1.5 x the RMS norm, or the same for the norm of bf16(x) - x) and the rows responsible are few
+ * (<= 1024), they are left out of the screen's thresholds and rescored exactly for every query; the screen's margin is then
+ * built from the other rows' maxima.  0: one class (a normalised corpus, or too many such rows).  Builder-defined like the
+ * whole retrieval path (the reference has no embeddings: SURVEY.md section 0). */
+int oi_index_long_rows(oi_index *idx, uint32_t *n_out);
+
 /* BM25 kernel choice: 0 = default (= 4), 1 = term-at-a-time with one workgroup per doc block (bm25.hip, the
  * first-generation kernel), 2 = batch scan of the forward index (bm25_scan.hip), 3 = term-at-a-time with one wave
  * per (doc block, query) task (bm25_wave.hip), 4 = term-at-a-time as a stream: every wave walks a weight-balanced

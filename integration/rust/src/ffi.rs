@@ -98,6 +98,7 @@ extern "C" {
     pub fn oi_index_local_stats(idx: *mut OiIndex, total_tokens_out: *mut u64, df_out_host: *mut u32) -> c_int;
     pub fn oi_index_finalize(idx: *mut OiIndex, global_n_docs: u64, global_total_tokens: u64,
                              global_df_host: *const u32) -> c_int;
+    pub fn oi_index_long_rows(idx: *mut OiIndex, n_out: *mut u32) -> c_int;
     pub fn oi_index_set_bm25_mode(idx: *mut OiIndex, mode: c_int) -> c_int;
     pub fn oi_index_set_max_query_terms(idx: *mut OiIndex, max_terms: u32) -> c_int;
 

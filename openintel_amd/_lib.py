@@ -85,6 +85,7 @@ SIGNATURES = {
     "oi_index_local_stats": (_I, [_P, C.POINTER(_U64), _P]),
     "oi_index_set_max_query_terms": (_I, [_P, _U32]),
     "oi_index_set_bm25_mode": (_I, [_P, _I]),
+    "oi_index_long_rows": (_I, [_P, C.POINTER(C.c_uint32)]),
     "oi_index_finalize": (_I, [_P, _U64, _U64, _P]),
     "oi_search_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P, _P, _P, _P, _P, _P]),
     "oi_search_lists_packed": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P]),

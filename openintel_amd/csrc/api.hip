@@ -781,6 +781,7 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     alias(v->max_row_norm, src->max_row_norm); alias(v->screen_copy, src->screen_copy);
     alias(v->uniq_keys, src->uniq_keys); alias(v->tf, src->tf); alias(v->doc_len, src->doc_len); alias(v->df_local, src->df_local);
     alias(v->postings, src->postings); alias(v->cell_start, src->cell_start); alias(v->idf, src->idf);
+    v->n_long = src->n_long; alias(v->long_list, src->long_list); alias(v->long_bitmap, src->long_bitmap);
     alias(v->fwd_terms, src->fwd_terms); alias(v->fwd_offsets, src->fwd_offsets);
     *out = v;
     return OI_OK;
@@ -846,13 +847,39 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
     if (normalize) OI_CHECK(oi_launch_l2_normalize(ctx, idx->rows, idx->n_docs, idx->dim));
     // the bf16 screen's error bound needs max |row| and max |bf16(row) - row| (cosine_prefilter.hip): one more pass
     // over the rows, now
-    OI_CHECK(idx->max_row_norm.ensure(16));
+    OI_CHECK(idx->max_row_norm.ensure(64));
     OI_CHECK(oi_launch_row_norm_max(ctx, idx->rows, idx->n_docs, idx->dim, idx->max_row_norm.as<uint32_t>()));
     OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    idx->n_long = 0;
+    idx->long_list.release(); idx->long_bitmap.release();
     {   // a corpus whose largest norm is not finite, or so large that bf16 products could overflow, is never screened
-        float mx[2] = {0.f, 0.f}; // X = max |row|, E = max |bf16(row) - row|
-        OI_HIP_CHECK(hipMemcpy(mx, idx->max_row_norm.p, 8, hipMemcpyDeviceToHost));
-        idx->screen_ok = mx[0] < 1.0e15f && mx[1] < 1.0e15f; // false for NaN
+        struct { float X, E; double sx2, se2; } mx = {0.f, 0.f, 0.0, 0.0}; // X = max |row|, E = max |bf16(row) - row|, sums of squares
+        OI_HIP_CHECK(hipMemcpy(&mx, idx->max_row_norm.p, 24, hipMemcpyDeviceToHost));
+        idx->screen_ok = mx.X < 1.0e15f && mx.E < 1.0e15f; // false for NaN
+        // Two classes (cosine_prefilter.hip): when the largest norms stand out from the corpus (> 1.5 x the RMS) and the rows
+        // responsible are few, they are set aside -- always rescored, never part of the screen's thresholds -- and the margin
+        // is built from the maxima over the REST.  A normalised corpus never gets here (no second pass over the rows).
+        const uint64_t n = idx->n_docs;
+        if (idx->screen_ok && n > 4 * OI_LONG_ROWS_MAX) {
+            const float X0 = 1.5f * (float)std::sqrt(mx.sx2 / (double)n), E0 = 1.5f * (float)std::sqrt(mx.se2 / (double)n);
+            if ((mx.X > X0 || mx.E > E0) && X0 > 0.f && E0 > 0.f) {
+                DevBuf cls;
+                OI_CHECK(cls.ensure(16));
+                OI_CHECK(idx->long_list.ensure(sizeof(uint32_t) * OI_LONG_ROWS_MAX));
+                OI_CHECK(idx->long_bitmap.ensure(((n + 31) / 32) * 4));
+                OI_CHECK(oi_launch_row_norm_classes(ctx, idx->rows, n, idx->dim, X0, E0, cls.as<uint32_t>(), idx->long_bitmap.as<uint32_t>(),
+                                                    idx->long_list.as<uint32_t>(), OI_LONG_ROWS_MAX));
+                uint32_t h[4] = {0, 0, 0, 0};
+                OI_HIP_CHECK(hipMemcpyAsync(h, cls.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                if (h[2] >= 1 && h[2] <= OI_LONG_ROWS_MAX) {
+                    idx->n_long = h[2];
+                    OI_HIP_CHECK(hipMemcpy(idx->max_row_norm.p, h, 8, hipMemcpyHostToDevice)); // the maxima over the other rows
+                } else {
+                    idx->long_list.release(); idx->long_bitmap.release(); // too many to set aside: one class, the corpus maxima
+                }
+            }
+        }
     }
     return OI_OK;
 }
@@ -913,6 +940,12 @@ extern "C" int oi_index_set_max_query_terms(oi_index *idx, uint32_t max_terms) {
     OI_REQUIRE(max_terms >= 1 && max_terms <= 1024, "max_query_terms=%u outside [1,1024]", max_terms);
     std::lock_guard<std::mutex> g(idx->ctx->mu);
     idx->max_query_terms = max_terms;
+    return OI_OK;
+}
+
+extern "C" int oi_index_long_rows(oi_index *idx, uint32_t *n_out) {
+    if (!idx || !n_out) { oi_set_error("null argument"); return OI_ERR_INVALID_ARG; }
+    *n_out = idx->n_long;
     return OI_OK;
 }
 
@@ -1297,7 +1330,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             DevBuf &pk = ctx->buf("pool_cos"), &rk = ctx->buf("screen_rescored"), &qb = ctx->buf("screen_q_bf16");
             OI_REQUIRE(words <= screen_words, "search: screen state does not fit its reservation");
             OI_REQUIRE(pk.cap >= sizeof(uint64_t) * (size_t)B * pf_stride, "search: the shared cosine pool is too small for the screen's view");
-            OI_CHECK(rk.ensure(sizeof(uint64_t) * (size_t)B * pf_carry));
+            const uint32_t rs_cap = pf_carry + OI_LONG_ROWS_MAX; // the survivors and the index's long rows (two-class margin)
+            OI_CHECK(rk.ensure(sizeof(uint64_t) * (size_t)B * rs_cap));
             const uint32_t n_padded = (B + 31u) & ~31u;
             OI_CHECK(qb.ensure(sizeof(uint16_t) * (size_t)(n_padded + 64) * idx->dim));
             uint32_t *w = screen_state; // zeroed with the pool state (prepare_pools)
@@ -1305,13 +1339,14 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             float *eps2 = reinterpret_cast<float *>(w + 3 * (size_t)B);
             uint32_t *gate = w + 4 * (size_t)B, *pf_seg = gate + 4;
             PoolView PF{pk.as<uint64_t>(), pf_cnt, pf_seg, pf_tau, pf_stride, pf_carry, 0, 0, segs, P.cos.overflow};
-            PoolView RS{rk.as<uint64_t>(), rs_cnt, pf_seg, nullptr, pf_carry, pf_carry, 0, 0, segs, P.cos.overflow};
+            PoolView RS{rk.as<uint64_t>(), rs_cnt, pf_seg, nullptr, rs_cap, rs_cap, 0, 0, segs, P.cos.overflow};
             OI_CHECK(oi_launch_screen_stage(ctx, d_qv, B, idx->dim, idx->max_row_norm.as<uint32_t>(), qb.as<uint16_t>(),
                                             eps2, gate));
             const uint64_t pf_max_chunk = pf_stride - pf_carry - pf_slack;
             SelectExtra mx;
             mx.eps2 = eps2;
             mx.margin_gate = gate;
+            if (idx->n_long) { mx.skip_bitmap = idx->long_bitmap.as<uint32_t>(); mx.skip_base = idx->doc_id_base; }
             if (want_copy && !idx->screen_copy.p) { // made once, on the first search that asks for it (n x d x 2 B of HBM)
                 OI_CHECK(idx->screen_copy.ensure(sizeof(uint16_t) * (size_t)n * idx->dim + 64));
                 OI_CHECK(oi_launch_make_screen_copy(ctx, idx->rows, n, idx->dim, idx->screen_copy.as<uint16_t>()));
@@ -1329,7 +1364,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 r = e;
                 chunk *= oi_chunk_growth(B);
             }
-            OI_CHECK(oi_launch_rescore(ctx, idx->rows, n, idx->dim, idx->doc_id_base, d_qv, B, PF, RS));
+            OI_CHECK(oi_launch_rescore(ctx, idx->rows, n, idx->dim, idx->doc_id_base, d_qv, B, PF, RS,
+                                       idx->n_long ? idx->long_list.as<uint32_t>() : nullptr, idx->n_long));
             RS.n_segs = 0;
             OI_CHECK(oi_launch_select(ctx, RS, B, depth, false, cos_s, cos_d, cos_c, depth));
             ctx->run_gate = gate;

@@ -260,9 +260,11 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
 // atomicMax on the bits orders them; a NaN has the largest bits and poisons the maximum on purpose -- the bound
 // does not hold for such a corpus).  The conversion is the screen's own (pf_pack -> v_cvt_pk_bf16_f32), so
 // whatever it does to a value (round to nearest even, a flushed denormal) is what E measures.
-//   out[0] = bits(X), out[1] = bits(E)
+//   out[0] = bits(X), out[1] = bits(E); (double) out[2..3] = sum_r |x_r|^2, out[4..5] = sum_r |bf16(x_r) - x_r|^2 (the RMS
+//   norms the two-class margin is cut at, oi_launch_row_norm_classes)
 __global__ __launch_bounds__(256) void pf_row_norm_max_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim,
                                                               uint32_t *out) {
+    double sum_x2 = 0.0, sum_e2 = 0.0;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -286,10 +288,60 @@ __global__ __launch_bounds__(256) void pf_row_norm_max_kernel(const float *__res
         bad = bad || !(nm == nm) || !(ne == ne);
         best = nm > best ? nm : best;
         best_e = ne > best_e ? ne : best_e;
+        sum_x2 += (double)ss;
+        sum_e2 += (double)se;
     }
     if (lane == 0) {
         atomicMax(out, bad ? 0x7FC00000u : __float_as_uint(best));
         atomicMax(out + 1, bad ? 0x7FC00000u : __float_as_uint(best_e));
+        atomicAdd(reinterpret_cast<double *>(out + 2), sum_x2);
+        atomicAdd(reinterpret_cast<double *>(out + 4), sum_e2);
+    }
+}
+
+// Two classes of rows (round 4).  The margin above uses the LARGEST |x_r| and |bf16(x_r) - x_r| of the
+// corpus, so a handful of long rows widened every query's margin until the survivors no longer fitted and the exact kernel
+// took over.  Rows with |x_r| > X0 or error norm > E0 (1.5 x the corpus RMS of each, api.hip) are LONG: listed (at most
+// `cap`), marked in a bitmap, left out of the screen's threshold logic by the margin selects (select.hip: skip_bitmap) and
+// rescored exactly for every query (pf_rescore_kernel: extra_docs).  The margin is then built from the maxima over the
+// other rows, which this kernel takes in the same pass.
+//   cls[0] = bits(max |x_r|) and cls[1] = bits(max error norm) over the rows that are NOT long, cls[2] = long rows found
+__global__ __launch_bounds__(256) void pf_row_norm_class_kernel(const float *__restrict__ rows, uint64_t n, uint32_t dim, float X0,
+                                                                float E0, uint32_t *cls, uint32_t *bitmap, uint32_t *list,
+                                                                uint32_t cap) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t nvec = dim >> 2;
+    float best = 0.f, best_e = 0.f;
+    for (uint64_t r = wave; r < n; r += n_waves) {
+        const float4 *x = reinterpret_cast<const float4 *>(rows + r * dim);
+        float ss = 0.f, se = 0.f;
+        for (uint32_t v = lane; v < nvec; v += 64) {
+            const float4 a = x[v];
+            ss = fmaf(a.x, a.x, ss); ss = fmaf(a.y, a.y, ss); ss = fmaf(a.z, a.z, ss); ss = fmaf(a.w, a.w, ss);
+            const pf_f32x4 f = {a.x, a.y, a.z, a.w};
+            const pf_bf16x8 b = pf_pack(f, f);
+            const float e0 = (float)b[0] - a.x, e1 = (float)b[1] - a.y, e2 = (float)b[2] - a.z, e3 = (float)b[3] - a.w;
+            se = fmaf(e0, e0, se); se = fmaf(e1, e1, se); se = fmaf(e2, e2, se); se = fmaf(e3, e3, se);
+        }
+        ss = oi_wave_sum(ss);
+        se = oi_wave_sum(se);
+        const float nm = sqrtf(ss), ne = sqrtf(se);
+        if (nm > X0 || ne > E0) { // (the same sums in the same order as the pass that set X0 and E0: the same values)
+            if (lane == 0) {
+                const uint32_t pos = atomicAdd(cls + 2, 1u);
+                if (pos < cap) list[pos] = (uint32_t)r;
+                atomicOr(bitmap + (r >> 5), 1u << (r & 31));
+            }
+        } else {
+            best = nm > best ? nm : best;
+            best_e = ne > best_e ? ne : best_e;
+        }
+    }
+    if (lane == 0) {
+        atomicMax(cls, __float_as_uint(best));
+        atomicMax(cls + 1, __float_as_uint(best_e));
     }
 }
 
@@ -405,11 +457,15 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
                                                          uint64_t n_rows, const float *__restrict__ queries,
                                                          const uint64_t *__restrict__ in_pools, const uint32_t *__restrict__ in_cnt,
                                                          uint64_t in_stride, uint32_t cap, uint64_t *out_pools,
-                                                         uint32_t *out_cnt, uint64_t out_stride) {
+                                                         uint32_t *out_cnt, uint64_t out_stride,
+                                                         const uint32_t *__restrict__ extra_docs, uint32_t n_extra) {
+    // extra_docs: the index's LONG rows (local row numbers, pf_row_norm_class_kernel) -- scored for every query after its
+    // survivors, whatever the screen made of them
     const uint32_t q = blockIdx.y, lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t c = in_cnt[q];
-    c = c < cap ? c : cap;
+    uint32_t c0 = in_cnt[q];
+    c0 = c0 < cap ? c0 : cap;
+    const uint32_t c = c0 + n_extra;
     const uint32_t nvec = dim >> 2;
     const float4 *qv = reinterpret_cast<const float4 *>(queries + (uint64_t)q * dim);
     // four survivors per wave and trip: their rows' loads are all in flight before the first reduction (one row at a
@@ -421,7 +477,7 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + u < c ? i0 + u : c - 1u; // (past the end: the last survivor again, not written)
-            doc[u] = oi_rank_key_doc(in_pools[(uint64_t)q * in_stride + i]);
+            doc[u] = i < c0 ? oi_rank_key_doc(in_pools[(uint64_t)q * in_stride + i]) : doc_id_base + extra_docs[i - c0];
             const uint64_t r = (uint64_t)(doc[u] - doc_id_base);
             x[u] = reinterpret_cast<const float4 *>(rows + (r < n_rows ? r : 0) * dim);
             a[u] = 0.f;
@@ -467,8 +523,21 @@ void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_s
     *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * PF_TILE_ROWS;
 }
 
+int oi_launch_row_norm_classes(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, float X0, float E0, uint32_t *cls,
+                               uint32_t *bitmap, uint32_t *list, uint32_t cap) {
+    OI_HIP_CHECK(hipMemsetAsync(cls, 0, 16, ctx->stream));
+    OI_HIP_CHECK(hipMemsetAsync(bitmap, 0, ((n + 31) / 32) * 4, ctx->stream));
+    uint64_t blocks = (n + 3) / 4;
+    const uint64_t capb = (uint64_t)ctx->num_cus * 8;
+    if (blocks > capb) blocks = capb;
+    hipLaunchKernelGGL(pf_row_norm_class_kernel, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, n, dim, X0, E0, cls, bitmap,
+                       list, cap);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 int oi_launch_row_norm_max(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint32_t *max_bits) {
-    OI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 8, ctx->stream)); // [0] = X, [1] = E
+    OI_HIP_CHECK(hipMemsetAsync(max_bits, 0, 24, ctx->stream)); // [0] = X, [1] = E, [2..5] = the two sums of squares (double)
     if (n == 0) return OI_OK;
     uint64_t blocks = (n + 3) / 4;
     const uint64_t cap = (uint64_t)ctx->num_cus * 8;
@@ -533,12 +602,14 @@ int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_b
 
 // Exact scores of the screen's survivors: in.carry region (in.carry_cnt keys per query) -> out.carry region.
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
-                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out) {
+                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out,
+                      const uint32_t *extra_docs, uint32_t n_extra) {
     if (n_queries == 0) return OI_OK;
-    OI_REQUIRE(out.carry_cap >= in.carry_cap, "rescore: output pool too small");
+    OI_REQUIRE(out.carry_cap >= in.carry_cap + n_extra, "rescore: output pool too small");
     ProfScope ps(ctx, "rescore");
     hipLaunchKernelGGL(pf_rescore_kernel, dim3(64, n_queries), dim3(256), 0, ctx->stream, rows, dim, doc_id_base, n_rows,
-                       d_queries, in.keys, in.carry_cnt, in.stride, in.carry_cap, out.keys, out.carry_cnt, out.stride);
+                       d_queries, in.keys, in.carry_cnt, in.stride, in.carry_cap, out.keys, out.carry_cnt, out.stride, extra_docs,
+                       n_extra);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

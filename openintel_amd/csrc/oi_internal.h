@@ -173,6 +173,10 @@ struct oi_index {
     DevBuf max_row_norm; // u32[2]: bits of X = max_r |row r| and E = max_r |bf16(row r) - row r| (f32), taken when the f32 rows
                          // are set; NaN if any norm is
     bool screen_ok = false; // those maxima are finite and < 1e15: the bf16 screen's bound holds for this corpus
+    // Two classes of rows (cosine_prefilter.hip): n_long > 0 = the maxima above are those of the rows that are NOT long; the
+    // long ones are listed (local row numbers), marked in a bitmap, skipped by the margin selects and always rescored
+    uint32_t n_long = 0;
+    DevBuf long_list, long_bitmap;
     DevBuf screen_copy;     // OI_COSINE_SCREEN_COPY: bf16(rows), made on first use (n_docs x dim x 2 B); empty otherwise
 
     // staged forward index (between set_forward and finalize)
@@ -249,6 +253,8 @@ struct SelectExtra {
     const float *eps2 = nullptr;
     uint32_t *margin_gate = nullptr;
     const uint32_t *run_gate = nullptr;
+    const uint32_t *skip_bitmap = nullptr; // margin mode: keys of docs whose bit (doc - skip_base) is set are left out of the selection
+    uint32_t skip_base = 0;
 };
 int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t k, bool compact,
                      float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride,
@@ -293,7 +299,11 @@ int oi_launch_make_screen_copy(oi_ctx *ctx, const float *rows, uint64_t n, uint3
 int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
                            const uint16_t *q_bf16, uint32_t n_queries, float *d_out);
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
-                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out);
+                      const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out,
+                      const uint32_t *extra_docs = nullptr, uint32_t n_extra = 0);
+#define OI_LONG_ROWS_MAX 1024u // rows the two-class margin may set aside (more: one class, the corpus maxima, as before)
+int oi_launch_row_norm_classes(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, float X0, float E0, uint32_t *cls,
+                               uint32_t *bitmap, uint32_t *list, uint32_t cap);
 int oi_launch_cosine_ksplit(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                             const float *q, uint32_t nq, bool two_tiles, uint32_t doc_id_base, const PoolView &p);
 // bm25.hip

@@ -353,7 +353,13 @@ __device__ __forceinline__ void sel_threshold(FE &&for_each, uint32_t kk_in, Sel
 template <int KPT>
 __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k, SelShared &sh, uint64_t *sel,
                                                     uint64_t *cand, float eps2, bool *in_cand, uint32_t *margin_tau,
-                                                    bool *margin_overflow) {
+                                                    bool *margin_overflow, const uint32_t *skip, uint32_t skip_base) {
+    // skip (the screen's two-class margin): keys of docs marked in this bitmap do not take part -- they are scored exactly
+    // whatever happens here, and their screen scores must not move the threshold (cosine_prefilter.hip)
+    auto skipped = [&](uint64_t kv) -> bool {
+        const uint32_t d = oi_rank_key_doc(kv) - skip_base;
+        return (skip[d >> 5] >> (d & 31u)) & 1u;
+    };
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = K.n;
     *in_cand = false;
     *margin_overflow = false;
@@ -362,6 +368,7 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
     const uint32_t first = wv * kpt * 64 + lane, last = n - 1;
     constexpr int NR = KPT > 0 ? KPT : 1;
     uint64_t key[NR];
+    uint32_t dead = 0; // bit j: key[j] is a skipped doc's
     if constexpr (KPT > 0) {
         SelCursor cur = sel_seek(K, first < n ? first : last);
         uint64_t at = sel_at(K, cur, first < n ? first : last);
@@ -371,12 +378,17 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
             if ((uint32_t)j < kpt && i < n) at = sel_at(K, cur, i); // the cursor only walks forward
             key[j] = K.pool[at];
         }
+        if (skip) {
+#pragma unroll
+            for (int j = 0; j < KPT; ++j)
+                if ((uint32_t)j < kpt && first + (uint32_t)j * 64 < n && skipped(key[j])) dead |= 1u << j;
+        }
     }
     auto for_each = [&](auto &&f) {
         if constexpr (KPT > 0) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j)
-                if ((uint32_t)j < kpt) f(first + (uint32_t)j * 64 < n, key[j]); // uniform guard
+                if ((uint32_t)j < kpt) f(first + (uint32_t)j * 64 < n && !((dead >> j) & 1u), key[j]); // uniform guard
         } else {
             SelCursor cur = sel_seek(K, first < n ? first : last);
             uint64_t at = sel_at(K, cur, first < n ? first : last);
@@ -391,14 +403,14 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
                     kx[u] = K.pool[at];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) f(ok[u], kx[u]);
+                for (int u = 0; u < 4; ++u) f(ok[u] && !(skip && skipped(kx[u])), kx[u]);
             }
         }
     };
     if (n <= k) {
         for_each([&](bool valid, uint64_t kv) { sel_append(sel, &sh.cnt, 2 * SEL_MAX, valid, kv); });
         __syncthreads();
-        return n;
+        return skip ? sh.cnt : n; // (skipped keys were not appended)
     }
     int shift;
     uint64_t prefix;
@@ -406,15 +418,17 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
     if (KPT != 4 && n > SEL_CAND) {
         // ---- cut the pool down with a sampled threshold: one key per thread, spread over the wave's range
         const uint32_t js = lane % kpt, is = first + js * 64;
-        const bool sv = is < n;
+        bool sv = is < n;
         uint64_t sk;
         if constexpr (KPT > 0) {
             sk = key[0];
 #pragma unroll
             for (int j = 1; j < KPT; ++j) sk = (uint32_t)j == js ? key[j] : sk;
+            sv = sv && !((dead >> js) & 1u);
         } else {
             SelCursor cur = sel_seek(K, sv ? is : last);
             sk = K.pool[sel_at(K, cur, sv ? is : last)];
+            sv = sv && !(skip && skipped(sk));
         }
         if (tid == 0) sh.n_samples = 0;
         __syncthreads();
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
     uint64_t *pools, uint32_t *carry_cnt, uint32_t *seg_cnt, uint32_t *tau_keys, uint64_t pool_stride,
     uint32_t carry_cap, uint32_t seg_cap, uint32_t n_segs, uint32_t seg_cnt_stride, uint32_t *overflow,
     uint32_t k, int compact, float *out_scores, uint32_t *out_docs, uint32_t *out_counts, uint32_t out_stride,
-    const float *eps2, uint32_t *margin_gate, const uint32_t *run_gate) {
+    const float *eps2, uint32_t *margin_gate, const uint32_t *run_gate, const uint32_t *skip, uint32_t skip_base) {
     // run_gate: this launch belongs to the gated exact pipeline (cosine_prefilter.hip) and only runs when the
     // screen gave up.  eps2: margin mode (see sel_flat_select); its overflow opens that gate.
     if (run_gate && *run_gate == 0u) return;
@@ -550,11 +564,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
     uint32_t m, m_tau = 0;
     bool in_cand = false, m_over = false;
     const float e2 = eps2 ? eps2[q] : -1.f;
-    if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
-    else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
-    else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
-    else if (K.n <= SEL_KPT_MAX * SEL_THREADS) m = sel_flat_select<SEL_KPT_MAX>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
-    else m = sel_flat_select<0>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over);
+    if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
+    else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
+    else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
+    else if (K.n <= SEL_KPT_MAX * SEL_THREADS) m = sel_flat_select<SEL_KPT_MAX>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
+    else m = sel_flat_select<0>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
     if (in_cand) { // margin mode: an unsorted superset of the top k in cand[]; only ever compacted
         if (m_over && tid == 0 && margin_gate) *margin_gate = 1u;
         for (uint32_t i = tid; i < m; i += SEL_THREADS) pool[i] = cand[i];
@@ -623,7 +637,8 @@ int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint
                            pool.carry_cnt, pool.seg_cnt, pool.tau_keys, pool.stride, pool.carry_cap, pool.seg_cap,
                            pool.n_segs, pool.seg_cnt_stride, pool.overflow, k, compact ? 1 : 0, out_scores, out_docs,
                            out_counts, out_stride, extra ? extra->eps2 : nullptr, extra ? extra->margin_gate : nullptr,
-                           extra ? extra->run_gate : nullptr);
+                           extra ? extra->run_gate : nullptr, extra && extra->eps2 ? extra->skip_bitmap : nullptr,
+                           extra ? extra->skip_base : 0u);
         OI_HIP_CHECK(hipGetLastError());
         return OI_OK;
     }

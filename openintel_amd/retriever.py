@@ -131,6 +131,12 @@ class HybridIndex(PostRetriever):
             loc = _lib.OI_HOST
         _lib.check(self.lib.oi_index_set_forward(self.handle, _lib.ptr(term_ids), _lib.ptr(doc_offsets), loc))
 
+    def long_rows(self) -> int:
+        """Rows the screened cosine scorer sets aside (always rescored, never part of its thresholds): oi_index_long_rows."""
+        n = C.c_uint32()
+        _lib.check(self.lib.oi_index_long_rows(self.handle, C.byref(n)))
+        return int(n.value)
+
     BM25_DEFAULT, BM25_TAAT, BM25_SCAN, BM25_WAVE, BM25_STREAM = 0, 1, 2, 3, 4
 
     def set_bm25_mode(self, mode: int) -> None:

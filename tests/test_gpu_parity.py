@@ -937,12 +937,12 @@ def test_index_view_and_pipeline_lanes(ctx, O):
     # the pipeline with a second lane
     fctx, lctx = oi.HipContext(0), oi.HipContext(0)
     pipe = sharded.ShardedPipeline(sr, fctx, B, depth, k, lane_ctxs=[lctx])
-    assert pipe.n_slots == 4 and len(pipe.lanes) == 2
+    assert pipe.n_slots == 6 and len(pipe.lanes) == 2
     outs = []
     for rep in range(2):
         for qv, qt, qo in batches:
             slot = pipe.submit(qv, qt, qo)
-            with torch.cuda.stream(pipe.side):   # a slot is reused four submits later: copy out behind the fusion
+            with torch.cuda.stream(pipe.side):   # a slot is reused n_slots submits later: copy out behind the fusion
                 r = pipe.results[slot]
                 outs.append((r.scores.clone(), r.docs.clone(), r.counts.clone()))
     pipe.drain()
