@@ -13,6 +13,8 @@ if [ -z "$PMC_ONLY" ]; then
 python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err && echo "bench ok"
 OI_BENCH_FORCE_DIST=1 python3 $R/bench.py --gpus 1 --docs 1250000 --steps 200 --warmup 20 --no-cpu-baseline --no-screen-copy > $OUT/rccl_world1_shard.json 2> $OUT/rccl_world1.err && echo "rccl world1 ok"
 OI_BENCH_BACKEND=gloo OI_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --docs 2500000 --steps 100 --warmup 10 --no-cpu-baseline --no-screen-copy > $OUT/launcher_gloo2.json 2> $OUT/launcher_gloo2.err && echo "gloo2 ok"
+# (four ranks sharing the card: the box admits six GPU processes and counted five ranks + their launcher as seven, round 4)
+OI_BENCH_BACKEND=gloo OI_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 4 --docs 1600000 --steps 50 --warmup 10 --no-cpu-baseline --no-screen-copy > $OUT/launcher_gloo4.json 2> $OUT/launcher_gloo4.err && echo "gloo4 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --latency-batches 1 --latency-warmup 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
 python3 $R/bench.py --cosine exact --steps 10 --no-cpu-baseline > $OUT/bench_exact.json 2> $OUT/bench_exact.err && echo "exact ok"
 python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
@@ -22,6 +24,8 @@ python3 $R/tools/headline_bench.py 10000000 10 > $OUT/headline_bench.json 2> $OU
 python3 $R/tools/lexicon_bench.py 10000000 10 > $OUT/lexicon_bench.json 2> $OUT/lexicon_bench.err && echo "lexicon ok"
 python3 $R/tools/bm25_bench.py 10000000 10 > $OUT/bm25_bench.json 2> $OUT/bm25_bench.err && echo "bm25 ok"
 python3 $R/tools/bm25_bench.py 10000000 5 256 > $OUT/bm25_bench_b256.json 2> $OUT/bm25_bench_b256.err && echo "bm25 b256 ok"
+python3 $R/tools/bm25_bench.py 1250000 20 64 > $OUT/bm25_bench_shard.json 2> $OUT/bm25_bench_shard.err && echo "bm25 shard ok"
+bash $R/tools/pmc_bm25_stream.sh $T/pmc_bm25_stream 10000000 > $OUT/pmc_bm25_stream.txt 2>&1 && echo "pmc bm25 stream ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -- python3 $R/tools/headline_bench.py 10000000 5 > /dev/null 2> $OUT/stats_headline.err && echo "stats headline ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bm25 -- python3 $R/tools/bm25_bench.py 10000000 3 > /dev/null 2> $OUT/stats_bm25.err && echo "stats bm25 ok"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_lexicon -- python3 $R/tools/lexicon_bench.py 10000000 5 > /dev/null 2> $OUT/stats_lexicon.err && echo "stats lexicon ok"
