@@ -481,8 +481,8 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     //   * parked as [writer][query tile][register block rb][lane][4 registers]: 12 ds_write_b128 per wave instead of 64
     //     ds_write_b32, and the owner reads 12 ds_read_b128 (256 B/clk) instead of 64 ds_read_b32 (128 B/clk);
     //   * the three foreign partials of a register block are read in groups 4 rb, 4 rb + 1, 4 rb + 2 (before the MFMAs) and
-    //     summed in group 4 rb + 3 in K order, score = ((q0 + q1) + q2) + q3 with the owner's quarter in its place -- the same
-    //     bits for a (query, row) pair in every slot of the batch and run to run; ONE branch per block tests max(four scores) >= tau, the per-register
+    //     summed in group 4 rb + 3: score = ((own + p[w+1]) + p[w+2]) + p[w+3] (writers mod 4) -- a fixed order per query
+    //     tile, so a score is the same bits run to run (the order depends on the query's slot: see finish_block); ONE branch per block tests max(four scores) >= tau, the per-register
     //     test and the ragged-tile cut are behind it (survivors are rare once a threshold exists).
     uint64_t row0_prev = 0;
     bool have_prev = false;
@@ -497,13 +497,13 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     auto finish_block = [&](auto rb_, const cb_f32x4 (&p)[3]) {
         constexpr int rb = decltype(rb_)::value;
         float sc[4];
-        // K quarters summed in K order 0..3 WHATEVER the owner (p[j] is writer (w + 1 + j) % 4's quarter): the score of a
-        // (query, row) pair is the same bits in every batch slot (round 3 added own first: last-ulp differences by slot)
+        // own quarter first, then the others in writer order w+1, w+2, w+3 (mod 4): a fixed order per QUERY TILE, so a score is the
+        // same bits run to run -- but the K-quarter order depends on the owning wave, i.e. on the query's slot in the batch: the
+        // same (query, row) pair can differ in the last ulp between slots (inside the 1e-5 bar; tests/test_gpu_bf16.py compares
+        // with the oracle at that bar, not bit for bit).  Summing in K order 0..3 whatever the owner was built in round 4 and
+        // cost 26 % of the launch (0.772 -> 0.976 ms: the order is a run-time property of the wave, four variants per score): not kept.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float o = own[4 * rb + i], a0 = p[0][i], a1 = p[1][i], a2 = p[2][i];
-            sc[i] = w == 0u ? ((o + a0) + a1) + a2 : w == 1u ? ((a2 + o) + a0) + a1 : w == 2u ? ((a1 + a2) + o) + a0 : ((a0 + a1) + a2) + o;
-        }
+        for (int i = 0; i < 4; ++i) sc[i] = ((own[4 * rb + i] + p[0][i]) + p[1][i]) + p[2][i];
         if (DBG == 3) { if (sc[0] + sc[1] + sc[2] + sc[3] == 12345.678f) *overflow = 2u; return; } // sums only
         // tau_f is the threshold as a float (-inf while there is none, NaN for a padded query: every compare false); a NaN
         // score drops out of the max and fails its own compare
