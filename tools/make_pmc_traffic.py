@@ -15,7 +15,7 @@ ALG = 10_000_000 * 768 * 4
 sc = d["cosine_screen"]
 out = {
     "source": "profiles/%s_pmc_summary.json (tools/pmc_profile.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes over "
-              "bench.py --steps 3 --warmup 1, default scorer; round 3)" % tag,
+              "bench.py --steps 3 --warmup 1 --latency-batches 1 --latency-warmup 0, default scorer; collected on the round's code: the tag says which)" % tag,
     "correction": "HBM read bytes = FETCH_SIZE*1024*2 (gfx950 tallies 128-B requests at 64 B on wide coalesced streams, "
                   "MI355X_MICROARCH.md section HBM); write bytes = WRITE_SIZE*1024",
     "kernel": "cosine_screen_filter<768,2>",
@@ -34,6 +34,17 @@ if bw:
         "lds_bank_conflict_cycles_frac": bw.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, bw.get("SQ_LDS_IDX_ACTIVE", 1.0)),
         "waves_waiting_frac": bw.get("SQ_WAIT_ANY", 0.0) / max(1.0, bw.get("SQ_WAVE_CYCLES", 1.0)),
         "note": "narrow (8-B per lane) loads: the FETCH_SIZE x2 correction is calibrated for 16-B-per-lane streams only; read as an upper bound"}
+for name, key in (("bm25_stream_kernel", "bm25_stream"), ("select_flat_kernel", "select_flat"), ("pf_rescore_kernel", "pf_rescore")):
+    k = d.get(key)
+    if k:
+        out[name] = {
+            "launches": k["launches"], "hbm_read_bytes_per_launch": k["hbm_read_bytes"] / k["launches"],
+            "hbm_write_bytes_per_launch": k.get("hbm_write_bytes", 0.0) / k["launches"],
+            "lds_bank_conflict_cycles_frac": k.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, k.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+            "waves_waiting_frac": k.get("SQ_WAIT_ANY", 0.0) / max(1.0, k.get("SQ_WAVE_CYCLES", 1.0))}
+if "bm25_stream_kernel" in out:
+    out["bm25_stream_kernel"]["note"] = ("two launches per batch; the postings are read twice, the second time from L2 (the reads above are HBM: "
+                                         "the algorithmic bytes once); the writes are the emitted candidate keys")
 ex = x["cosine_ksplit"]
 out["exact_kernel"] = {
     "kernel": "cosine_ksplit16_filter<768,2>",
@@ -47,6 +58,6 @@ out["exact_kernel"] = {
     "cosine_lds_bank_conflict_cycles_frac": ex.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, ex.get("SQ_LDS_IDX_ACTIVE", 1.0)),
 }
 out["exact_kernel_source"] = ("profiles/%s_exact_pmc_summary.json (the same passes over bench.py --cosine exact --steps 3 --warmup 1; "
-                              "round 3, the kernel with non-temporal loads)" % tag)
+                              "the kernel with non-temporal loads)" % tag)
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
