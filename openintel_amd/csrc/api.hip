@@ -1248,14 +1248,43 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         }
         return OI_OK;
     };
-    if (overlap) {
-        OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // pools are reset, queries staged
+    auto fork_bm25 = [&]() -> int {
         OI_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
         ctx->stream = ctx->side_stream;
         const int rc = bm25_leg();
         ctx->stream = st;
         if (rc != OI_OK) { (void)hipStreamSynchronize(ctx->side_stream); return rc; } // nothing of this call stays in flight
         OI_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->side_stream));
+        return OI_OK;
+    };
+    // Round 4: beside the screen the BM25 leg starts with the LAST corpus chunk, not the first.  The screen's persistent
+    // workgroups leave 1/8 of the CUs free; the BM25 kernels (enqueued AFTER the last chunk's launch, so that the screen's
+    // workgroups are resident first) run there while the long chunk streams -- instead of sharing the CUs with the two short
+    // first chunks, whose launches they stretched (10M rows: step 4.998 -> 4.940 ms on one box, -44 .. -58 us on three;
+    // tools/r04_epilogue_probe.sh, r04_old_new_ab.sh).  Only when the last chunk is long enough to cover the leg: >= 512K rows.
+    // OI_BM25_EARLY=1 (A/B): the round-3 placement.
+    static const bool early_env = oi_ablation_env("OI_BM25_EARLY") != nullptr;
+    bool late_pending = false;
+    if (overlap) {
+        bool late = false;
+        if (!early_env && !idx->rows_bf16 && idx->rows && ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && idx->screen_ok &&
+            oi_cosine_screen_supported(idx->dim) && pf_stride > pf_carry + pf_slack) {
+            const uint64_t mc = pf_stride - pf_carry - pf_slack; // the screen's own schedule (cosine_leg below), dry
+            uint64_t chunk = oi_first_chunk_rows(depth), r = 0, last = 0;
+            while (r < n) {
+                if (chunk > mc) chunk = mc;
+                const uint64_t e = oi_chunk_end(r, chunk, n, mc, chunk * oi_chunk_growth(B));
+                last = e - r;
+                r = e;
+                chunk *= oi_chunk_growth(B);
+            }
+            late = last >= (512u << 10);
+        }
+        if (late) late_pending = true;
+        else {
+            OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // pools are reset, queries staged
+            OI_CHECK(fork_bm25());
+        }
     }
     // ---- cosine list
     auto cosine_leg = [&]() -> int {
@@ -1358,8 +1387,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, chunk * oi_chunk_growth(B));
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
+                if (late_pending && e == n) OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (before the last chunk's launch)
                 if (want_copy) OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, d_qv, B, idx->doc_id_base, PF));
                 else OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
+                if (late_pending && e == n) { late_pending = false; OI_CHECK(fork_bm25()); } // ... enqueued after it: the screen's workgroups get their CUs first
                 OI_CHECK(oi_launch_select(ctx, PF, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth, &mx));
                 r = e;
                 chunk *= oi_chunk_growth(B);
@@ -1382,6 +1413,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             if (overlap) (void)hipStreamSynchronize(ctx->side_stream);
             return rc;
         }
+    }
+    if (late_pending) { // (the screen was not taken after all)
+        OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st));
+        OI_CHECK(fork_bm25());
     }
     if (overlap) OI_HIP_CHECK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     else if (bm_s) OI_CHECK(bm25_leg());

@@ -109,6 +109,40 @@ __device__ __forceinline__ pf_bf16x8 pf_pack(const pf_f32x4 &a, const pf_f32x4 &
     return r;
 }
 
+// Survivor staging of the screen kernel: PF_STAGE entries per wave (a power of two), flushed PF_STAGE_FLUSH at a time.
+#define PF_STAGE 128
+#define PF_STAGE_FLUSH 64u
+#define PF_STAGE_LDS (4 * PF_STAGE * 12)
+__device__ __forceinline__ uint32_t pf_incl_scan(uint32_t v) { // wave-wide inclusive prefix sum (DPP, no LDS)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// The first NF staged entries of the wave leave for the pool: lane l takes entry st_head + l, its position in its query's
+// segment from ONE LDS atomic, one store instruction for all of them.  (A macro: a lambda would take st_head / st_n by
+// reference and hipcc then keeps them in scratch.)  The compiler barriers keep the staging writes of other lanes in front of
+// these reads, and these reads in front of the next tile's writes (LDS operations of a wave execute in order).
+#define PF_FLUSH(NF)                                                                                                   \
+    do {                                                                                                               \
+        const uint32_t nf_ = (NF);                                                                                     \
+        asm volatile("" ::: "memory");                                                                                 \
+        if (lane < nf_) {                                                                                              \
+            const uint32_t i_ = (st_head + lane) & (PF_STAGE - 1);                                                     \
+            const uint64_t key_ = stage_keys[i_];                                                                      \
+            const uint32_t q_ = stage_q[i_];                                                                           \
+            const uint32_t pos_ = atomicAdd(&seg_fill[q_], 1u);                                                        \
+            if (pos_ < seg_cap) my_seg[(uint64_t)q_ * pool_stride + pos_] = key_;                                      \
+            else *overflow = 1u;                                                                                       \
+        }                                                                                                              \
+        asm volatile("" ::: "memory");                                                                                 \
+        st_head = (st_head + nf_) & (PF_STAGE - 1);                                                                    \
+        st_n -= nf_;                                                                                                   \
+    } while (0)
+
 template <int D, int NQT>
 __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
     const float *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
@@ -124,11 +158,15 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char *ring = smem;                                                         // [4][NBUF][4 KiB]
-    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * PF_SLOT_BYTES); // [32*NQT]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * PF_SLOT_BYTES); // [64]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t li = lane & 31, lh = lane >> 5;
+    // the wave's staging ring of survivors (keys and their queries), behind seg_fill
+    uint64_t *stage_keys = reinterpret_cast<uint64_t *>(smem + 4 * NBUF * PF_SLOT_BYTES + 256) + w * PF_STAGE;
+    uint32_t *stage_q = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * PF_SLOT_BYTES + 256 + 4 * PF_STAGE * 8) + w * PF_STAGE;
+    uint32_t st_head = 0, st_n = 0; // wave-uniform: first staged entry (mod PF_STAGE), staged entries (< PF_STAGE_FLUSH between tiles)
 
     // ---- every query over the whole K, in registers for the whole launch: B[k = 16 s + 8 lh + 0..7][n = li]
     pf_bf16x8 qreg[NQT][KSTEPS];
@@ -137,11 +175,17 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
             qreg[t][s] = *reinterpret_cast<const pf_bf16x8 *>(queries + (uint64_t)(32 * t + li) * D + 16 * s + 8 * lh);
-    uint32_t tau[NQT]; // screen thresholds (tau~ - 2 eps, as orderable keys) of the queries this lane filters
+    // Screen thresholds (tau~ - 2 eps) of the queries this lane filters, as FLOATS: for a score s that is not a NaN,
+    // oi_f32_key(s) >= key  <=>  s >= oi_key_f32(key) (the key is strictly monotone on floats after s + 0 has made -0 a +0, and
+    // the comparison does not tell -0 from +0 either); keys at or below key(-inf) pass every such score (-inf), keys above
+    // key(+inf) -- 0xFFFFFFFF: no query in this slot -- map to NaN bit patterns, which no score is >=.  A NaN score fails the
+    // comparison by itself.  One v_cmp per score instead of the key's five instructions.
+    float tauf[NQT];
 #pragma unroll
     for (int t = 0; t < NQT; ++t) {
         const uint32_t q = 32u * t + li;
-        tau[t] = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+        const uint32_t k = q < n_queries ? tau_keys[q] : 0xFFFFFFFFu;
+        tauf[t] = k <= 0x007FFFFFu ? -__builtin_inff() : oi_key_f32(k);
     }
     if (tid < 32 * NQT) seg_fill[tid] = 0;
     __syncthreads(); // the only barrier before the end: seg_fill is zero before any wave appends
@@ -229,23 +273,72 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
 
             // ---- filter + append, straight out of the accumulators: register r of query tile t holds
             // D[row (r&3) + 8 (r>>2) + 4 lh][query 32 t + li]
+            // Round 4: which of the lane's 16 NQT scores pass is collected in a mask first (one compare each); a tile without
+            // a survivor -- most tiles of the large chunks -- leaves through one ballot, and a lane with survivors takes ONE
+            // LDS atomic per query for all of them.  (Round 3 took an atomic and waited for it per score: 200-350 wave
+            // cycles per survivor, 0.13 ms of the 4.9 ms step at 10M rows -- tools/r04_epilogue_probe.sh.)
             const uint64_t row0 = tile_row0(ti);
+            uint32_t m = 0;
 #pragma unroll
-            for (int t = 0; t < NQT; ++t) {
-                const uint32_t q = 32u * t + li;
+            for (int t = 0; t < NQT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float s = acc[t][r];
-                    if (row < row_end && s == s && oi_f32_key(s) >= tau[t]) {
-                        const uint32_t pos = atomicAdd(&seg_fill[q], 1u); // LDS
-                        if (pos < seg_cap) my_seg[(uint64_t)q * pool_stride + pos] = oi_rank_key(s, doc_id_base + (uint32_t)row);
-                        else *overflow = 1u;
+                for (int r = 0; r < 16; ++r) m |= acc[t][r] >= tauf[t] ? 1u << (16 * t + r) : 0u;
+            if (row_end - row0 < (uint64_t)PF_TILE_ROWS) { // the ragged last tile: rows past the end read as zeros
+                const uint32_t left = (uint32_t)(row_end - row0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * lh >= left) m &= ~(0x00010001u << r);
+            }
+            if (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+                const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+                const uint32_t incl = pf_incl_scan(cnt);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total <= PF_STAGE_FLUSH) {
+                    // SPARSE tile (every tile once a threshold stands): the survivors go to the wave's LDS staging ring, and
+                    // 64 of them leave with ONE store instruction.  A store per survivor sat in the same in-order vmcnt queue
+                    // as the DMA pieces: every counted wait then also waited for slots it did not need yet (the stores behind
+                    // them), 0.13 ms of the 4.9 ms step at 10M rows (tools/r04_epilogue_probe.sh).
+                    uint32_t idx = st_head + st_n + incl - cnt;
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (m & (1u << (16 * t + r))) {
+                                const uint32_t row = (uint32_t)row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                stage_keys[idx & (PF_STAGE - 1)] = oi_rank_key(acc[t][r], doc_id_base + row);
+                                stage_q[idx & (PF_STAGE - 1)] = 32u * t + li;
+                                ++idx;
+                            }
+                    st_n += total;
+                    if (st_n >= PF_STAGE_FLUSH) {
+                        PF_FLUSH(PF_STAGE_FLUSH);
+                    }
+                } else {
+                    // DENSE tile (the first chunk, scored without a threshold: every score passes): straight to the pool
+                    uint32_t pos[NQT];
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t) // (both atomics are in flight before the first is waited for; adding 0 is harmless)
+                        pos[t] = atomicAdd(&seg_fill[32u * t + li], (uint32_t)__builtin_popcount((m >> (16 * t)) & 0xFFFFu));
+#pragma unroll
+                    for (int t = 0; t < NQT; ++t) {
+                        uint64_t *dst = my_seg + (uint64_t)(32u * t + li) * pool_stride;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (m & (1u << (16 * t + r))) {
+                                const uint32_t row = (uint32_t)row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                if (pos[t] < seg_cap) dst[pos[t]] = oi_rank_key(acc[t][r], doc_id_base + row);
+                                else *overflow = 1u;
+                                ++pos[t];
+                            }
+                        }
                     }
                 }
             }
             cur = nxt;
             nxt = tile_srd(ti + 2);
+        }
+        if (st_n) {
+            PF_FLUSH(st_n);
         }
     }
     __syncthreads(); // every wave's appends are counted
@@ -518,7 +611,8 @@ void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_s
     // 192: 0.69-0.72, 160: 0.75, and from 176 down the single-stream time grows).  OI_SCREEN_CUS: A/B switch.
     static const char *cus_s = oi_ablation_env("OI_SCREEN_CUS");
     const uint64_t cus = cus_s ? (uint64_t)std::max(1, atoi(cus_s)) : std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 7 / 8);
-    const uint64_t grid = quads < cus ? (quads ? quads : 1) : cus;
+    static const bool small_full = oi_ablation_env("OI_SCREEN_SMALL_FULL") != nullptr; // A/B: a chunk of <= one quad per CU takes every CU
+    const uint64_t grid = small_full && quads <= (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (quads < cus ? (quads ? quads : 1) : cus);
     *n_segs = (uint32_t)grid;
     *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * PF_TILE_ROWS;
 }
@@ -561,7 +655,7 @@ template <int D, int NQT>
 static int launch_screen(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
                          uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
     constexpr int NKC = D / PF_SLOT_K, NBUF = NKC % 8 == 0 ? 8 : (NKC % 6 == 0 ? 6 : NKC);
-    constexpr size_t smem = 4 * NBUF * PF_SLOT_BYTES + 64 * 4;
+    constexpr size_t smem = 4 * NBUF * PF_SLOT_BYTES + 64 * 4 + PF_STAGE_LDS;
     OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_screen_filter<D, NQT>), (size_t)(smem)));
     hipLaunchKernelGGL((cosine_screen_filter<D, NQT>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin,
                        row_end, q, nq, doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride,
@@ -587,6 +681,12 @@ int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_b
         p.carry_cnt += q0;
         p.seg_cnt += (uint64_t)q0 * pool.seg_cnt_stride;
         p.tau_keys += q0;
+        static const bool tau_max = oi_ablation_env("OI_SCREEN_TAU_MAX") != nullptr; // A/B (WRONG results): chunks of >= 1M rows pass nothing
+        if (tau_max && row_end - row_begin >= (1u << 20)) {
+            DevBuf &tb = ctx->buf("abl_tau_max");
+            if (!tb.p) { OI_CHECK(tb.ensure(4096 * 4)); OI_HIP_CHECK(hipMemsetAsync(tb.p, 0xFF, 4096 * 4, ctx->stream)); }
+            p.tau_keys = tb.as<uint32_t>();
+        }
         const uint16_t *qptr = q_bf16 + (uint64_t)q0 * dim;
         const bool two = nq_here > 32;
         if (dim == 768) {
