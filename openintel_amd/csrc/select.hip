@@ -219,10 +219,19 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
 //     near-threshold scores are nearly all equal, i.e. one LDS address).
 #define SEL_MAX_SEGS 4096
 #define SEL_KPT_MAX 32
+#ifdef OI_ABLATION
+// OI_SELECT_STAMPS=1 (ablation builds): query 0's thread 0 prints where a select_flat launch spends its cycles
+__device__ int sel_dbg_on;
+__device__ unsigned long long sel_dbg_t[16];
+#define SEL_STAMP(i) do { if (sel_dbg_on && blockIdx.x == 0 && threadIdx.x == 0) sel_dbg_t[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEL_STAMP(i) do { } while (0)
+#endif
 #define SEL_CAND 4096
 
 struct SelShared {
     uint32_t hist[256];
+    uint32_t hist2k[2048]; // the margin selects' 11-bit digits (sel_flat_select, fast margin path)
     uint32_t seg_off[SEL_MAX_SEGS + 1];
     uint32_t wave_tot[SEL_THREADS / 64];
     uint32_t cnt, kk, bin_cnt, n_samples;
@@ -291,6 +300,33 @@ __device__ __forceinline__ void sel_append(uint64_t *dst, uint32_t *count, uint3
     base = (uint32_t)__shfl((int)base, (int)leader, OI_WAVE);
     const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (take && pos < cap) dst[pos] = key;
+}
+
+// wave-wide inclusive prefix sum in DPP steps (no LDS round trips, unlike __shfl_up)
+__device__ __forceinline__ uint32_t sel_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// hist[digit] += weight for the active lanes; the two most common digits of the wave go in as one atomic each
+__device__ __forceinline__ void sel_hist_add_w(uint32_t *hist, bool active, uint32_t digit, uint32_t weight) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned long long m = __ballot(active);
+        if (!m) return;
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, (int)leader);
+        const bool same = active && digit == d0;
+        const uint32_t sum = (uint32_t)__builtin_amdgcn_readlane((int)sel_incl_scan(same ? weight : 0u), 63);
+        if (lane == leader) atomicAdd(&hist[d0], sum);
+        active = active && !same;
+    }
+    if (active) atomicAdd(&hist[digit], weight);
 }
 
 // Radix select over the keys `for_each` enumerates (f(valid, key), same keys on every call): finds
@@ -412,6 +448,120 @@ __device__ __forceinline__ uint32_t sel_flat_select(const SelFlat &K, uint32_t k
         __syncthreads();
         return skip ? sh.cnt : n; // (skipped keys were not appended)
     }
+    SEL_STAMP(2);
+    if (eps2 >= 0.f) {
+        // ---- margin mode, the fast path (round 4).  What the next chunk and the rescoring need is ANY lower bound tau' of the
+        // k-th largest screen score and every key within eps2 of tau' -- not the k-th key itself.  Two passes of 11-bit digits
+        // over the valid keys find the 22-bit bin (sign, exponent, 13 bits of mantissa) that holds the k-th largest; its LOWER
+        // EDGE is tau': at least k keys are >= it, and it is below the k-th score by < 2^-13 of its size, ~1e-5 where the margin
+        // is ~4e-3, so the survivor set grows by a fraction of a percent.  (The exact path below: a 1024-key sample, 4-7 passes of
+        // 8-bit digits over the sample, a cut, 4-7 more over the cut, the k-th key, then the margin filter -- 25-30 us per launch
+        // between two corpus chunks; this one: two histogram passes and the filter.)  Fewer than k valid keys: the exact path.
+        uint32_t kk = k;
+        uint32_t pfx = 0;
+        bool enough = true;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int shift = 53 - 11 * pass;
+            sh.hist2k[tid] = 0;
+            sh.hist2k[tid + SEL_THREADS] = 0;
+            __syncthreads();
+            if (pass == 0) {
+                // the leading digit (sign, exponent, two bits of mantissa) of a pool of near-threshold scores takes a handful of
+                // values: a thread adds its keys up in runs first, and the wave its threads' last runs (one LDS address each)
+                uint32_t run_d = 0, run_c = 0;
+                for_each([&](bool valid, uint64_t kv) {
+                    if (valid) {
+                        const uint32_t d = (uint32_t)(kv >> 53);
+                        if (run_c && d != run_d) { atomicAdd(&sh.hist2k[run_d], run_c); run_c = 0; }
+                        run_d = d;
+                        ++run_c;
+                    }
+                });
+                sel_hist_add_w(sh.hist2k, run_c != 0u, run_d, run_c);
+            } else { // 11 bits of mantissa inside one leading bin: spread over the 2048 addresses, plain atomics
+                for_each([&](bool valid, uint64_t kv) {
+                    if (valid && (uint32_t)(kv >> 53) == pfx) atomicAdd(&sh.hist2k[(uint32_t)(kv >> shift) & 2047u], 1u);
+                });
+            }
+            __syncthreads();
+            { // 64 super-bins of 32 bins: a thread adds two bins, a DPP row (16 lanes) the 32 of a super-bin -- conflict-free reads
+                uint32_t v = sh.hist2k[2 * tid] + sh.hist2k[2 * tid + 1];
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+                if ((tid & 15u) == 15u) sh.hist[tid >> 4] = v; // super-bin s = bins [32 s, 32 s + 32)
+            }
+            __syncthreads();
+            if (tid < 64) { // wave 0: the super-bin, then the bin, holding the kk-th key counted from the top -- two scans, no walk
+                const uint32_t x = sh.hist[63u - tid];
+                const uint32_t incl = sel_incl_scan(x);
+                const unsigned long long ball = __ballot(incl >= kk);
+                if (!ball) {
+                    if (tid == 0) sh.bin_cnt = 0xFFFFFFFFu; // fewer than kk valid keys
+                } else {
+                    const uint32_t l1 = (uint32_t)__builtin_ctzll(ball), sb = 63u - l1;
+                    const uint32_t kk2 = kk - (uint32_t)__builtin_amdgcn_readlane((int)(incl - x), (int)l1);
+                    const uint32_t y = tid < 32u ? sh.hist2k[32u * sb + 31u - tid] : 0u;
+                    const uint32_t incl2 = sel_incl_scan(y);
+                    const unsigned long long ball2 = __ballot(incl2 >= kk2); // (non-empty: the super-bin holds >= kk2 keys)
+                    const uint32_t l2 = ball2 ? (uint32_t)__builtin_ctzll(ball2) : 31u;
+                    // (read with every lane active: inside the one-lane branch below hipcc computes incl2 - y for that lane only)
+                    const uint32_t above = (uint32_t)__builtin_amdgcn_readlane((int)(incl2 - y), (int)l2);
+                    if (tid == 0) {
+                        sh.prefix = (uint64_t)(32u * sb + 31u - l2);
+                        sh.kk = kk2 - above;
+                        sh.bin_cnt = 1u;
+#ifdef OI_ABLATION
+                        if (sel_dbg_on > 1) { // OI_SELECT_STAMPS=2: self-check against the plain walk from the top
+                            uint32_t cum = 0; int dd = 2047;
+                            for (; dd >= 0; --dd) { if (cum + sh.hist2k[dd] >= kk) break; cum += sh.hist2k[dd]; }
+                            if ((uint32_t)dd != (uint32_t)sh.prefix || kk - cum != sh.kk)
+                                printf("MISMATCH q=%u pass=%d kk=%u: walk (%d, %u) super-bin (%u, %u) sb=%u l1=%u kk2=%u l2=%u\n", blockIdx.x, pass, kk, dd, kk - cum,
+                                       (uint32_t)sh.prefix, sh.kk, sb, l1, kk2, l2);
+                        }
+#endif
+                    }
+                }
+            }
+            __syncthreads();
+            enough = sh.bin_cnt != 0xFFFFFFFFu;
+            const uint32_t d = (uint32_t)sh.prefix;
+            kk = sh.kk;
+            __syncthreads(); // (sh.prefix / sh.kk / sh.bin_cnt are rewritten by the next pass or the exact path)
+            if (!enough) break;
+            if (pass == 0) pfx = d;
+            else pfx = (pfx << 11) | d;
+            SEL_STAMP(3 + pass);
+        }
+        if (enough) {
+            uint32_t tkey = pfx << 10; // the bin's lower edge as a 32-bit score key
+            tkey = tkey < 0x007FFFFFu ? 0x007FFFFFu : tkey; // (below key(-inf) the bit pattern is a NaN's: -inf instead)
+            const uint32_t t32 = eps2 < __builtin_inff() ? oi_f32_key(oi_key_f32(tkey) - eps2) : 0u;
+            // the filter: a thread counts its survivors, the wave takes ONE slot range for all of them
+            uint32_t mine = 0;
+            for_each([&](bool valid, uint64_t kv) { mine += valid && (uint32_t)(kv >> 32) >= t32 ? 1u : 0u; });
+            const uint32_t incl = sel_incl_scan(mine);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint32_t base = 0;
+            if (lane == 0 && tot) base = atomicAdd(&sh.cnt, tot);
+            uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - mine;
+            for_each([&](bool valid, uint64_t kv) {
+                if (valid && (uint32_t)(kv >> 32) >= t32) {
+                    if (pos < SEL_CAND) cand[pos] = kv;
+                    ++pos;
+                }
+            });
+            __syncthreads();
+            const uint32_t c = sh.cnt;
+            *in_cand = true;
+            *margin_tau = t32;
+            *margin_overflow = c > SEL_CAND;
+            SEL_STAMP(5);
+            return c > SEL_CAND ? SEL_CAND : c;
+        }
+    }
     int shift;
     uint64_t prefix;
     bool selected = false; // sel[0..k) holds the top k
@@ -515,6 +665,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint64_t *pool = pools + (uint64_t)q * pool_stride;
     uint32_t *segc = seg_cnt + (uint64_t)q * seg_cnt_stride;
+    SEL_STAMP(0);
+    const uint32_t c0_raw = carry_cnt[q];    // (issued beside the segment counts: not a second round trip after the scan)
+    const float e2 = eps2 ? eps2[q] : -1.f;
 
     // exclusive scan of the (clamped) segment counts -> sh.seg_off; SEL_MAX_SEGS / SEL_THREADS = 4 per thread
     constexpr int SPT = SEL_MAX_SEGS / SEL_THREADS;
@@ -528,12 +681,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
         c[u] = v;
         local += v;
     }
-    uint32_t incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o, OI_WAVE);
-        if ((int)lane >= o) incl += v;
-    }
+    const uint32_t incl = sel_incl_scan(local);
     if (lane == 63) sh.wave_tot[wv] = incl;
     if (tid == 0) { sh.cnt = 0; sh.min_key = ~0ull; }
     __syncthreads();
@@ -556,14 +704,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
 
     SelFlat K;
     K.pool = pool; K.seg_off = sh.seg_off; K.carry_cap = carry_cap; K.seg_cap = seg_cap; K.n_segs = n_segs;
-    K.c0 = carry_cnt[q] < carry_cap ? carry_cnt[q] : carry_cap;
+    K.c0 = c0_raw < carry_cap ? c0_raw : carry_cap;
     K.n = K.c0 + total;
     K.steps = 0;
     while ((1u << K.steps) < n_segs) ++K.steps;
+    SEL_STAMP(1);
 
     uint32_t m, m_tau = 0;
     bool in_cand = false, m_over = false;
-    const float e2 = eps2 ? eps2[q] : -1.f;
     if (K.n <= 4 * SEL_THREADS) m = sel_flat_select<4>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
     else if (K.n <= 8 * SEL_THREADS) m = sel_flat_select<8>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
     else if (K.n <= 16 * SEL_THREADS) m = sel_flat_select<16>(K, k, sh, sel, cand, e2, &in_cand, &m_tau, &m_over, skip, skip_base);
@@ -577,6 +725,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_flat_kernel(
             carry_cnt[q] = m;
             if (tau_keys && m_tau > tau_keys[q]) tau_keys[q] = m_tau;
         }
+#ifdef OI_ABLATION
+        __syncthreads();
+        if (sel_dbg_on && blockIdx.x == 0 && tid == 0) {
+            const unsigned long long e = __builtin_readcyclecounter();
+            printf("select margin n=%u m=%u segs=%u: scan %llu, loads+skip %llu, pass0 %llu, pass1 %llu, filter %llu, compact %llu (cycles)\n", K.n, m, n_segs,
+                   sel_dbg_t[1] - sel_dbg_t[0], sel_dbg_t[2] - sel_dbg_t[1], sel_dbg_t[3] - sel_dbg_t[2], sel_dbg_t[4] - sel_dbg_t[3], sel_dbg_t[5] - sel_dbg_t[4], e - sel_dbg_t[5]);
+        }
+#endif
         return;
     }
 
@@ -626,6 +782,14 @@ int oi_launch_select(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint
     OI_REQUIRE(k >= 1 && k <= OI_MAX_DEPTH && k <= pool.carry_cap, "select: k=%u outside [1,%u]", k, OI_MAX_DEPTH);
     ProfScope ps(ctx, "select");
     static const bool v1 = oi_ablation_env("OI_SELECT_V1") != nullptr; // A/B switch: the segment-walking kernel
+#ifdef OI_ABLATION
+    static const bool stamps = [] {
+        const int on = oi_ablation_env("OI_SELECT_STAMPS") ? std::max(1, atoi(oi_ablation_env("OI_SELECT_STAMPS"))) : 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(sel_dbg_on), &on, sizeof(int));
+        return on != 0;
+    }();
+    (void)stamps;
+#endif
     const bool special = extra && (extra->eps2 || extra->run_gate);
     if (special) {
         OI_REQUIRE(pool.n_segs <= SEL_MAX_SEGS, "select: %u segments (margin / gated selects take <= %u)", pool.n_segs, SEL_MAX_SEGS);

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/epi4
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for cfg in "OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation OI_SCREEN_TAU_MAX=1" "OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation OI_BM25_LATE=1"; do
+for cfg in ${CFGS:-"OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation_old" "OI_LIB=ablation"}; do
   i=$((i+1))
   for kv in $cfg; do export $kv; done
   rocprofv3 --kernel-trace --output-format csv -d $OUT/run$i -- python3 $R/tools/step_ab.py 10000000 20 > $OUT/run$i.json 2> $OUT/run$i.err || exit 1

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/oldnew4
 mkdir -p $OUT
 i=0
-for cfg in "OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation OI_BM25_LATE=1" "OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation OI_BM25_LATE=1"; do
+for cfg in "OI_LIB=ablation_old" "OI_LIB=ablation" "OI_LIB=ablation_old" "OI_LIB=ablation"; do
   i=$((i+1))
   env $cfg timeout -k 10 200 python3 $R/tools/step_ab.py 10000000 40 > $OUT/full_$i.json 2> $OUT/full_$i.err || exit 1
   env $cfg timeout -k 10 100 python3 $R/tools/shard_step_bench.py 1250000 50 > $OUT/shard_$i.json 2> $OUT/shard_$i.err || exit 1
