@@ -109,8 +109,9 @@ __device__ __forceinline__ pf_bf16x8 pf_pack(const pf_f32x4 &a, const pf_f32x4 &
     return r;
 }
 
-// Survivor staging of the screen kernel: PF_STAGE entries per wave (a power of two), flushed PF_STAGE_FLUSH at a time.
-#define PF_STAGE 128
+// Survivor staging of the screen kernel: PF_STAGE entries per wave (a power of two), flushed PF_STAGE_FLUSH at a time (fewer than
+// PF_STAGE_FLUSH stay between tiles, so a tile of up to PF_STAGE - PF_STAGE_FLUSH survivors is staged).
+#define PF_STAGE 256
 #define PF_STAGE_FLUSH 64u
 #define PF_STAGE_LDS (4 * PF_STAGE * 12)
 __device__ __forceinline__ uint32_t pf_incl_scan(uint32_t v) { // wave-wide inclusive prefix sum (DPP, no LDS)
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
                 const uint32_t cnt = (uint32_t)__builtin_popcount(m);
                 const uint32_t incl = pf_incl_scan(cnt);
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                if (total <= PF_STAGE_FLUSH) {
+                if (total <= PF_STAGE - PF_STAGE_FLUSH) {
                     // SPARSE tile (every tile once a threshold stands): the survivors go to the wave's LDS staging ring, and
                     // 64 of them leave with ONE store instruction.  A store per survivor sat in the same in-order vmcnt queue
                     // as the DMA pieces: every counted wait then also waited for slots it did not need yet (the stores behind
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
                                 ++idx;
                             }
                     st_n += total;
-                    if (st_n >= PF_STAGE_FLUSH) {
+                    while (st_n >= PF_STAGE_FLUSH) {
                         PF_FLUSH(PF_STAGE_FLUSH);
                     }
                 } else {

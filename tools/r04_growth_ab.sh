@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/growth4
 mkdir -p $OUT
 export OI_LIB=ablation
-for cfg in "8 1" "64 1" "64 2" "64 4" "16 2" "8 1"; do
+for cfg in "8 1" "64 1" "64 2" "32 1" "8 1" "64 1"; do
   set -- $cfg
   export OI_CHUNK_GROWTH=$1 OI_FIRST_CHUNK_MULT=$2
   timeout -k 10 200 python3 $R/tools/step_ab.py 10000000 40 > $OUT/full_$1_$2.json 2> $OUT/full_$1_$2.err || exit 1
