@@ -1039,6 +1039,17 @@ static uint64_t oi_first_chunk_rows(uint32_t depth) {
     static const uint64_t mult = oi_ablation_env("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(oi_ablation_env("OI_FIRST_CHUNK_MULT"))) : 1;
     return std::max<uint64_t>(8192, 32ull * depth) * mult;
 }
+// The screen's first chunk (round 4): a whole number of ROUNDS of the persistent grid -- 7/8 of the CUs x 4 waves x 32-row tiles
+// (cosine_prefilter.hip: oi_cosine_screen_geometry) -- so that no wave of the two short first launches runs one tile more than
+// the others (32000 rows = 1000 tiles on 896 waves: 104 waves with two tiles; 256000 rows: 9.1 per wave, i.e. 10 rounds).
+// Chunk k is 8^k times the first and keeps the property.  OI_SCREEN_NO_ROUND=1 (A/B): as before.
+static uint64_t oi_screen_first_chunk_rows(const oi_ctx *ctx, uint32_t depth) {
+    static const bool no_round = oi_ablation_env("OI_SCREEN_NO_ROUND") != nullptr;
+    uint64_t rows = oi_first_chunk_rows(depth);
+    const uint64_t round = 32ull * 4 * std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 7 / 8);
+    if (!no_round && rows >= round) rows -= rows % round;
+    return rows;
+}
 // Measured (tools/growth_ab.sh): 8 is best for the MFMA batch path at 10M and 1.25M rows (more survivors per
 // chunk cost more in the epilogue and the select than the launch they save); the GEMV path (B <= 8) gains
 // 3 % from 16 (1M rows: 3 launches instead of 4).
@@ -1270,7 +1281,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
         if (!early_env && !idx->rows_bf16 && idx->rows && ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && idx->screen_ok &&
             oi_cosine_screen_supported(idx->dim) && pf_stride > pf_carry + pf_slack) {
             const uint64_t mc = pf_stride - pf_carry - pf_slack; // the screen's own schedule (cosine_leg below), dry
-            uint64_t chunk = oi_first_chunk_rows(depth), r = 0, last = 0;
+            uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth), r = 0, last = 0;
             while (r < n) {
                 if (chunk > mc) chunk = mc;
                 const uint64_t e = oi_chunk_end(r, chunk, n, mc, chunk * oi_chunk_growth(B));
@@ -1380,7 +1391,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(idx->screen_copy.ensure(sizeof(uint16_t) * (size_t)n * idx->dim + 64));
                 OI_CHECK(oi_launch_make_screen_copy(ctx, idx->rows, n, idx->dim, idx->screen_copy.as<uint16_t>()));
             }
-            uint64_t chunk = oi_first_chunk_rows(depth);
+            uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth);
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
