@@ -84,7 +84,10 @@ void PinBuf::release() {
 // ---------------------------------------------------------------- profiling hooks
 void oi_ctx::prof_begin(const char *tag) {
     ProfSpan s;
-    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    // (timing only: without the system-scope fence a default event performs when it completes -- each pair sits between two
+    // kernels of the timed step)
+    if (hipEventCreateWithFlags(&s.a, hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&s.b, hipEventDisableSystemFence) != hipSuccess) return;
     (void)hipEventRecord(s.a, stream);
     prof[tag].push_back(s);
 }
@@ -273,8 +276,8 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
-    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) c->ev_join = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) c->ev_fork = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) c->ev_join = nullptr;
     *out = c;
     return OI_OK;
 }
