@@ -303,7 +303,7 @@ def main():
 
     # ---------------------------------------------------------------- timed region: exactly K steps
     for c in [ctx] + lane_ctxs:
-        c.profile_reset(2)   # HIP events around the dominant kernel's launches only (each pair costs stream time)
+        c.profile_reset(0 if os.environ.get("OI_BENCH_NO_LIVE_EVENTS") else 2)   # HIP events around the dominant kernel's launches only (each pair costs stream time)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
