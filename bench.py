@@ -315,6 +315,11 @@ def main():
     if world > 1:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     elapsed = float(tm.item())
+    if os.environ.get("OI_BENCH_NO_LIVE_EVENTS"):   # experiment: what the kernel's event pairs cost the timed region (no roofline possible)
+        if rank == 0:
+            print(json.dumps({"value": args.batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "p50_ms": None,
+                              "note": "OI_BENCH_NO_LIVE_EVENTS: timed region without the dominant kernel's HIP events"}))
+        return
     # every rank's own set-up and clock (rank 0 prints them all: a scaling number can be tied to the lanes that produced it)
     mine = {"rank": rank, "docs_per_gpu": n_local, "doc_id_base": lo, "own_elapsed_ms_per_step": float(tm_own) / args.steps * 1e3,
             "lane_calibration": pipe.calibration if pipe is not None else None,
@@ -468,7 +473,7 @@ def main():
                 g = solo if left <= solo else (128 if left > 96 else 96) if args.dim == 1024 else (96 if (left + 95) // 96 < (left + 63) // 64 else 64)
                 left -= min(g, left)
                 passes += 1
-        cos_s = cos_ms / 1e3
+        cos_s = cos_ms / 1e3 if cos_ms > 0 else float('nan')   # (nan: OI_BENCH_NO_LIVE_EVENTS, an experiment without the kernel's events)
         if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}
