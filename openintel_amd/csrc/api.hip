@@ -784,6 +784,7 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     alias(v->max_row_norm, src->max_row_norm); alias(v->screen_copy, src->screen_copy);
     alias(v->uniq_keys, src->uniq_keys); alias(v->tf, src->tf); alias(v->doc_len, src->doc_len); alias(v->df_local, src->df_local);
     alias(v->postings, src->postings); alias(v->cell_start, src->cell_start); alias(v->idf, src->idf);
+    alias(v->impact_floor, src->impact_floor);
     v->n_long = src->n_long; alias(v->long_list, src->long_list); alias(v->long_bitmap, src->long_bitmap);
     alias(v->fwd_terms, src->fwd_terms); alias(v->fwd_offsets, src->fwd_offsets);
     *out = v;
@@ -1144,8 +1145,16 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             static const uint32_t first_div = oi_ablation_env("OI_BM25_FIRST_DIV") ? std::max(1, atoi(oi_ablation_env("OI_BM25_FIRST_DIV"))) : 8;
             // Up to 48 blocks (1.5M docs: a shard of configs[3]) ONE phase: every touched doc is a candidate (~30K keys per query,
             // the select's register path), one launch and one select fewer -- 0.052 vs 0.081 ms of kernels at 1.25M docs.
-            const uint32_t first = nb > 48 ? std::max<uint32_t>(8, nb / first_div) : nb;
-            const uint32_t cap1 = oi_bm25_stream_seg_cap(depth, true), cap2 = oi_bm25_stream_seg_cap(depth, false);
+            // Round 4, second half: NO threshold-less phase at all when the index has its per-term impact floors (bm25.hip): the
+            // plan kernel starts every query at max_t fl(idf_t * floor_t) -- at least `depth` docs score that much, so it is a valid
+            // lower bound of the depth-th best score before a posting is read -- and ONE launch scores every block against it, with the
+            // small pruned segments of the former second phase.  At 10M docs that bound is HIGHER than the first phase's (the 1024th
+            // impact of one term over all docs vs the 1000th score over an eighth of them), and a launch, a select and the first
+            // phase's 30 K candidates per query go away.  OI_BM25_TWO_PHASE=1 (A/B): the phases as before.
+            static const bool two_phase_env = oi_ablation_env("OI_BM25_TWO_PHASE") != nullptr;
+            const bool floors = idx->impact_floor.p != nullptr && !two_phase_env;
+            const uint32_t first = floors ? nb : nb > 48 ? std::max<uint32_t>(8, nb / first_div) : nb;
+            const uint32_t cap1 = oi_bm25_stream_seg_cap(depth, !floors), cap2 = oi_bm25_stream_seg_cap(depth, false);
             const uint64_t sstride = (uint64_t)carry_cap + std::max<uint64_t>((uint64_t)first * cap1, (uint64_t)nb * cap2);
             uint64_t pass = (2ull << 30) / 8 / sstride; // <= 2 GiB of pool (0.2 GB for 64 queries over 10M docs)
             pass = std::max<uint64_t>(1, std::min<uint64_t>(pass, std::min<uint32_t>(B, oi_bm25_stream_pass_queries())));
@@ -1157,7 +1166,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 const uint32_t nq = std::min<uint32_t>((uint32_t)pass, B - q0);
                 uint32_t *w = sc.as<uint32_t>();
                 // (the plan launch also zeroes the pass's pool state: carry_cnt[pass] tau[pass] seg_cnt[pass][nb])
-                OI_CHECK(oi_launch_bm25_plan(idx, d_qt, d_qo, q0, nq, w, swords));
+                OI_CHECK(oi_launch_bm25_plan(idx, d_qt, d_qo, q0, nq, w, swords, depth, (uint32_t)pass, (uint32_t)pass, floors));
                 PoolView W1{sp.as<uint64_t>(), w, w + 2 * (size_t)pass, w + pass, sstride, carry_cap, cap1, first, nb, P.bm.overflow};
                 OI_CHECK(oi_launch_bm25_stream(idx, d_qt, d_qo, q0, nq, depth, W1, 0, first));
                 if (first < nb) {

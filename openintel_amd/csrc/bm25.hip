@@ -112,6 +112,74 @@ __global__ void bm_impact_kernel(const uint64_t *uniq, const uint32_t *tf, uint6
     }
 }
 
+// Per-term impact floors (round 4).  floor[t][j] = the bits of a LOWER BOUND of term t's r_j-th largest posting impact,
+// r = 16, 64, 256, 1024 (0.0f when the term has fewer postings): the lower edge of the 22-bit bin (two 11-bit histogram passes
+// over the term's postings) that holds it.  What it is for: at least r_j docs hold term t with an impact >= floor, every one of
+// them scores >= idf_t * floor for any query that contains t (the other terms add >= 0, f32 sums of non-negative values never
+// fall below an addend), so max_t fl(idf_t * floor[t][j]) with r_j >= depth is a valid lower bound of the query's depth-th
+// best BM25 score BEFORE a single posting is read -- the stream kernel starts with that threshold instead of a threshold-less
+// first phase (bm25_stream.hip).  One 256-thread workgroup per term.
+__device__ void bm_floor_find(const uint32_t *hist, uint32_t kk, uint32_t *bin_out, uint32_t *above_out) {
+    // wave 0: the bin of hist[0..2048) holding the kk-th entry counted from the top; lane l owns bins 2047 - 32 l - (0..31)
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t mine = 0;
+    for (uint32_t i = 0; i < 32; ++i) mine += hist[2047u - (lane * 32u + i)];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o, OI_WAVE);
+        if ((int)lane >= o) incl += v;
+    }
+    const unsigned long long ball = __ballot(incl >= kk);
+    const uint32_t owner = ball ? (uint32_t)__builtin_ctzll(ball) : 63u;
+    if (lane == owner) {
+        uint32_t cum = incl - mine, b = 2047u - lane * 32u;
+        for (uint32_t i = 0; i < 32; ++i, --b) {
+            const uint32_t c = hist[b];
+            if (cum + c >= kk || i == 31) break;
+            cum += c;
+        }
+        *bin_out = b;
+        *above_out = cum;
+    }
+}
+__global__ __launch_bounds__(256) void bm_term_floor_kernel(const Posting *__restrict__ postings, const uint32_t *__restrict__ cell_start,
+                                                            uint32_t n_win, uint32_t vocab, uint32_t *__restrict__ floors) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t s_bin[OI_BM25_FLOOR_RANKS], s_above[OI_BM25_FLOOR_RANKS], s_bin2, s_above2;
+    const uint32_t t = blockIdx.x, tid = threadIdx.x;
+    if (t >= vocab) return;
+    const uint32_t lo = cell_start[(uint64_t)t * n_win], hi = cell_start[(uint64_t)(t + 1) * n_win];
+    const uint32_t df = hi - lo;
+    const uint32_t ranks[OI_BM25_FLOOR_RANKS] = {16u, 64u, 256u, 1024u};
+    if (df < ranks[0]) return; // (the table is zeroed before the launch)
+    // ---- pass 1: the leading 11 bits (sign 0, exponent, two bits of mantissa) of every impact
+    for (uint32_t i = tid; i < 2048; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 256) atomicAdd(&hist[__float_as_uint(postings[i].impact) >> 21], 1u);
+    __syncthreads();
+    for (int j = 0; j < OI_BM25_FLOOR_RANKS; ++j) { // (sequential: bm_floor_find is wave 0's, with its own results)
+        if (tid < 64 && df >= ranks[j]) bm_floor_find(hist, ranks[j], &s_bin[j], &s_above[j]);
+        __syncthreads();
+    }
+    // ---- pass 2 per rank: the next 11 bits among the impacts of its leading bin
+    for (int j = 0; j < OI_BM25_FLOOR_RANKS; ++j) {
+        if (df < ranks[j]) break; // uniform
+        const uint32_t d1 = s_bin[j], kk = ranks[j] - s_above[j];
+        for (uint32_t i = tid; i < 2048; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = lo + tid; i < hi; i += 256) {
+            const uint32_t b = __float_as_uint(postings[i].impact);
+            if ((b >> 21) == d1) atomicAdd(&hist[(b >> 10) & 2047u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) bm_floor_find(hist, kk, &s_bin2, &s_above2);
+        __syncthreads();
+        if (tid == 0) floors[(uint64_t)t * OI_BM25_FLOOR_RANKS + j] = (d1 << 21) | (s_bin2 << 10); // the bin's lower edge
+        __syncthreads();
+    }
+}
+
 int oi_bm25_stage_forward(oi_index *idx, const uint32_t *d_terms, const uint64_t *d_offsets) {
     oi_ctx *ctx = idx->ctx;
     hipStream_t st = ctx->stream;
@@ -240,6 +308,14 @@ int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, c
         hipLaunchKernelGGL(bm_impact_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, idx->uniq_keys.as<uint64_t>(),
                            idx->tf.as<uint32_t>(), idx->n_postings, idx->doc_len.as<uint32_t>(), avgdl,
                            idx->postings.as<Posting>());
+        OI_HIP_CHECK(hipGetLastError());
+    }
+    // the per-term impact floors the stream kernel's first threshold is read from
+    OI_CHECK(idx->impact_floor.ensure(sizeof(uint32_t) * (size_t)idx->vocab * OI_BM25_FLOOR_RANKS));
+    OI_HIP_CHECK(hipMemsetAsync(idx->impact_floor.p, 0, sizeof(uint32_t) * (size_t)idx->vocab * OI_BM25_FLOOR_RANKS, st));
+    if (idx->n_postings) {
+        hipLaunchKernelGGL(bm_term_floor_kernel, dim3(idx->vocab), dim3(256), 0, st, idx->postings.as<Posting>(),
+                           idx->cell_start.as<uint32_t>(), idx->n_win, idx->vocab, idx->impact_floor.as<uint32_t>());
         OI_HIP_CHECK(hipGetLastError());
     }
     OI_HIP_CHECK(hipStreamSynchronize(st)); // idf vector goes out of scope

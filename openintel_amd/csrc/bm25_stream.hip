@@ -680,8 +680,12 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ df, uint32_t vocab, uint32_t n_blocks,
                                                         uint32_t q_begin, uint32_t nq, uint32_t *unit, uint64_t *cum,
                                                         uint32_t *state, uint64_t state_words, const float *__restrict__ idf,
-                                                        uint32_t n_win, uint2 *qctx) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < state_words; i += (uint64_t)gridDim.x * 256) state[i] = 0u;
+                                                        uint32_t n_win, uint2 *qctx, const uint32_t *__restrict__ floors,
+                                                        uint32_t floor_j, uint32_t tau_off, uint32_t tau_words) {
+    // floors (round 4): the per-term impact floors of bm25.hip -- state[tau_off + r] (query r's threshold key) starts at
+    // max over its terms of fl(idf * floor[term][floor_j]) instead of 0; those words are workgroup 0's, the rest is zeroed here
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < state_words; i += (uint64_t)gridDim.x * 256)
+        if (!floors || i < tau_off || i >= (uint64_t)tau_off + tau_words) state[i] = 0u;
     // every query's first 64 runs as the stream kernel's lanes want them: {term * n_win, idf} or {~0, 0} (all workgroups)
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq * 64u; i += gridDim.x * 256) {
         const uint32_t r = i >> 6, j = i & 63u;
@@ -705,6 +709,20 @@ __global__ __launch_bounds__(256) void bm25_plan_kernel(const uint32_t *__restri
         s_unit[r] = (uint32_t)u;
         unit[r] = (uint32_t)u;
     }
+    if (floors) {
+        for (uint32_t r = threadIdx.x; r < tau_words; r += 256) {
+            float best = 0.f;
+            if (r < nq)
+                for (uint32_t i = q_offsets[q_begin + r]; i < q_offsets[q_begin + r + 1]; ++i) {
+                    const uint32_t term = q_terms[i];
+                    if (term < vocab) { // the product the kernel forms for a posting of this term with that impact (one rounding, monotone)
+                        const float f = __fmul_rn(idf[term], __uint_as_float(floors[(uint64_t)term * OI_BM25_FLOOR_RANKS + floor_j]));
+                        best = f > best ? f : best;
+                    }
+                }
+            state[tau_off + r] = best > 0.f ? (__float_as_uint(best) | 0x80000000u) : 0u; // the key of a score > 0; 0 = no threshold
+        }
+    }
     if (threadIdx.x < 2) unit[BS_MAX_Q + threadIdx.x] = 0u; // the two phases' hand-out counters
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -721,7 +739,7 @@ uint32_t oi_bm25_stream_seg_cap(uint32_t depth, bool first_phase) {
 }
 
 int oi_launch_bm25_plan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin, uint32_t nq,
-                        uint32_t *state, uint64_t state_words) {
+                        uint32_t *state, uint64_t state_words, uint32_t depth, uint32_t tau_off, uint32_t tau_words, bool with_floors) {
     oi_ctx *ctx = idx->ctx;
     OI_REQUIRE(nq >= 1 && nq <= BS_MAX_Q, "bm25 (stream): %u queries in one pass (limit %u)", nq, BS_MAX_Q);
     DevBuf &pb = ctx->buf("bm25_stream_plan");
@@ -733,7 +751,8 @@ int oi_launch_bm25_plan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
     ProfScope ps(ctx, "bm25");
     hipLaunchKernelGGL(bm25_plan_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_q_terms, d_q_offsets,
                        idx->df_local.as<uint32_t>(), idx->vocab, idx->n_blocks, q_begin, nq, unit, cum, state, state_words,
-                       idx->idf.as<float>(), idx->n_win, qctx);
+                       idx->idf.as<float>(), idx->n_win, qctx, with_floors && idx->impact_floor.p ? idx->impact_floor.as<uint32_t>() : nullptr,
+                       depth <= 16 ? 0u : depth <= 64 ? 1u : depth <= 256 ? 2u : 3u, tau_off, tau_words);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
@@ -827,7 +846,8 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
                 fprintf(stderr, "[bm25 stream wave longest] wave %u whole %llu wait %llu visits %llu tasks %llu xcc %llu start +%llu\n", order.back().second, o[0], o[1], o[2] >> 32,
                         o[2] & 0xFFFFFFFF, o[3] >> 56, (o[3] & 0xFFFFFFFFull) - t0min);
             }
-            for (unsigned long long i = 0; i < ns && i < 6; ++i) {
+            const unsigned long long n_print = std::max(6, atoi(oi_ablation_env("OI_BM25_STREAM_TIMING"))); // OI_BM25_STREAM_TIMING=N: N samples of long waits printed
+            for (unsigned long long i = 0; i < ns && i < n_print; ++i) {
                 const unsigned long long *o = &smp[32 + i * 4];
                 fprintf(stderr, "[bm25 stream sample] dur %llu pass %llu v %llu C %llu | visit# %llu stores %llu task# %llu | at cycle %llu ahead %llu\n", o[0],
                         o[1] >> 48, (o[1] >> 32) & 0xFFFF, o[1] & 0xFFFFFFFF, o[2] >> 32, (o[2] >> 16) & 0xFFFF, o[2] & 0xFFFF, o[3] >> 8, o[3] & 255);

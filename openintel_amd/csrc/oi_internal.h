@@ -156,6 +156,7 @@ struct ProfScope {
     }
 };
 
+#define OI_BM25_FLOOR_RANKS 4
 // ---------------------------------------------------------------- index
 struct oi_index {
     uint64_t uid = 0;         // process-unique (graph cache keys: an address can be reused, a uid cannot)
@@ -194,6 +195,9 @@ struct oi_index {
     DevBuf postings;   // {u32 doc_in_block, f32 impact} per unique key, (term, doc) order: one contiguous list per term
     DevBuf cell_start; // u32 [vocab * n_win + 1]: start of the (term, window) run; the next entry is its end
     DevBuf idf;        // f32 per term
+    // u32 [vocab][OI_BM25_FLOOR_RANKS] (round 4): bits of a lower bound of the term's r-th largest posting impact, r = 16, 64,
+    // 256, 1024 (0: fewer than r postings).  A query's first BM25 threshold is read off this table (bm25_stream.hip: the plan).
+    DevBuf impact_floor;
     // forward index kept for the batch scan (bm25_scan.hip)
     DevBuf fwd_terms;   // u32 per token
     DevBuf fwd_offsets; // u64 per doc + 1
@@ -325,7 +329,7 @@ int oi_launch_bm25_wave(oi_index *idx, const uint32_t *d_q_terms, const uint32_t
 uint32_t oi_bm25_stream_pass_queries(void);
 uint32_t oi_bm25_stream_seg_cap(uint32_t depth, bool first_phase);
 int oi_launch_bm25_plan(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin, uint32_t nq,
-                        uint32_t *state, uint64_t state_words);
+                        uint32_t *state, uint64_t state_words, uint32_t depth, uint32_t tau_off, uint32_t tau_words, bool with_floors);
 int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32_t *d_q_offsets, uint32_t q_begin,
                           uint32_t nq, uint32_t depth, const PoolView &pool, uint32_t block_begin, uint32_t block_end);
 // Doc blocks [block_begin, block_end); candidates below pool.tau_keys (if set) are dropped.

@@ -437,6 +437,44 @@ def test_bm25_edge_cases(ctx, O):
     idx.close()
 
 
+def test_bm25_stream_starts_from_the_terms_impact_floors(ctx, O):
+    """Round 4: the stream kernel has no threshold-less phase -- a query starts at max over its terms of idf * (a lower bound of
+    the term's r-th largest impact), r = 16 / 64 / 256 / 1024 >= depth (bm25.hip: bm_term_floor_kernel).  A bound that is too high
+    drops docs of the list: depths on both sides of every rank, terms whose df sits on both sides of every rank (a Zipf
+    vocabulary over several doc blocks), rare-only queries (no bound at all), repeated terms, a nonzero doc base -- every list
+    bit-identical to the oracle's and to the wave kernel's."""
+    from openintel_amd import pack_query_terms
+    rng = np.random.default_rng(404)
+    n, vocab = 70_000, 3000
+    rows = rng.integers(-2, 3, size=(n, 8)).astype(np.float32)
+    terms, offs = _small_forward(rng, n, vocab, max_len=10, zipf=True)
+    df = np.bincount(terms, minlength=vocab)
+    order = np.argsort(-df)
+    pick = lambda lo, hi: [int(t) for t in order if lo <= df[t] < hi][:3]
+    frequent, mid, low, rare = pick(2000, 10**9), pick(300, 1000), pick(70, 250), pick(1, 15)
+    assert frequent and mid and low and rare, (df.max(), df.min())
+    queries = [frequent[:1], frequent[:2] + mid[:1], mid[:2], low[:2], rare[:2], rare[:1] + frequent[:1], [frequent[0]] * 3,
+               low[:1] + rare[:1], mid + low + rare + frequent, [], [int(order[-1])]]
+    qt, qo = pack_query_terms(queries)
+    q = rng.integers(-2, 3, size=(len(queries), 8)).astype(np.float32)
+    idx = _build(ctx, rows, terms, offs, vocab, doc_base=1000)
+    idx.set_max_query_terms(16)
+    full = [O.bm25_scores(terms, offs, vocab, np.array(tq, np.uint32)) for tq in queries]
+    for depth in (1, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 1024):
+        lists = {}
+        for mode in (idx.BM25_STREAM, idx.BM25_WAVE):
+            idx.set_bm25_mode(mode)
+            lists[mode] = idx.search_lists(q, qt, qo, depth=depth)
+        L, W = lists[idx.BM25_STREAM], lists[idx.BM25_WAVE]
+        for b in range(len(queries)):
+            bs, bd = O.topk(full[b], depth, True, 1000)
+            assert int(L.bm25_counts[b]) == bd.size == int(W.bm25_counts[b]), (depth, b)
+            assert np.array_equal(L.bm25_docs[b][:bd.size], bd), (depth, b)
+            assert np.array_equal(L.bm25_scores[b][:bd.size].view(np.uint32), bs.view(np.uint32)), (depth, b)
+            assert np.array_equal(W.bm25_docs[b][:bd.size], bd), (depth, b)
+    idx.close()
+
+
 @pytest.mark.parametrize("n,vocab,B,max_terms,depth", [
     (70_000, 40, 33, 8, 100),     # heavy terms: most docs match several batch terms (> 6 distinct -> exact slow path)
     (70_000, 5000, 70, 8, 1000),  # sparse terms, two passes of the batch (1024/8 = 128 ... B=70 fits one; see next)
