@@ -57,9 +57,15 @@
 #endif
 #define BS_STAGE 128u     // staged keys (a lane's two postings are appended one after the other: <= 64 to < 64 left over)
 #define BS_MAX_Q 128u     // queries per pass
-#define BS_RUN_COST 64u   // weight of a run beside its postings (its last chunk is half empty on average), in postings: the cost
-                          // of a task is its chunk visits
-#define BS_TASK_COST 384u // weight of a task beside its runs: table, sweep, multi docs, end of task (measured: ~7 visits)
+#define BS_RUN_COST 64u   // weight of a run beside its postings, in postings
+#define BS_TASK_COST 384u // weight of a task beside its runs: table, sweep, multi docs, end of task
+// (Round 4 measured what a wave's time is made of -- OI_BM25_STREAM_TIMING=light, per-wave records of the PRODUCT kernel
+// regressed on what the waves did: lifetime = 0.383 us x chunk visits + 0.563 us x tasks + 11 us, residual 4.5 us; a run's
+// chunks start at the run, so a run of X postings takes ceil(X / 128) chunks, each visited twice -- and rebuilt the weight as
+// 766 ns x E[ceil(X_t / 128)] summed over the terms + 563 ns: modelled and measured visits per task then agree to 3 % per
+// query, the launch's span went 102 -> 98 us, and the plan kernel's Poisson sums cost 5-8 us, more than they returned (0.111
+// -> 0.116 ms at 10M docs, 0.046 -> 0.054 at a shard): not kept.  What is left of the spread -- mean 77 us, longest 98 -- is
+// granularity: a range holds whole (query, block) tasks, 5 or 6 of a big query's 13-us tasks.)
 
 struct BsArgs {
     const uint2 *postings;     // {doc_in_block, impact bits}, term-major
@@ -168,6 +174,13 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     uint32_t t_stores = 0, t_tasks = 0; // (TIMING) 64-key stores and tasks so far
     auto stamp = [&]() __attribute__((always_inline)) -> unsigned long long { return TIMING ? __builtin_amdgcn_s_memtime() : 0ull; };
     const unsigned long long t_wave0 = stamp();
+#ifdef OI_ABLATION
+    // OI_BM25_STREAM_TIMING=light: the PRODUCT instantiation with two constant-rate stamps per wave (start, end: s_memrealtime,
+    // 100 MHz, the same clock on every XCD) -- the stamped instantiation's s_memtime reads drain the LDS queue at every
+    // section and run 3.5x slower than this kernel, so its per-section shares are not this kernel's
+    const unsigned long long t_light0 = (!TIMING && a.timing) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t t_first_q = 0xFFFFFFFFu; // the first query of the wave's range (light records)
+#endif
     constexpr uint32_t WORDS = L::WORDS, WPL = WORDS / 64; // map words per lane in the sweep: 8 (W = 16384) or 16
     constexpr uint32_t NWB = BS_BLOCK / W;                  // windows per block: 2 or 1
     constexpr uint32_t WSTEP = W / BS_FINE;                 // cells per window: 1 or 2
@@ -546,6 +559,9 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         // ---- the query (plain loads: nothing is in flight here)
         const unsigned long long t_qs = stamp();
         t_q = r;
+#ifdef OI_ABLATION
+        if (t_first_q == 0xFFFFFFFFu) t_first_q = r;
+#endif
         t_tau_q = bs_rfl(s_tau[r]);
         q_tb = bs_rfl(a.q_offsets[a.q_begin + r]);
         q_T = bs_rfl(a.q_offsets[a.q_begin + r + 1]) - q_tb;
@@ -587,7 +603,14 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
             }
             if (TIMING) t_acc[4] += stamp() - t_tb;
             uint32_t inxt = 0;
-            if (win == 0) { start_task(blk); if (TIMING) ++t_tasks; }
+            if (win == 0) {
+                start_task(blk);
+#ifdef OI_ABLATION
+                ++t_tasks; // (the light records count tasks and visits too)
+#else
+                if (TIMING) ++t_tasks;
+#endif
+            }
             if (cur.slow) { // (nothing of this window is in the ring)
                 direct_runs(win, [&](uint32_t ix, uint32_t bit, uint32_t, float) __attribute__((always_inline)) { pass_a(ix, bit, 0u, 0u); });
                 sweep();
@@ -607,6 +630,9 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
                     for (uint32_t v = 0; v < C; ++v) { wait_oldest(); consume(cur, v, false); BS_REFILL(); }
                     sweep();
                     for (uint32_t v = 0; v < C; ++v) { wait_oldest(); consume(cur, v, true); BS_REFILL(); }
+#ifdef OI_ABLATION
+                    t_n_wait += V;
+#endif
                 } else {
                     for (uint32_t v = 0; v < C; ++v) {
                         const unsigned long long t0 = stamp(); wait_oldest();
@@ -652,6 +678,17 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         ch = G + bs_rfl(nx);
     }
     }
+#ifdef OI_ABLATION
+    if (!TIMING && a.timing && lane == 0 && w < 4096) {
+        unsigned long long *o = a.timing + 32 + 2048 * 4 + (unsigned long long)w * 4;
+        uint32_t xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[0] = t_light0; o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = ((unsigned long long)t_n_wait << 32) | t_tasks;
+        o[3] = ((unsigned long long)(xcc & 0xF) << 56) | ((unsigned long long)(hwid & 0xFFFFFF) << 32) | t_first_q;
+    }
+#endif
     if (TIMING && lane == 0 && a.timing) {
         const unsigned long long whole = stamp() - t_wave0;
         for (int i = 0; i < 8; ++i) atomicAdd(&a.timing[i], t_acc[i]);
@@ -802,6 +839,42 @@ int oi_launch_bm25_stream(oi_index *idx, const uint32_t *d_q_terms, const uint32
         return OI_OK;
     };
 #ifdef OI_ABLATION
+    if (oi_ablation_env("OI_BM25_STREAM_TIMING") && strcmp(oi_ablation_env("OI_BM25_STREAM_TIMING"), "light") == 0) {
+        DevBuf &tb = ctx->buf("bm25_stream_timing");
+        const size_t tbytes = (32 + 2048 * 4 + 4096 * 4) * sizeof(unsigned long long);
+        OI_CHECK(tb.ensure(tbytes));
+        OI_HIP_CHECK(hipMemsetAsync(tb.p, 0, tbytes, ctx->stream));
+        a.timing = tb.as<unsigned long long>();
+        OI_CHECK(launch(bm25_stream_kernel<BS_BLOCK>, BsLds<BS_BLOCK>::TOTAL));
+        OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        std::vector<unsigned long long> smp(32 + 2048 * 4 + 4096 * 4);
+        OI_HIP_CHECK(hipMemcpy(smp.data(), tb.p, smp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (unsigned i = 0; i < 4096; ++i) { const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)i * 4]; if (o[1]) { t0 = std::min(t0, o[0]); t1 = std::max(t1, o[1]); } }
+        double xs[16] = {0}, xe[16] = {0}, xb[16] = {0}, xl[16] = {0}; unsigned xn[16] = {0};
+        for (unsigned i = 0; i < 4096; ++i) {
+            const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)i * 4];
+            if (!o[1]) continue;
+            const unsigned x = (unsigned)(o[3] >> 56) & 15u;
+            xs[x] += (double)(o[1] - o[0]); xb[x] += (double)(o[0] - t0); xe[x] += (double)(o[1] - t0); xl[x] = std::max(xl[x], (double)(o[1] - t0)); ++xn[x];
+        }
+        fprintf(stderr, "[bm25 stream light] launch span %.1f us (100 MHz stamps)\n", (double)(t1 - t0) / 100.0);
+        if (const char *path = oi_ablation_env("OI_BM25_STREAM_LIGHT_CSV")) { // raw per-wave rows for a regression
+            if (FILE *f = fopen(path, "w")) {
+                fprintf(f, "wave,xcc,start_us,life_us,tasks,visits,first_q\n");
+                for (unsigned i = 0; i < 4096; ++i) {
+                    const unsigned long long *o = &smp[32 + 2048 * 4 + (size_t)i * 4];
+                    if (o[1]) fprintf(f, "%u,%u,%.2f,%.2f,%llu,%llu,%u\n", i, (unsigned)(o[3] >> 56) & 15u, (double)(o[0] - t0) / 100.0, (double)(o[1] - o[0]) / 100.0,
+                                      o[2] & 0xFFFFFFFFull, o[2] >> 32, (unsigned)(o[3] & 0xFFFFFFFFull));
+                }
+                fclose(f);
+            }
+        }
+        for (unsigned x = 0; x < 16; ++x)
+            if (xn[x]) fprintf(stderr, "[bm25 stream light xcc %u] waves %u: start +%.1f us, lifetime %.1f us, end +%.1f us (last +%.1f)\n", x, xn[x], xb[x] / xn[x] / 100.0,
+                               xs[x] / xn[x] / 100.0, xe[x] / xn[x] / 100.0, xl[x] / 100.0);
+        return OI_OK;
+    }
     if (oi_ablation_env("OI_BM25_STREAM_TIMING")) { // the stamped instantiation, sums and the first long waits printed per launch
         DevBuf &tb = ctx->buf("bm25_stream_timing");
         const size_t tbytes = (32 + 2048 * 4 + 4096 * 4) * sizeof(unsigned long long);

@@ -32,6 +32,12 @@ idx.set_forward(terms, offs)
 idx.set_max_query_terms(4)
 idx.finalize()
 qv, qt, qo = synth.query_batch_torch(B, DIM, dev)
+if os.environ.get("OI_BM25_DUMP_DF"):   # df of every query term (a weight-model check beside OI_BM25_STREAM_LIGHT_CSV)
+    dfv = torch.bincount(terms.to(torch.int64), minlength=synth.VOCAB)   # token counts ~ doc frequency (terms rarely repeat in a doc)
+    with open(os.environ["OI_BM25_DUMP_DF"], "w") as fh:
+        for b in range(B):
+            tq = qt[int(qo[b]):int(qo[b + 1])].to(torch.int64)
+            fh.write("%d,%s\n" % (b, ",".join(str(int(dfv[t])) for t in tq)))
 res = {}
 lists = {}
 MODES = (("stream", idx.BM25_STREAM), ("wave", idx.BM25_WAVE), ("taat", idx.BM25_TAAT), ("scan", idx.BM25_SCAN))
