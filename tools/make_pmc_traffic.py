@@ -43,8 +43,8 @@ for name, key in (("bm25_stream_kernel", "bm25_stream"), ("select_flat_kernel", 
             "lds_bank_conflict_cycles_frac": k.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, k.get("SQ_LDS_IDX_ACTIVE", 1.0)),
             "waves_waiting_frac": k.get("SQ_WAIT_ANY", 0.0) / max(1.0, k.get("SQ_WAVE_CYCLES", 1.0))}
 if "bm25_stream_kernel" in out:
-    out["bm25_stream_kernel"]["note"] = ("two launches per batch; the postings are read twice, the second time from L2 (the reads above are HBM: "
-                                         "the algorithmic bytes once); the writes are the emitted candidate keys")
+    out["bm25_stream_kernel"]["note"] = ("one launch per batch since the per-term impact floors (two before); the postings are read twice, the second "
+                                         "time from L2 (the reads above are HBM: the algorithmic bytes once); the writes are the emitted candidate keys")
 ex = x["cosine_ksplit"]
 out["exact_kernel"] = {
     "kernel": "cosine_ksplit16_filter<768,2>",
