@@ -60,6 +60,35 @@ def _check(L, b, ref, depth, n, base=0):
     assert (ref[d] >= kth - 2 * COS_TOL).all(), "a clearly worse doc is present"
 
 
+@pytest.mark.parametrize("shift", [-0.5, 0.0, 0.25])
+def test_margin_selects_on_negative_zero_and_clustered_scores(ctx, O, shift):
+    """Round 4: a margin select takes the lower edge of the k'-th key's 22-bit bin as its threshold, and the screen compares floats
+    where it compared keys.  Scores of one sign bit or the other, a k'-th score at exactly 0.0 (half the rows orthogonal to every
+    query), and thousands of scores inside one leading-digit bin: the lists must stay the exact scorer's (same bars as everywhere)."""
+    from openintel_amd import synth
+    n, dim, B = 70_000, 768, 40
+    rng = np.random.default_rng(int(100 + 10 * shift))
+    rows = synth.embeddings_np(n, dim, seed=901)
+    q = synth.embeddings_np(B, dim, seed=902)
+    axis = np.zeros(dim, np.float32)
+    axis[0] = 1.0
+    if shift == 0.0:
+        rows[::2, :] = 0.0           # every second row scores exactly 0 against every query ...
+        rows[::2, 1] = 1.0
+        q[:, 1] = 0.0                # ... because the queries have nothing in that coordinate
+    else:
+        q = (q + shift * 8.0 * axis).astype(np.float32)        # all scores move by shift * 8 * x_0: one sign for most rows
+        rows[:, 0] = np.abs(rows[:, 0])                         # (shift < 0: negative scores, shift > 0: positive)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50, base=5)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    for depth in (100, 1000):
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        for b in range(0, B, 5):
+            _check(L, b, O.dot_scores(rows, q[b]), depth, n, base=5)
+    idx.close()
+
+
 @pytest.mark.parametrize("B,dim,n", [(9, 768, 5000), (40, 768, 9000), (64, 768, 60_000), (70, 384, 6000),
                                      (33, 384, 40_000), (130, 768, 3000), (64, 768, 300_000)])
 def test_screened_lists_meet_the_exact_bar(ctx, O, B, dim, n):
