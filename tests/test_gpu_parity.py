@@ -832,6 +832,70 @@ def test_full_size_bm25_bench_shape_against_the_oracle(ctx, O):
     idx.close()
 
 
+def test_full_size_config3_eight_shards_compose_to_the_single_index(ctx):
+    """BASELINE configs[3] composed at FULL size on one GPU: the 10M x 768 corpus as EIGHT row shards of 1.25M (doc_id_base =
+    first row, global N / token count / df handed to every finalize -- what the all-reduce delivers), every shard's packed
+    lists concatenated in rank order (what the all-gather delivers) and fused with oi_fuse_packed -- against oi_search on ONE
+    index over the same 10M rows.  Small-integer embeddings: every dot product is exact in any summation order, so the cosine
+    lists, the BM25 lists (global statistics: the same f32 operations) and the fused top-100 must be equal bit for bit."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import synth
+    dev = torch.device("cuda:0")
+    n, dim, B, depth, k, S, vocab = 10_000_000, 768, 64, 1000, 100, 8, 131072
+    g = torch.Generator(device=dev)
+    g.manual_seed(83)
+    rows = torch.empty((n, dim), dtype=torch.float32, device=dev)
+    for s0 in range(0, n, 1 << 20):      # small integers, chunk by chunk (randint's int64 scratch stays small)
+        e0 = min(n, s0 + (1 << 20))
+        rows[s0:e0] = torch.randint(-3, 4, (e0 - s0, dim), generator=g, device=dev).to(torch.float32)
+    qv = torch.randint(-3, 4, (B, dim), generator=g, device=dev).to(torch.float32)
+    _, qt, qo = synth.query_batch_torch(B, dim, dev, vocab=vocab)
+    terms, offs = synth.forward_index_torch(n, dev, vocab=vocab)
+    one = oi.HybridIndex(ctx, n, dim, vocab)
+    one.set_embeddings(rows, normalize=False)
+    one.set_forward(terms, offs)
+    one.set_max_query_terms(4)
+    one.finalize()
+    R = one.search(qv, qt, qo, k=k, depth=depth)
+    L = one.search_lists(qv, qt, qo, depth=depth)
+    ctx.synchronize()
+    want = (R.docs.clone(), R.scores.clone(), R.counts.clone())
+    want_l = [t.clone() for t in (L.cos_docs, L.cos_scores, L.bm25_docs, L.bm25_scores, L.bm25_counts)]
+    one.close()
+    del one, R, L
+    bounds = [(r * n // S, (r + 1) * n // S) for r in range(S)]
+    shards, tot, gdf = [], 0, None
+    for lo, hi in bounds:
+        t_lo, t_hi = int(offs[lo]), int(offs[hi])
+        ix = oi.HybridIndex(ctx, hi - lo, dim, vocab, doc_id_base=lo)
+        ix.set_embeddings(rows[lo:hi], normalize=False)
+        ix.set_forward(terms[t_lo:t_hi].contiguous(), (offs[lo:hi + 1] - offs[lo]).contiguous())
+        ix.set_max_query_terms(4)
+        t, df = ix.local_stats()
+        tot += t
+        gdf = df.astype(np.uint64) if gdf is None else gdf + df
+        shards.append(ix)
+    del rows
+    for ix in shards:
+        ix.finalize(n, tot, gdf.astype(np.uint32))
+    packed = torch.cat([ix.search_lists_packed(qv, qt, qo, depth=depth) for ix in shards])
+    F = oi.fuse_packed(ctx, packed, S, B, depth, k)
+    lists = [ix.search_lists(qv, qt, qo, depth=depth) for ix in shards]
+    st = lambda f: torch.stack([getattr(l, f) for l in lists])
+    ms, md, mc = oi.merge_lists(ctx, st("cos_scores"), st("cos_docs"), st("cos_counts"))
+    bs, bd, bc = oi.merge_lists(ctx, st("bm25_scores"), st("bm25_docs"), st("bm25_counts"))
+    ctx.synchronize()
+    assert torch.equal(F.docs, want[0]) and torch.equal(F.scores, want[1]) and torch.equal(F.counts, want[2])
+    assert torch.equal(md, want_l[0]) and torch.equal(ms, want_l[1])
+    assert torch.equal(bc, want_l[4])
+    for b in range(B):
+        c = int(bc[b])
+        assert torch.equal(bd[b, :c], want_l[2][b, :c]) and torch.equal(bs[b, :c], want_l[3][b, :c])
+    for ix in shards:
+        ix.close()
+
+
 def test_full_size_config3_shard_through_sharded_retriever(ctx, O):
     """BASELINE configs[3] as ONE GPU of the 8 sees it: a 1.25M-row x 768-d f32 shard with a nonzero doc_id_base,
     driven through ShardedRetriever (world 1: finalize's statistics exchange and the packed list format are the
