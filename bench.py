@@ -86,7 +86,9 @@ def cpu_baseline(n_total, dim, vocab, depth, k, sample_docs, sample_queries):
         "single_thread": {"value": single, "unit": "queries/s", "cores": 1,
                           "sample": "%d queries against the same %d-doc slice, one thread (%.1f s)" % (n_q1, sample_docs, dt1)},
         "nproc": nproc, "parallel_speedup": blocked / single,
-        "compiler": O.CFLAGS, "label": "build's CPU restatement (scalar C oracle), not the reference's Rust",
+        "compiler": O.CFLAGS,
+        "label": "build's CPU restatement (scalar C oracle), not the reference's Rust; EXTRAPOLATED x%g: measured on a %d-doc slice, "
+                 "scaled to %d docs (linear in corpus size)" % (n_total / sample_docs, sample_docs, n_total),
     }
 
 
@@ -139,10 +141,13 @@ def main():
                          "taat: the first-generation workgroup kernel)")
     ap.add_argument("--corpus", choices=["f32", "bf16"], default="f32",
                     help="embedding storage (default f32 = BASELINE configs[1]/[2]; bf16 = the configs[4] regime, HBM-bound)")
-    ap.add_argument("--cosine", choices=["screen", "exact", "split", "screen-copy"], default="screen",
+    ap.add_argument("--cosine", choices=["screen", "exact", "split", "screen-copy", "screen-stream"], default="screen",
                     help="f32 corpus scorer: a bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
-                         "(default: the exact scorer's lists, HBM-bound), exact f32 MFMA for every row, or split-precision "
-                         "products (six bf16 MFMAs)")
+                         "(default: the exact scorer's lists, HBM-bound; the screen streams the index's bf16 screening copy, "
+                         "made at finalize), screen-stream (the same screen converting the f32 rows on the fly: rounds 1-4's "
+                         "default), exact f32 MFMA for every row, or split-precision products (six bf16 MFMAs)")
+    ap.add_argument("--no-screen-copy-index", action="store_true",
+                    help="oi_index_set_screen_copy(NEVER): the index holds no bf16 screening copy (the default scorer then streams the f32 rows)")
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: do not overlap exchange + fusion with the next batch's lists")
     ap.add_argument("--lanes", type=int, default=2,
@@ -151,7 +156,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--settle-steps", type=int, default=0,
                     help="untimed steps (x the number of ranks) before the warm-up (an experiment: no effect measured, round 4); 0 = none")
-    ap.add_argument("--no-screen-copy", action="store_true", help="skip the opt-in screen-copy side measurement")
+    ap.add_argument("--no-stream-side", action="store_true", help="skip the f32-stream screen's side measurement (f32_stream_scorer)")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
     ap.add_argument("--latency-batches", type=int, default=200, help="timed batches of the latency loops (SURVEY 8d: >= 200)")
@@ -206,7 +211,7 @@ def main():
     ctx.use_torch_current_stream()
     from openintel_amd import _lib as _oil
     MODES = {"screen": _oil.OI_COSINE_SCREEN, "exact": _oil.OI_COSINE_EXACT, "split": _oil.OI_COSINE_SPLIT,
-             "screen-copy": _oil.OI_COSINE_SCREEN_COPY}
+             "screen-copy": _oil.OI_COSINE_SCREEN_COPY, "screen-stream": _oil.OI_COSINE_SCREEN_STREAM}
     ctx.set_cosine_mode(MODES[args.cosine])
 
     # ---------------------------------------------------------------- corpus shard in HBM
@@ -221,6 +226,8 @@ def main():
         idx.set_embeddings_bf16(rows)
     else:
         idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
+    if args.no_screen_copy_index:
+        idx.set_screen_copy(idx.SCREEN_COPY_NEVER)
     idx.set_forward(terms, offs)
     idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
     idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE, "stream": idx.BM25_STREAM}[args.bm25])
@@ -232,6 +239,10 @@ def main():
         sr.exchange = True
     sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
     _, df_local = idx.local_stats()                    # for the BM25 leg's algorithmic bytes (rank 0 reports)
+    rows_owned_b, screen_copy_b, bm25_index_b = idx.index_bytes()
+    # what the default scorer's screen streams on this rank: the index's bf16 screening copy if finalize made it
+    copy_streamed = (args.corpus == "f32" and args.cosine in ("screen", "screen-copy") and args.batch > 8 and args.dim in (384, 768)
+                     and (screen_copy_b > 0 or args.cosine == "screen-copy"))
     # Distinct query batches rotated through the steps (step i uses batch i mod NB): no step can profit from the
     # previous step's thresholds, pools or cache contents being those of the same queries.
     NB = max(1, args.query_batches)
@@ -356,6 +367,7 @@ def main():
     # The default scorer screens in bf16 and rescores exactly; the same batch through the exact f32 MFMA kernel for
     # every row is measured beside it (untimed steps), so that the line carries both scorers.
     exact_side = None
+    stream_side = None
     if args.cosine == "screen" and args.corpus == "f32" and args.batch > 8:
         gate_opened = ctx.profile_read("screen_gate")[0]
         ctx.set_cosine_mode(MODES["exact"])
@@ -377,10 +389,10 @@ def main():
                       "mfma_frac": 2.0 * n_local * args.dim * args.batch * ex_steps / (ex_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                       "note": "same batch, same K steps, oi_set_cosine_mode(OI_COSINE_EXACT): f32 MFMA for every row (rank 0's clock, outside the headline's timed region)"}
         screen_fallback = gate_opened != 0.0
-        # opt-in OI_COSINE_SCREEN_COPY beside it (same lists; the screen reads a bf16 copy of the rows: half the bytes)
-        copy_side = None
-        if args.dim in (384, 768) and not args.no_screen_copy:
-            ctx.set_cosine_mode(MODES["screen-copy"])
+        # rounds 1-4's default beside it: the same screen converting the f32 rows on the fly (4 d bytes per row instead of 2 d)
+        stream_side = None
+        if copy_streamed and not args.no_stream_side:
+            ctx.set_cosine_mode(MODES["screen-stream"])
             step(); step()
             fence()
             ctx.profile_reset(2)
@@ -389,16 +401,16 @@ def main():
             for _ in range(ex_steps):
                 step()
             fence()
-            cp_elapsed = time.perf_counter() - t1
-            cp_ms, cp_launches = ctx.profile_read("cosine")
+            st_elapsed = time.perf_counter() - t1
+            st_ms, st_launches = ctx.profile_read("cosine")
             ctx.profile_reset(False)
             ctx.set_cosine_mode(MODES["screen"])
-            copy_side = {"ms_per_step": cp_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / cp_elapsed, "steps": ex_steps,
-                         "screen_ms_per_step": cp_ms / ex_steps,
-                         "hbm_frac_on_its_bytes": 2.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (cp_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
-                         "extra_hbm_bytes": 2 * n_local * args.dim,
-                         "note": "OPT-IN mode oi_set_cosine_mode(OI_COSINE_SCREEN_COPY), not the headline: same bound, same exact f32 rescoring, "
-                                 "identical lists (tests/test_gpu_prefilter.py); the screen streams a bf16 copy (+50 % corpus memory)"}
+            stream_side = {"ms_per_step": st_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / st_elapsed, "steps": ex_steps,
+                           "screen_ms_per_step": st_ms / ex_steps,
+                           "hbm_frac_on_its_bytes": 4.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (st_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                           "note": "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM): rounds 1-4's headline -- the same bound, the same survivors, the same "
+                                   "exact f32 rescoring, identical lists (tests/test_gpu_prefilter.py); the screen converts the f32 rows on the fly "
+                                   "(4 d bytes per row and batch)"}
 
     # ---------------------------------------------------------------- latency: >= 200 timed batches after 20 warm-ups,
     # whatever --steps says.  (a) device-resident: HIP events on the launch stream around ONE batch at a time (queries and
@@ -464,17 +476,17 @@ def main():
         # keeps the queries in registers takes one corpus pass per 64 queries (bf16 corpus, d = 1024: 64 per pass of
         # the pair kernel): its extra passes are re-reads and count AGAINST it here (frac falls), never for it.
         bytes_step = (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim
-        if args.corpus == "f32" and args.cosine == "screen-copy":
-            bytes_step = 2.0 * n_local * args.dim   # what that (opt-in) mode's screen has to read once per batch
+        if copy_streamed:
+            bytes_step = 2.0 * n_local * args.dim   # the screen streams the index's bf16 screening copy: 2 d bytes per row, once per batch
         passes = (args.batch + 63) // 64 if args.batch > 8 else 1
-        if args.corpus == "bf16" or args.cosine == "screen-copy":   # the bf16-corpus scorer's plan (cosine_bf16.hip, cb_group)
+        if args.corpus == "bf16":   # the bf16-corpus scorer's plan (cosine_bf16.hip, cb_group)
             left, passes, solo = args.batch, 0, (32 if args.dim == 1024 else 64)
             while left > 0:
                 g = solo if left <= solo else (128 if left > 96 else 96) if args.dim == 1024 else (96 if (left + 95) // 96 < (left + 63) // 64 else 64)
                 left -= min(g, left)
                 passes += 1
         cos_s = cos_ms / 1e3 if cos_ms > 0 else float('nan')   # (nan: OI_BENCH_NO_LIVE_EVENTS, an experiment without the kernel's events)
-        if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine == "screen" and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
+        if args.batch > 8 and args.corpus == "f32" and args.cosine == "exact" or (args.cosine in ("screen", "screen-copy", "screen-stream") and args.dim not in (384, 768) and args.batch > 8 and args.corpus == "f32"):
             roof = {"bound": "mfma", "achieved": flops_step * args.steps / cos_s / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s"}
         else:
@@ -487,8 +499,9 @@ def main():
         if os.path.exists(pmc) and (args.docs, args.dim, args.batch, world, args.corpus) == (10_000_000, 768, 64, 1, "f32"):
             try:
                 pm = json.load(open(pmc))   # the screen kernel's counters; the exact kernel's under "exact_kernel"
-                roof["traffic"] = (pm if args.cosine == "screen" else pm.get("exact_kernel", {}) if args.cosine == "exact"
-                                   else {}).get("cosine_hbm_bytes_per_launch")
+                roof["traffic"] = (pm if (args.cosine in ("screen", "screen-copy") and copy_streamed and "cosine_copy_screen" in pm.get("kernel", ""))
+                                   else pm.get("f32_stream_kernel", {}) if args.cosine in ("screen", "screen-stream") and not copy_streamed
+                                   else pm.get("exact_kernel", {}) if args.cosine == "exact" else {}).get("cosine_hbm_bytes_per_launch")
                 roof["traffic_source"] = ("NOT measured in this run: read from the committed profiles/pmc_traffic.json (%s), a separate "
                                           "rocprofv3 --pmc pass of this workload (tools/pmc_profile.sh; FETCH_SIZE/WRITE_SIZE with the "
                                           "guide's gfx950 corrections), per launch" % pm.get("source", "see file"))
@@ -499,8 +512,13 @@ def main():
             roof["kernel"] = "cosine over the bf16 corpus (bf16 MFMA, all corpus-chunk launches of a batch)"
         roof["corpus_passes_per_batch"] = passes
         roof["hbm_GBs_streamed"] = bytes_step * passes * args.steps / (cos_ms / 1e3) / 1e9
-        if args.cosine == "screen" and roof["bound"] == "hbm" and args.batch > 8 and args.corpus == "f32":
-            roof["kernel"] = "cosine screen (bf16 MFMA over the f32 corpus, all corpus-chunk launches of a batch)"
+        if args.cosine in ("screen", "screen-copy", "screen-stream") and roof["bound"] == "hbm" and args.batch > 8 and args.corpus == "f32":
+            roof["kernel"] = ("cosine_copy_screen (bf16 MFMA over the index's bf16 screening copy, all corpus-chunk launches of a batch)" if copy_streamed
+                              else "cosine_screen_filter (bf16 MFMA over the f32 corpus converted on the fly, all corpus-chunk launches of a batch)")
+            roof["algorithmic_bytes_per_launch"] = bytes_step / max(1.0, cos_launches / max(1, args.steps))
+            roof["algorithmic_bytes_note"] = ("%d rows x %d dims x %d B, read once per 64-query batch by the screen; the exact f32 rescoring of the "
+                                              "~2.45 k' survivors per query (~0.48 GB of scattered 3-KB f32 rows per batch at 10M x 768) is a separate "
+                                              "kernel (other_kernels_ms_per_step.rescore)" % (n_local, args.dim, 2 if copy_streamed else 4))
         roof["launches_per_step"] = cos_launches / max(1, args.steps)
         roof["avg_launch_ms"] = cos_ms / max(1, cos_launches)
         roof["kernel_ms_per_step"] = cos_ms / max(1, args.steps)
@@ -534,11 +552,17 @@ def main():
                        "docs": args.docs, "dim": args.dim, "batch": args.batch, "k": args.k, "depth": args.depth,
                        "vocab": args.vocab, "docs_per_gpu": n_local, "tokens_rank0": n_tokens_local,
                        "query_batches_rotated": NB, "settle_steps": settle_steps,
-                       "cosine_scorer": {"screen": "bf16 screen with a proven error bound + exact f32 rescoring of the survivors "
-                                                   "(the exact scorer's lists; gated exact fallback)",
+                       "cosine_scorer": {"screen": "bf16 screen with a proven error bound + exact f32 rescoring of the survivors from the f32 rows "
+                                                   "(the exact scorer's lists; gated exact fallback); the screen streams " +
+                                                   ("the index's bf16 screening copy (made at finalize, +%.2f GB of HBM)" % (screen_copy_b / 1e9) if copy_streamed
+                                                    else "the f32 rows, converted on the fly (the index holds no screening copy)"),
                                          "exact": "f32 MFMA for every row", "split": "bf16x3 split products",
-                                         "screen-copy": "bf16 screen over a bf16 COPY of the rows (opt-in) + exact f32 rescoring"}[args.cosine]
+                                         "screen-copy": "bf16 screen over the bf16 screening copy (made on first use if missing) + exact f32 rescoring",
+                                         "screen-stream": "bf16 screen over the f32 rows converted on the fly + exact f32 rescoring (rounds 1-4's default)"}[args.cosine]
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
+                       "index_GB": {"rows_owned_by_library": rows_owned_b / 1e9, "rows_borrowed_from_caller": (0.0 if rows_owned_b else
+                                    (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim / 1e9),
+                                    "screening_copy": screen_copy_b / 1e9, "bm25_structures": bm25_index_b / 1e9},
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
                                       ("; %d batches' lists in flight per rank, each through its own view of the shard" % len(lane_ctxs)
@@ -576,14 +600,16 @@ def main():
                                      "note": "algorithmic bytes = 8 B x postings of the batch's terms + 12 B (stream; 8 B wave) x (blocks x "
                                              "terms); at this batch size the kernel is latency/issue-bound, not byte-bound (DESIGN 4.3)"}
         if exact_side is not None:
-            line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring, bound hbm; "
-                                     "round 2: error bound re-derived from measured rounding errors and adversarially tested, "
-                                     "DESIGN 4.1a). The north star's f32-MFMA GEMM over every row is exact_scorer, same K steps; "
-                                     "--cosine exact makes it the headline.")
+            line["headline_note"] = ("value/roofline are the default SCREENED scorer (bf16 screen + exact f32 rescoring from the f32 rows, bound hbm; "
+                                     "error bound built from measured rounding errors and adversarially tested, DESIGN 4.1). Round 5: the screen "
+                                     "streams the index's bf16 screening copy (a derived structure made at finalize, like the BM25 impact postings): "
+                                     "roofline is computed on THAT kernel's bytes (2 d per row). f32_stream_scorer = rounds 1-4's headline (the same "
+                                     "screen over the f32 rows, identical lists); exact_scorer = the north star's f32-MFMA GEMM over every row; "
+                                     "same K steps each; --cosine screen-stream / exact make them the headline.")
             line["exact_scorer"] = exact_side
             line["screen_fell_back_to_exact"] = screen_fallback
-            if copy_side is not None:
-                line["screen_copy_scorer"] = copy_side
+            if stream_side is not None:
+                line["f32_stream_scorer"] = stream_side
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)

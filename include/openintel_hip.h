@@ -96,27 +96,36 @@ int oi_set_stream(oi_ctx *ctx, void *hip_stream);
 int oi_synchronize(oi_ctx *ctx);
 
 /* How the batch cosine scorer works over an f32 corpus (dim 384 / 768, more than 8 queries; other shapes
- * always use the exact kernels).  The corpus stays f32 in HBM in every mode.
+ * always use the exact kernels).  The corpus handed to the library stays f32 in HBM in every mode, and every score the
+ * library returns is computed in f32 from those f32 rows.
  *   OI_COSINE_SCREEN (default) a bf16 screen with a proven error bound picks the rows that can reach the list
- *                              (one bf16 MFMA per product, rows converted on the fly: HBM-bound; the bound is
- *                              built from the MEASURED rounding errors of the corpus and of each query), exact f32
- *                              scores are then computed for those rows only; a query whose survivors do not fit
- *                              falls back, inside the same call, to the exact kernel.  The lists are the exact
- *                              scorer's (csrc/cosine_prefilter.hip has the argument).
+ *                              (one bf16 MFMA per product: HBM-bound; the bound is built from the MEASURED rounding
+ *                              errors of the corpus and of each query), exact f32 scores are then computed for those
+ *                              rows only; a query whose survivors do not fit falls back, inside the same call, to the
+ *                              exact kernel.  The screen reads the index's bf16 SCREENING COPY of the rows when the
+ *                              index holds one (oi_index_set_screen_copy: made at finalize when it fits the budget --
+ *                              2 d bytes per row and batch) and converts the f32 rows on the fly otherwise (4 d bytes).
+ *                              Same products, same bound, same survivors, same rescoring either way.
+ *                              What comes out: the SET of rows of the exact scorer's list up to ties -- two rows whose
+ *                              exact f32 scores differ by less than the f32 rounding of two summation orders (measured
+ *                              <= 5e-7 at d = 768) may swap neighbouring ranks or, at the list's last rank, places;
+ *                              every score within the 1e-5 bar (csrc/cosine_prefilter.hip has the argument).  RRF
+ *                              output is bit-exact GIVEN the two lists.
  *   OI_COSINE_EXACT            v_mfma_f32_* on the f32 values for every row: matrix-pipe-bound.
  *   OI_COSINE_SPLIT            every f32 operand is split exactly into three bf16 values and the dot product
  *                              taken as six bf16 MFMAs with f32 accumulation (the three smallest of the nine
  *                              cross terms, <= 2^-23 relative, are dropped): f32-grade scores (measured error
  *                              vs f64 ~4e-8 on unit vectors; the exact kernel's f32 accumulation ~1e-7).
- *   OI_COSINE_SCREEN_COPY      (opt-in) OI_COSINE_SCREEN with the screen reading a bf16 COPY of the rows, made by the
- *                              library on first use (n_docs x dim x 2 bytes of HBM on top of the f32 corpus) with the
- *                              screen's own conversion: the same products, the same bound, the same exact f32
- *                              rescoring from the f32 rows -- the same lists -- at half the screen's bytes per row.
- * Also selectable with OI_COSINE_MODE=screen|exact|split|screen-copy at oi_create. */
+ *   OI_COSINE_SCREEN_COPY      OI_COSINE_SCREEN, and an index without a screening copy gets one on the first search
+ *                              whatever its policy (rounds 2-4's opt-in mode; kept for callers that used it).
+ *   OI_COSINE_SCREEN_STREAM    OI_COSINE_SCREEN with the screen ALWAYS converting the f32 rows on the fly, copy or not
+ *                              (rounds 1-4's default; A/B runs and bench.py's `f32_stream_scorer`).
+ * Also selectable with OI_COSINE_MODE=screen|exact|split|screen-copy|screen-stream at oi_create. */
 #define OI_COSINE_EXACT 0
 #define OI_COSINE_SPLIT 1
 #define OI_COSINE_SCREEN 2
 #define OI_COSINE_SCREEN_COPY 3
+#define OI_COSINE_SCREEN_STREAM 4
 int oi_set_cosine_mode(oi_ctx *ctx, int mode);
 
 /* A hybrid query has two independent legs until fusion.  By default the BM25 leg is issued on an
@@ -300,6 +309,29 @@ int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t global_tot
  * built from the other rows' maxima.  0: one class (a normalised corpus, or too many such rows).  Builder-defined like the
  * whole retrieval path (the reference has no embeddings: SURVEY.md section 0). */
 int oi_index_long_rows(oi_index *idx, uint32_t *n_out);
+
+/* The bf16 SCREENING COPY of an f32 corpus: a derived index structure like the BM25 impact postings -- bf16(x) of every
+ * row, made by the library with the screen's own conversion (so the measured error bound of OI_COSINE_SCREEN is the copy's),
+ * n_docs x dim x 2 bytes of HBM on top of the f32 rows.  The screen streams it instead of the f32 rows (half the bytes of
+ * an HBM-bound kernel); survivors are still rescored in f32 from the f32 rows, so the lists do not change.
+ *   OI_SCREEN_COPY_AUTO (default)  made by oi_index_finalize / oi_index_finalize_sharded (and again by
+ *                                  oi_index_set_embeddings on a finalized index) when the corpus can be screened (dim 384 /
+ *                                  768, finite norms) and the copy is at most a quarter of the device memory that is FREE at
+ *                                  that moment (OI_SCREEN_COPY_MAX_FRAC=0.25 overrides the fraction); otherwise no copy:
+ *                                  the screen converts the f32 rows on the fly.
+ *   OI_SCREEN_COPY_NEVER           no copy (an existing one is freed).
+ *   OI_SCREEN_COPY_ALWAYS          made whatever the budget (OI_ERR_HIP if the allocation fails).
+ * Call before finalize (or any time: a finalized index applies the policy at once).  OI_SCREEN_COPY=auto|never|always sets
+ * the process-wide default.  Views (oi_index_view) borrow the source's copy.  No reference counterpart (the reference has no
+ * embeddings: SURVEY.md section 0). */
+#define OI_SCREEN_COPY_AUTO 0
+#define OI_SCREEN_COPY_NEVER 1
+#define OI_SCREEN_COPY_ALWAYS 2
+int oi_index_set_screen_copy(oi_index *idx, int policy);
+/* HBM the index itself holds right now (oi_workspace_bytes reports the searching contexts' workspaces): the embedding
+ * rows as handed over (0 when the caller's device pointer is borrowed), the screening copy, and the BM25 structures
+ * (postings, cell table, idf / floors, doc lengths, the kept forward index).  Any output may be NULL. */
+int oi_index_bytes(oi_index *idx, uint64_t *rows_owned_bytes_out, uint64_t *screen_copy_bytes_out, uint64_t *bm25_bytes_out);
 
 /* BM25 kernel choice: 0 = default (= 4), 1 = term-at-a-time with one workgroup per doc block (bm25.hip, the
  * first-generation kernel), 2 = batch scan of the forward index (bm25_scan.hip), 3 = term-at-a-time with one wave

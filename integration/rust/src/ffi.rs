@@ -40,6 +40,10 @@ pub const OI_COSINE_EXACT: c_int = 0;
 pub const OI_COSINE_SPLIT: c_int = 1;
 pub const OI_COSINE_SCREEN: c_int = 2;
 pub const OI_COSINE_SCREEN_COPY: c_int = 3;
+pub const OI_COSINE_SCREEN_STREAM: c_int = 4;
+pub const OI_SCREEN_COPY_AUTO: c_int = 0;
+pub const OI_SCREEN_COPY_NEVER: c_int = 1;
+pub const OI_SCREEN_COPY_ALWAYS: c_int = 2;
 
 extern "C" {
     pub fn oi_abi_version() -> c_int;
@@ -99,6 +103,9 @@ extern "C" {
     pub fn oi_index_finalize(idx: *mut OiIndex, global_n_docs: u64, global_total_tokens: u64,
                              global_df_host: *const u32) -> c_int;
     pub fn oi_index_long_rows(idx: *mut OiIndex, n_out: *mut u32) -> c_int;
+    pub fn oi_index_set_screen_copy(idx: *mut OiIndex, policy: c_int) -> c_int;
+    pub fn oi_index_bytes(idx: *mut OiIndex, rows_owned_bytes_out: *mut u64, screen_copy_bytes_out: *mut u64,
+                          bm25_bytes_out: *mut u64) -> c_int;
     pub fn oi_index_set_bm25_mode(idx: *mut OiIndex, mode: c_int) -> c_int;
     pub fn oi_index_set_max_query_terms(idx: *mut OiIndex, max_terms: u32) -> c_int;
 

@@ -18,7 +18,8 @@ OI_MAX_DEPTH = 1024
 OI_MAX_DIM = 1024
 OI_BM25_BLOCK_DOCS = 32768
 OI_N_CATALYST_KEYWORDS = 16
-OI_COSINE_EXACT, OI_COSINE_SPLIT, OI_COSINE_SCREEN, OI_COSINE_SCREEN_COPY = 0, 1, 2, 3
+OI_COSINE_EXACT, OI_COSINE_SPLIT, OI_COSINE_SCREEN, OI_COSINE_SCREEN_COPY, OI_COSINE_SCREEN_STREAM = 0, 1, 2, 3, 4
+OI_SCREEN_COPY_AUTO, OI_SCREEN_COPY_NEVER, OI_SCREEN_COPY_ALWAYS = 0, 1, 2
 
 OI_ERR_INVALID_ARG = -1
 OI_ERR_HIP = -2
@@ -86,6 +87,8 @@ SIGNATURES = {
     "oi_index_set_max_query_terms": (_I, [_P, _U32]),
     "oi_index_set_bm25_mode": (_I, [_P, _I]),
     "oi_index_long_rows": (_I, [_P, C.POINTER(C.c_uint32)]),
+    "oi_index_set_screen_copy": (_I, [_P, _I]),
+    "oi_index_bytes": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64), C.POINTER(_U64)]),
     "oi_index_finalize": (_I, [_P, _U64, _U64, _P]),
     "oi_search_lists": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P, _P, _P, _P, _P, _P]),
     "oi_search_lists_packed": (_I, [_P, _P, _P, _P, _U32, _U32, _I, _P]),

@@ -44,9 +44,10 @@ class HipContext:
         _lib.check(self.lib.oi_synchronize(self.handle))
 
     def set_cosine_mode(self, mode: int) -> None:
-        """_lib.OI_COSINE_SCREEN (default: bf16 screen with a proven bound + exact f32 rescoring, HBM-bound),
-        _lib.OI_COSINE_EXACT (f32 MFMA for every row), _lib.OI_COSINE_SPLIT (six bf16 MFMAs per f32 product) or
-        _lib.OI_COSINE_SCREEN_COPY (opt-in: the screen reads a bf16 copy of the rows the library makes on first use)."""
+        """_lib.OI_COSINE_SCREEN (default: bf16 screen with a proven bound + exact f32 rescoring, HBM-bound; the screen
+        streams the index's bf16 screening copy when it holds one, the f32 rows otherwise), _lib.OI_COSINE_EXACT (f32 MFMA
+        for every row), _lib.OI_COSINE_SPLIT (six bf16 MFMAs per f32 product), _lib.OI_COSINE_SCREEN_COPY (screen; a missing
+        copy is made on first use) or _lib.OI_COSINE_SCREEN_STREAM (screen, always over the f32 rows)."""
         _lib.check(self.lib.oi_set_cosine_mode(self.handle, int(mode)))
 
     def set_overlap(self, enable: bool) -> None:

@@ -272,12 +272,16 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
     c->stream = nullptr;
     if (const char *m = getenv("OI_COSINE_MODE"))
         c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "exact") == 0 ? OI_COSINE_EXACT
-                         : strcmp(m, "screen-copy") == 0 ? OI_COSINE_SCREEN_COPY : OI_COSINE_SCREEN;
+                         : strcmp(m, "screen-copy") == 0 ? OI_COSINE_SCREEN_COPY
+                         : strcmp(m, "screen-stream") == 0 ? OI_COSINE_SCREEN_STREAM : OI_COSINE_SCREEN;
     // best effort: without these the two legs of a query simply run one after the other
     // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) c->ev_fork = nullptr;
-    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) c->ev_join = nullptr;
+    // (fork / join ORDER the side stream's kernels against the main stream's through hipStreamWaitEvent: they keep the default
+    // fence -- hipEventDisableSystemFence is documented for timing events only; the ~12 us it saved per step in round 4 rested
+    // on the kernels' own release semantics, an implementation detail of the runtime)
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) c->ev_fork = nullptr;
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) c->ev_join = nullptr;
     *out = c;
     return OI_OK;
 }
@@ -342,7 +346,8 @@ extern "C" int oi_set_stream(oi_ctx *ctx, void *hip_stream) {
 
 extern "C" int oi_set_cosine_mode(oi_ctx *ctx, int mode) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
-    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT || mode == OI_COSINE_SCREEN || mode == OI_COSINE_SCREEN_COPY,
+    OI_REQUIRE(mode == OI_COSINE_EXACT || mode == OI_COSINE_SPLIT || mode == OI_COSINE_SCREEN || mode == OI_COSINE_SCREEN_COPY ||
+                   mode == OI_COSINE_SCREEN_STREAM,
                "oi_set_cosine_mode: unknown mode %d", mode);
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->cosine_mode = mode;
@@ -776,7 +781,7 @@ extern "C" int oi_index_view(oi_index *src, oi_ctx *ctx, oi_index **out) {
     v->is_view = true;
     v->n_docs = src->n_docs; v->dim = src->dim; v->vocab = src->vocab; v->doc_id_base = src->doc_id_base;
     v->rows = src->rows; v->rows_bf16 = src->rows_bf16; // rows_owned / rows_bf16_owned stay false
-    v->screen_ok = src->screen_ok;
+    v->screen_ok = src->screen_ok; v->screen_copy_policy = src->screen_copy_policy;
     v->forward_set = src->forward_set; v->finalized = true;
     v->total_tokens = src->total_tokens; v->n_postings = src->n_postings; v->n_blocks = src->n_blocks; v->n_win = src->n_win;
     v->avgdl = src->avgdl; v->max_query_terms = src->max_query_terms; v->bm25_mode = src->bm25_mode;
@@ -822,6 +827,75 @@ extern "C" void oi_index_destroy(oi_index *idx) {
         if (idx->ctx->side_stream) (void)hipStreamSynchronize(idx->ctx->side_stream);
     }
     index_release(idx);
+}
+
+// The bf16 screening copy of an f32 corpus (include/openintel_hip.h: oi_index_set_screen_copy).  Called with the ctx mutex
+// held, at finalize and whenever the rows or the policy of a finalized index change.  AUTO: only when the corpus can be
+// screened at all and n x d x 2 bytes are at most a quarter (OI_SCREEN_COPY_MAX_FRAC) of the device memory free right now.
+static int default_screen_copy_policy() {
+    static const int p = [] {
+        const char *e = getenv("OI_SCREEN_COPY");
+        return !e ? OI_SCREEN_COPY_AUTO : strcmp(e, "never") == 0 ? OI_SCREEN_COPY_NEVER : strcmp(e, "always") == 0 ? OI_SCREEN_COPY_ALWAYS
+                                                                                                                  : OI_SCREEN_COPY_AUTO;
+    }();
+    return p;
+}
+static int apply_screen_copy_policy(oi_index *idx) {
+    oi_ctx *ctx = idx->ctx;
+    if (idx->is_view) return OI_OK;
+    const int policy = idx->screen_copy_policy < 0 ? default_screen_copy_policy() : idx->screen_copy_policy;
+    const bool possible = idx->rows && !idx->rows_bf16 && idx->screen_ok && oi_cosine_screen_supported(idx->dim);
+    if (policy == OI_SCREEN_COPY_NEVER || !possible) {
+        if (idx->screen_copy.p) { OI_HIP_CHECK(hipStreamSynchronize(ctx->stream)); idx->screen_copy.release(); }
+        return OI_OK;
+    }
+    if (idx->screen_copy.p) return OI_OK; // (set_embeddings releases a copy of the previous rows)
+    const size_t bytes = sizeof(uint16_t) * (size_t)idx->n_docs * idx->dim + 64;
+    if (policy == OI_SCREEN_COPY_AUTO) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return OI_OK; // no figure, no copy
+        static const double frac = [] {
+            const char *e = getenv("OI_SCREEN_COPY_MAX_FRAC");
+            const double f = e ? atof(e) : 0.25;
+            return f > 0.0 && f <= 1.0 ? f : 0.25;
+        }();
+        if ((double)bytes > frac * (double)free_b) return OI_OK;
+    }
+    OI_CHECK(idx->screen_copy.ensure(bytes));
+    OI_CHECK(oi_launch_make_screen_copy(ctx, idx->rows, idx->n_docs, idx->dim, idx->screen_copy.as<uint16_t>()));
+    OI_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OI_OK;
+}
+
+extern "C" int oi_index_set_screen_copy(oi_index *idx, int policy) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    if (idx->is_view) { oi_set_error("index view: read-only (set the policy on the index it was taken from)"); return OI_ERR_STATE; }
+    OI_REQUIRE(policy == OI_SCREEN_COPY_AUTO || policy == OI_SCREEN_COPY_NEVER || policy == OI_SCREEN_COPY_ALWAYS,
+               "oi_index_set_screen_copy: unknown policy %d", policy);
+    oi_ctx *ctx = idx->ctx;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    OI_HIP_CHECK(hipSetDevice(ctx->device));
+    idx->screen_copy_policy = policy;
+    if (!idx->finalized) return OI_OK; // applied by finalize
+    g_oi_ws_epoch.fetch_add(1);        // captured query calls hold (or lack) the copy's pointer
+    return apply_screen_copy_policy(idx);
+}
+
+extern "C" int oi_index_bytes(oi_index *idx, uint64_t *rows_owned, uint64_t *screen_copy, uint64_t *bm25) {
+    if (!idx) { oi_set_error("null index"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(idx->ctx->mu);
+    if (rows_owned)
+        *rows_owned = (idx->rows_owned ? sizeof(float) * (uint64_t)idx->n_docs * idx->dim : 0) +
+                      (idx->rows_bf16_owned ? sizeof(uint16_t) * (uint64_t)idx->n_docs * idx->dim : 0);
+    if (screen_copy) *screen_copy = idx->screen_copy.p && !idx->screen_copy.borrowed ? (uint64_t)idx->screen_copy.cap : 0;
+    if (bm25) {
+        uint64_t b = 0;
+        for (const DevBuf *d : {&idx->uniq_keys, &idx->tf, &idx->doc_len, &idx->df_local, &idx->postings, &idx->cell_start, &idx->idf,
+                                &idx->impact_floor, &idx->fwd_terms, &idx->fwd_offsets})
+            if (d->p && !d->borrowed) b += d->cap;
+        *bm25 = b;
+    }
+    return OI_OK;
 }
 
 extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location, int normalize) {
@@ -885,6 +959,7 @@ extern "C" int oi_index_set_embeddings(oi_index *idx, float *rows, int location,
             }
         }
     }
+    if (idx->finalized) OI_CHECK(apply_screen_copy_policy(idx)); // new rows under a finalized index: a new copy, now
     return OI_OK;
 }
 
@@ -900,6 +975,7 @@ extern "C" int oi_index_set_embeddings_bf16(oi_index *idx, const uint16_t *rows,
     OI_REQUIRE(oi_cosine_bf16_supported(idx->dim), "index: a bf16 corpus needs dim 384, 768 or 1024 (got %u)", idx->dim);
     if (idx->rows_owned && idx->rows) (void)hipFree(idx->rows);
     idx->rows = nullptr; idx->rows_owned = false;
+    idx->screen_copy.release(); // (a copy of f32 rows that are gone)
     if (idx->rows_bf16_owned && idx->rows_bf16) (void)hipFree(idx->rows_bf16);
     idx->rows_bf16 = nullptr; idx->rows_bf16_owned = false;
     const size_t bytes = (size_t)idx->n_docs * idx->dim * sizeof(uint16_t);
@@ -986,7 +1062,8 @@ extern "C" int oi_index_finalize(oi_index *idx, uint64_t global_n_docs, uint64_t
     if (!idx->forward_set) { oi_set_error("index: set_forward has not been called"); return OI_ERR_STATE; }
     if (idx->finalized) { oi_set_error("index: already finalized"); return OI_ERR_STATE; }
     OI_HIP_CHECK(hipSetDevice(ctx->device));
-    return oi_bm25_finalize(idx, global_n_docs, global_total_tokens, global_df_host);
+    OI_CHECK(oi_bm25_finalize(idx, global_n_docs, global_total_tokens, global_df_host));
+    return apply_screen_copy_policy(idx); // the derived structure of the cosine leg, beside the BM25 leg's postings
 }
 
 // ---------------------------------------------------------------- search
@@ -1290,7 +1367,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     bool late_pending = false;
     if (overlap) {
         bool late = false;
-        if (!early_env && !idx->rows_bf16 && idx->rows && ctx->cosine_mode == OI_COSINE_SCREEN && B > 8 && idx->screen_ok &&
+        if (!early_env && !idx->rows_bf16 && idx->rows &&
+            (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY || ctx->cosine_mode == OI_COSINE_SCREEN_STREAM) && B > 8 && idx->screen_ok &&
             oi_cosine_screen_supported(idx->dim) && pf_stride > pf_carry + pf_slack) {
             const uint64_t mc = pf_stride - pf_carry - pf_slack; // the screen's own schedule (cosine_leg below), dry
             uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth), r = 0, last = 0;
@@ -1369,8 +1447,12 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             static const bool shape16 = !(oi_ablation_env("OI_KS_SHAPE") && atoi(oi_ablation_env("OI_KS_SHAPE")) == 32);
             static const bool cos_v1 = oi_ablation_env("OI_COSINE_V1") != nullptr || oi_ablation_env("OI_SELECT_V1") != nullptr;
             // (a view never makes a copy of its own: it streams the source's if that exists, the f32 rows otherwise)
-            const bool want_copy = ctx->cosine_mode == OI_COSINE_SCREEN_COPY && !(idx->is_view && !idx->screen_copy.p);
-            const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
+            // OI_COSINE_SCREEN streams the index's bf16 screening copy when there is one (made at finalize, budget permitting);
+            // _COPY also makes a missing one now; _STREAM converts the f32 rows on the fly whatever the index holds
+            const bool want_copy = ctx->cosine_mode != OI_COSINE_SCREEN_STREAM &&
+                                   (idx->screen_copy.p != nullptr || (ctx->cosine_mode == OI_COSINE_SCREEN_COPY && !idx->is_view));
+            const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY ||
+                                 ctx->cosine_mode == OI_COSINE_SCREEN_STREAM) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
                                 idx->screen_ok && shape16 && !cos_v1;
             if (!screen) return exact_pipeline(nullptr, nullptr);
 
@@ -1411,7 +1493,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
                 if (late_pending && e == n) OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (before the last chunk's launch)
-                if (want_copy) OI_CHECK(oi_launch_cosine_bf16_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, d_qv, B, idx->doc_id_base, PF));
+                if (want_copy) OI_CHECK(oi_launch_cosine_screen_copy_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
                 else OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
                 if (late_pending && e == n) { late_pending = false; OI_CHECK(fork_bm25()); } // ... enqueued after it: the screen's workgroups get their CUs first
                 OI_CHECK(oi_launch_select(ctx, PF, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth, &mx));
@@ -1849,7 +1931,8 @@ extern "C" int oi_index_finalize_sharded(oi_index *idx, oi_comm *comm) {
     OI_HIP_CHECK(hipMemcpyAsync(glob, ws.p, 16, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipMemcpyAsync(gdf.data(), d_df, sizeof(uint32_t) * (size_t)idx->vocab, hipMemcpyDeviceToHost, st));
     OI_HIP_CHECK(hipStreamSynchronize(st));
-    return oi_bm25_finalize(idx, glob[0], glob[1], gdf.data());
+    OI_CHECK(oi_bm25_finalize(idx, glob[0], glob[1], gdf.data()));
+    return apply_screen_copy_policy(idx);
 }
 
 extern "C" int oi_search_sharded(oi_index *idx, oi_comm *comm, const float *qv, const uint32_t *qt, const uint32_t *qo,

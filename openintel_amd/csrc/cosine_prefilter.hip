@@ -610,7 +610,7 @@ void oi_cosine_screen_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_s
     // flight -- the BM25 leg on the side stream, the selects and the rescoring of another batch scored through a view of the
     // same shard (oi_index_view): 0.817 -> 0.713 ms per batch at 1.25M rows with two batches in flight (tools/dual_stream_probe.py;
     // 192: 0.69-0.72, 160: 0.75, and from 176 down the single-stream time grows).  OI_SCREEN_CUS: A/B switch.
-    static const char *cus_s = oi_ablation_env("OI_SCREEN_CUS");
+    const char *cus_s = oi_ablation_env("OI_SCREEN_CUS"); // (read per call: sweep tools change it between runs of one process)
     const uint64_t cus = cus_s ? (uint64_t)std::max(1, atoi(cus_s)) : std::max<uint64_t>(1, (uint64_t)ctx->num_cus * 7 / 8);
     static const bool small_full = oi_ablation_env("OI_SCREEN_SMALL_FULL") != nullptr; // A/B: a chunk of <= one quad per CU takes every CU
     const uint64_t grid = small_full && quads <= (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (quads < cus ? (quads ? quads : 1) : cus);

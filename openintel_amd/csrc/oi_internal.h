@@ -122,7 +122,7 @@ struct oi_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_legs = true;              // oi_set_overlap
     int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default),
-                                           // 3 = 2 with the screen reading a bf16 COPY of the rows (opt-in)
+                                           // 3 = 2 + make a missing screening copy on first use, 4 = 2 but never read the copy
     std::mutex mu;
     std::map<std::string, DevBuf> ws; // named workspaces
     int prof_enabled = 0; // 0 off, 1 every tagged launch, 2 the cosine scorer only
@@ -178,7 +178,8 @@ struct oi_index {
     // long ones are listed (local row numbers), marked in a bitmap, skipped by the margin selects and always rescored
     uint32_t n_long = 0;
     DevBuf long_list, long_bitmap;
-    DevBuf screen_copy;     // OI_COSINE_SCREEN_COPY: bf16(rows), made on first use (n_docs x dim x 2 B); empty otherwise
+    DevBuf screen_copy;     // the bf16 screening copy: bf16(rows), n_docs x dim x 2 B, made at finalize when the policy allows
+    int screen_copy_policy = -1; // oi_index_set_screen_copy; -1 = the process default (OI_SCREEN_COPY, else AUTO)
 
     // staged forward index (between set_forward and finalize)
     bool forward_set = false, finalized = false;
@@ -300,6 +301,9 @@ int oi_launch_screen_stage(oi_ctx *ctx, const float *d_queries, uint32_t n_queri
 int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                   const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
 int oi_launch_make_screen_copy(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, uint16_t *out);
+// cosine_screen_copy.hip
+int oi_launch_cosine_screen_copy_chunk(oi_ctx *ctx, const uint16_t *copy_rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
+                                       const uint16_t *q_bf16, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool);
 int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
                            const uint16_t *q_bf16, uint32_t n_queries, float *d_out);
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,

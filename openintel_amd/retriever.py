@@ -137,6 +137,20 @@ class HybridIndex(PostRetriever):
         _lib.check(self.lib.oi_index_long_rows(self.handle, C.byref(n)))
         return int(n.value)
 
+    SCREEN_COPY_AUTO, SCREEN_COPY_NEVER, SCREEN_COPY_ALWAYS = _lib.OI_SCREEN_COPY_AUTO, _lib.OI_SCREEN_COPY_NEVER, _lib.OI_SCREEN_COPY_ALWAYS
+
+    def set_screen_copy(self, policy: int) -> None:
+        """The bf16 screening copy of an f32 corpus (oi_index_set_screen_copy): SCREEN_COPY_AUTO (default: made at finalize
+        when n_docs x dim x 2 B is at most a quarter of the free HBM), _NEVER, _ALWAYS.  The default scorer's screen streams
+        it instead of the f32 rows -- half the bytes, the same lists."""
+        _lib.check(self.lib.oi_index_set_screen_copy(self.handle, int(policy)))
+
+    def index_bytes(self):
+        """(rows owned by the library, screening copy, BM25 structures) in bytes of HBM: oi_index_bytes."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.oi_index_bytes(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
+
     BM25_DEFAULT, BM25_TAAT, BM25_SCAN, BM25_WAVE, BM25_STREAM = 0, 1, 2, 3, 4
 
     def set_bm25_mode(self, mode: int) -> None:

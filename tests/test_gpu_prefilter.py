@@ -12,12 +12,16 @@ pytestmark = pytest.mark.gpu
 COS_TOL = 1e-5
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# Round 5: the default mode streams the index's bf16 SCREENING COPY (made at finalize); OI_COSINE_SCREEN_STREAM is rounds 1-4's
+# default, the same screen converting the f32 rows on the fly.  Every test of this module runs in both: the adversarial cases
+# are the new default's tests too.
+@pytest.fixture(scope="module", params=["copy", "stream"])
+def ctx(request):
     import openintel_amd as oi
     from openintel_amd import _lib
     c = oi.HipContext(0)
-    c.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    c.screen_mode = _lib.OI_COSINE_SCREEN if request.param == "copy" else _lib.OI_COSINE_SCREEN_STREAM
+    c.set_cosine_mode(c.screen_mode)
     yield c
     c.close()
 
@@ -120,7 +124,7 @@ def test_screen_and_exact_modes_agree(ctx, O):
     assert _gate(ctx) == 0.0
     ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
     Le = idx.search_lists(q, qt, qo, depth=1000)
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    ctx.set_cosine_mode(ctx.screen_mode)
     assert np.array_equal(Ls.cos_counts, Le.cos_counts)
     assert np.abs(Ls.cos_scores - Le.cos_scores).max() <= 5e-7    # two f32 summation orders
     assert (Ls.cos_docs == Le.cos_docs).mean() > 0.999            # order can only differ between near-ties
@@ -224,7 +228,7 @@ def test_hard_cases_for_the_bound(ctx, O):
     assert _gate(ctx) != 0.0
     ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
     Le = idx.search_lists(q2, qt, qo, depth=100)
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    ctx.set_cosine_mode(ctx.screen_mode)
     assert np.array_equal(L.cos_counts, Le.cos_counts) and int(L.cos_counts[3]) == 0 and int(L.cos_counts[4]) == 100
     for b in range(B):       # (entries past a list's count are not defined: the screened pass may have left its own there)
         c = int(L.cos_counts[b])
@@ -279,7 +283,7 @@ def test_a_few_long_rows_do_not_open_the_gate(ctx, O, n_long):
     # the same lists from the exact mode: same docs at (nearly) every rank, same scores to the bar
     ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
     Le = idx.search_lists(q, qt, qo, depth=depth)
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    ctx.set_cosine_mode(ctx.screen_mode)
     same = np.mean(L.cos_docs[:, :depth] == Le.cos_docs[:, :depth])
     assert same > 0.98, same
     assert np.abs(L.cos_scores[:, :depth] - Le.cos_scores[:, :depth]).max() <= COS_TOL * 3.0
@@ -369,7 +373,7 @@ def test_tie_rounding_adversary_keeps_the_true_top_row(ctx, O, n_comp, depth):
     assert (gate != 0.0) == (n_comp > 4096), "only the 5000-competitor case overflows the survivors"
     ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
     Le = idx.search_lists(q, qt, qo, depth=depth)
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    ctx.set_cosine_mode(ctx.screen_mode)
     c = int(L.cos_counts[0])
     assert c == depth and int(L.cos_docs[0][0]) == planted
     head = min(depth, 1 + n_comp)                          # planted + competitors in doc-id order, exact sums
@@ -511,7 +515,7 @@ def test_full_size_screened_10M_768_batch64(ctx):
     Le = idx.search_lists(qv, qt, qo, depth=depth)
     Re = idx.search(qv, qt, qo, k=k, depth=depth)
     ctx.synchronize()
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+    ctx.set_cosine_mode(ctx.screen_mode)
     es, ed = Le.cos_scores.cpu().numpy(), Le.cos_docs.cpu().numpy()
     # same score at every rank (two f32 summation orders), same doc except where neighbours are closer than that
     assert np.abs(cs - es).max() <= 5e-7 and (cd == ed).mean() > 0.995
@@ -529,8 +533,8 @@ class L_np:
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# OI_COSINE_SCREEN_COPY (opt-in): the screen reads a bf16 copy of the rows.  Same products, same bound, same exact
-# rescoring from the f32 rows: the lists must be the default screen's BIT FOR BIT, the adversary included.
+# The screening copy (round 5: the default whenever the index holds one): the screen reads bf16(rows) made once.  Same products,
+# same bound, same exact rescoring from the f32 rows: the lists must be the f32-stream screen's BIT FOR BIT, the adversary included.
 @pytest.mark.parametrize("B,dim,n,depth", [(64, 768, 120_000, 1000), (40, 384, 50_000, 100), (130, 768, 30_000, 500)])
 def test_screen_copy_mode_returns_the_same_lists(ctx, O, B, dim, n, depth):
     from openintel_amd import _lib, synth
@@ -540,16 +544,25 @@ def test_screen_copy_mode_returns_the_same_lists(ctx, O, B, dim, n, depth):
     terms, offs = _forward(rng, n)
     idx = _index(ctx, rows, terms, offs, 50, base=11)
     qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    assert idx.index_bytes()[1] >= 2 * n * dim                  # finalize made the copy (AUTO: it fits the budget)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN_STREAM)            # the f32 rows converted on the fly: rounds 1-4's default
     L0 = idx.search_lists(q, qt, qo, depth=depth)
     assert _gate(ctx) == 0.0
-    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN_COPY)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)                   # the default: streams the copy
     try:
         L1 = idx.search_lists(q, qt, qo, depth=depth)
         assert _gate(ctx) == 0.0
-        L2 = idx.search_lists(q, qt, qo, depth=depth)            # second call: the copy already exists
+        idx.set_screen_copy(idx.SCREEN_COPY_NEVER)               # the copy is freed: the default mode streams the f32 rows
+        assert idx.index_bytes()[1] == 0
+        L3 = idx.search_lists(q, qt, qo, depth=depth)
+        ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN_COPY)          # rounds 2-4's opt-in mode: makes a missing copy on first use
+        L2 = idx.search_lists(q, qt, qo, depth=depth)
+        assert idx.index_bytes()[1] >= 2 * n * dim
+        idx.set_screen_copy(idx.SCREEN_COPY_ALWAYS)
+        L4 = idx.search_lists(q, qt, qo, depth=depth)
     finally:
-        ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
-    for L in (L1, L2):
+        ctx.set_cosine_mode(ctx.screen_mode)
+    for L in (L1, L2, L3, L4):
         assert np.array_equal(L.cos_counts, L0.cos_counts) and np.array_equal(L.cos_docs, L0.cos_docs)
         assert np.array_equal(L.cos_scores.view(np.uint32), L0.cos_scores.view(np.uint32))
     for b in range(0, B, 7):
@@ -577,7 +590,7 @@ def test_screen_copy_mode_on_the_tie_rounding_adversary(ctx, O):
     try:
         L = idx.search_lists(q, qt, qo, depth=depth)
     finally:
-        ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN)
+        ctx.set_cosine_mode(ctx.screen_mode)
     assert int(L.cos_docs[0][0]) == planted
     assert np.array_equal(L.cos_docs[0], Le.cos_docs[0])
     assert np.array_equal(L.cos_scores[0].view(np.uint32), Le.cos_scores[0].view(np.uint32))
