@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share one run one after the
+# other.  Two batches in flight (N > 1, and the pipelined side measurement at N = 1) have seven streams in play: 8 queues keep
+# them apart (csrc/api.hip has the measurement).  Read by the runtime when it initialises: set before torch touches the GPU.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
@@ -92,6 +96,178 @@ def cpu_baseline(n_total, dim, vocab, depth, k, sample_docs, sample_queries):
     }
 
 
+def text_paths(oi, ctx, dev, n_items, reps, cpu_sample):
+    """The reference-pinned paths in the driver-run line: the lexicon scan + social summary over
+    `n_items` synthetic posts and the headline gate's title scan over as many synthetic titles, resident in HBM (SURVEY 8d
+    seeds); kernel time from HIP events inside the library, algorithmic bytes per SURVEY 8d, the host-inclusive latency of ONE
+    call at the reference's real size (100 posts: src/adapters/sources/reddit/mod.rs:93; a ticker's headlines), and the CPU
+    oracle -- for THESE paths a line-by-line restatement of the reference (lexicon.rs:53-87, polarity.rs:8-14,
+    speculation_engine.rs:70-125, dip.rs:247-272), pinned by the reference's own vectors -- single-thread (how the reference
+    runs it) and on all host cores (the same scalar function per post, OpenMP static chunks).  Outside the timed region."""
+    import numpy as np
+    import torch
+    from openintel_amd import dip, synth
+    from oracle import lib as O
+    nproc = os.cpu_count() or 1
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = max(1, min(nproc, O.max_threads()))
+    out = {}
+
+    def pct(v, q):
+        v = sorted(v)
+        return v[min(len(v) - 1, max(0, int(round(q * (len(v) - 1)))))]
+
+    # ------------------------------------------------------------ lexicon scan + social summary (A1-A4)
+    an = oi.HipLexiconAnalyzer(ctx)
+    cfg = oi.EngineConfig()
+    blob, offs = synth.posts_torch(n_items, dev)
+    n = n_items
+    pol = torch.zeros(n, dtype=torch.float64, device=dev)
+    spec = torch.zeros(n, dtype=torch.uint8, device=dev)
+    src = (torch.arange(n, device=dev) % 3 == 0).to(torch.uint8)
+    text_bytes = int(blob.numel())
+    for _ in range(2):
+        an.analyze_device(blob, offs, pol, spec)
+    torch.cuda.synchronize()
+    ctx.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        an.analyze_device(blob, offs, pol, spec)
+    torch.cuda.synchronize()
+    call_ms = (time.perf_counter() - t0) / reps * 1e3
+    k_ms, k_n = ctx.profile_read("lexicon")
+    ctx.profile_reset(False)
+    for _ in range(2):
+        fc = an.summary_device(blob, offs, src, tau=cfg.bull_bear_threshold)
+    ctx.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fc = an.summary_device(blob, offs, src, tau=cfg.bull_bear_threshold)
+    f_call_ms = (time.perf_counter() - t0) / reps * 1e3
+    f_ms, f_n = ctx.profile_read("lexicon")
+    ctx.profile_reset(False)
+    alg = text_bytes + 8 * (n + 1) + 9 * n          # SURVEY 8d: text + offsets in, (f64 + u8) per post out
+    alg_f = text_bytes + 8 * (n + 1) + n            # fused with the A4 reduction: + sources in, 64 B of counters out
+    # one call at the reference's size, host buffers in and out (OI_HOST: H2D, scan, D2H, synchronous)
+    texts100 = synth.posts_np(100)
+    b100, o100 = oi.pack_posts(texts100)
+    for _ in range(20):
+        an.analyze_packed(b100, o100)
+    lat = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        an.analyze_packed(b100, o100)
+        lat.append((time.perf_counter() - t0) * 1e6)
+    # CPU: the reference-faithful oracle on a slice of the same posts
+    ns = min(n, cpu_sample)
+    hb = blob[: int(offs[ns])].cpu().numpy()
+    ho = offs[: ns + 1].cpu().numpy().astype(np.uint64)
+    hs = src[:ns].cpu().numpy()
+    t0 = time.perf_counter()
+    rpol, rspec = O.lexicon_analyze(hb, ho)
+    t_cpu1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.social_summary(hs, rpol, rspec)
+    t_sum = time.perf_counter() - t0
+    O.lexicon_analyze(hb[: int(ho[min(ns, 50_000)])], ho[: min(ns, 50_000) + 1], n_threads=threads)   # (spin the thread pool up)
+    t0 = time.perf_counter()
+    mpol, mspec = O.lexicon_analyze(hb, ho, n_threads=threads)
+    t_cpun = time.perf_counter() - t0
+    ok = bool(np.array_equal(pol[:ns].cpu().numpy().view(np.uint64), rpol.view(np.uint64)) and np.array_equal(spec[:ns].cpu().numpy(), rspec)
+              and np.array_equal(mpol.view(np.uint64), rpol.view(np.uint64)) and np.array_equal(mspec, rspec))
+    ksec = k_ms / max(1, k_n) / 1e3
+    fsec = f_ms / max(1, f_n) / 1e3
+    out["lexicon_path"] = {
+        "rows": "SURVEY 8 A1-A4: LexiconAnalyzer::score / analyze (lexicon.rs:53-87), Polarity::new, social_summary (speculation_engine.rs:70-125)",
+        "posts": n, "text_bytes": text_bytes,
+        "scan": {"kernel_ms": k_ms / max(1, k_n), "call_ms": call_ms, "posts_per_s": n / ksec, "algorithmic_bytes": alg,
+                 "algorithmic_GBs": alg / ksec / 1e9, "frac_of_hbm_peak": alg / ksec / 1e9 / PEAK_HBM_GBS,
+                 "note": "oi_lexicon_analyze_device: per-post (f64 polarity, u8 speculative) written; bytes = text + 8(n+1) offsets in + 9n out"},
+        "fused_scan_and_summary": {"kernel_ms": f_ms / max(1, f_n), "call_ms": f_call_ms, "algorithmic_bytes": alg_f,
+                                   "algorithmic_GBs": alg_f / fsec / 1e9, "frac_of_hbm_peak": alg_f / fsec / 1e9 / PEAK_HBM_GBS,
+                                   "note": "oi_lexicon_summary_device: the scan with the A4 reduction fused in, nothing written per post",
+                                   "counters": {"total": int(fc.total), "bullish": int(fc.bullish), "bearish": int(fc.bearish),
+                                                "neutral": int(fc.neutral), "speculative": int(fc.spec_count)}},
+        "one_call_of_100_posts_host_inclusive_us": {"p50": pct(lat, 0.5), "p95": pct(lat, 0.95), "calls": len(lat),
+                                                    "note": "oi_lexicon_analyze (OI_HOST): pack-free host arrays in, H2D, scan, D2H, synchronous; "
+                                                            "the reference fetches at most 100 posts per source and call (reddit/mod.rs:93)"},
+        "bit_exact_vs_oracle_on_slice": ok,
+        "cpu_baseline": {"kind": "port", "reference_faithful": True, "sample": "%d of the same posts" % ns,
+                         "single_thread": {"posts_per_s": ns / t_cpu1, "cores": 1, "seconds": t_cpu1,
+                                           "social_summary_seconds": t_sum,
+                                           "note": "how the reference runs it: one thread maps `score` over the posts (lexicon.rs:82-87)"},
+                         "all_cores": {"posts_per_s": ns / t_cpun, "cores": threads, "seconds": t_cpun,
+                                       "note": "the same scalar function per post, OpenMP static chunks (oio_lexicon_analyze_mt)"},
+                         "nproc": nproc, "compiler": O.CFLAGS,
+                         "label": "build's CPU restatement of the reference's Rust, pinned by the reference's own vectors (tests/test_oracle_golden.py); "
+                                  "the reference itself cannot be built here (no cargo/rustc)"},
+    }
+    del blob, offs, pol, spec, src
+    # ------------------------------------------------------------ headline gate's title scan (f-3)
+    sc = oi.HeadlineScanner(ctx)
+    forms = dip.company_name_forms([synth.HEADLINE_COMPANY])
+    blob, offs = synth.headlines_torch(n_items, dev)
+    mask = torch.zeros(n, dtype=torch.int16, device=dev)
+    order = torch.zeros(n, dtype=torch.int64, device=dev)
+    about = torch.zeros(n, dtype=torch.uint8, device=dev)
+    text_bytes = int(blob.numel())
+    for _ in range(2):
+        sc.scan_device(blob, offs, synth.HEADLINE_TICKER, forms, mask, order, about)
+    torch.cuda.synchronize()
+    ctx.profile_reset(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sc.scan_device(blob, offs, synth.HEADLINE_TICKER, forms, mask, order, about)
+    torch.cuda.synchronize()
+    call_ms = (time.perf_counter() - t0) / reps * 1e3
+    k_ms, k_n = ctx.profile_read("headline")
+    ctx.profile_reset(False)
+    alg = text_bytes + 8 * (n + 1) + 11 * n         # titles + offsets in, (u16 mask + u64 order + u8 about) per title out
+    t100 = synth.headlines_np(100)
+    tb, to = oi.pack_posts(t100)
+    for _ in range(20):
+        sc.scan_packed(tb, to, synth.HEADLINE_TICKER, forms)
+    lat = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        sc.scan_packed(tb, to, synth.HEADLINE_TICKER, forms)
+        lat.append((time.perf_counter() - t0) * 1e6)
+    ns = min(n, cpu_sample)
+    hb = blob[: int(offs[ns])].cpu().numpy()
+    ho = offs[: ns + 1].cpu().numpy().astype(np.uint64)
+    t0 = time.perf_counter()
+    rm, ro, ra = O.headline_scan(hb, ho, synth.HEADLINE_TICKER, forms)
+    t_cpu1 = time.perf_counter() - t0
+    O.headline_scan(hb[: int(ho[min(ns, 50_000)])], ho[: min(ns, 50_000) + 1], synth.HEADLINE_TICKER, forms, n_threads=threads)
+    t0 = time.perf_counter()
+    mm, mo, ma = O.headline_scan(hb, ho, synth.HEADLINE_TICKER, forms, n_threads=threads)
+    t_cpun = time.perf_counter() - t0
+    ok = bool(np.array_equal(mask[:ns].cpu().numpy().view(np.uint16), rm) and np.array_equal(order[:ns].cpu().numpy().view(np.uint64), ro)
+              and np.array_equal(about[:ns].cpu().numpy(), ra) and np.array_equal(mm, rm) and np.array_equal(mo, ro) and np.array_equal(ma, ra))
+    ksec = k_ms / max(1, k_n) / 1e3
+    out["headline_path"] = {
+        "rows": "SURVEY 8 f-3: catalyst_hits / headline_mentions_company (dip.rs:247-272)",
+        "titles": n, "text_bytes": text_bytes,
+        "scan": {"kernel_ms": k_ms / max(1, k_n), "call_ms": call_ms, "titles_per_s": n / ksec, "algorithmic_bytes": alg,
+                 "algorithmic_GBs": alg / ksec / 1e9, "frac_of_hbm_peak": alg / ksec / 1e9 / PEAK_HBM_GBS,
+                 "note": "oi_headline_scan_device; bytes = titles + 8(n+1) offsets in + 11n out (u16 mask, u64 first-hit order, u8 about)"},
+        "one_call_of_100_titles_host_inclusive_us": {"p50": pct(lat, 0.5), "p95": pct(lat, 0.95), "calls": len(lat),
+                                                     "note": "oi_headline_scan (OI_HOST): H2D, scan, D2H, synchronous"},
+        "titles_with_hits": int((mask != 0).sum().item()), "titles_about_company": int(about.sum().item()),
+        "bit_exact_vs_oracle_on_slice": ok,
+        "cpu_baseline": {"kind": "port", "reference_faithful": True, "sample": "%d of the same titles" % ns,
+                         "single_thread": {"titles_per_s": ns / t_cpu1, "cores": 1, "seconds": t_cpu1},
+                         "all_cores": {"titles_per_s": ns / t_cpun, "cores": threads, "seconds": t_cpun,
+                                       "note": "the same scalar functions per title, OpenMP static chunks (oio_headline_scan_mt)"},
+                         "nproc": nproc, "compiler": O.CFLAGS,
+                         "label": "build's CPU restatement of the reference's Rust, pinned by the reference's own vectors (tests/test_dip.py)"},
+    }
+    return out
+
+
 def launcher_command(argv, n_gpus, port, python=None):
     """argv/env of the child that runs the N ranks (tests/test_bench_launcher.py).  `argv` = this script's own
     arguments, passed through unchanged so that every rank parses what the user typed."""
@@ -153,7 +329,17 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="N > 1, pipelined: batches whose lists are scored at once, each through its own view of the shard "
                          "(own stream and workspaces; sharded.ShardedPipeline); 1 = one at a time")
+    ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
+                    help="N > 1: who runs the pipeline and the all-gather -- torch (sharded.ShardedPipeline over torch.distributed, "
+                         "the default) or native (oi_pipeline_* + oi_comm_*: lanes, streams and RCCL inside the library, what a host on "
+                         "the C ABI gets; torch.distributed then only ships the communicator's 128-byte id)")
+    ap.add_argument("--no-pipelined-side", action="store_true",
+                    help="N = 1: skip the side measurement of the native two-lane pipeline (pipelined_native)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-text-paths", action="store_true",
+                    help="N = 1: skip the reference-pinned paths' blocks (lexicon_path, headline_path: SURVEY 8 rows A1-A4, f-3)")
+    ap.add_argument("--text-items", type=int, default=10_000_000, help="synthetic posts / titles of the text-path blocks (SURVEY 8d: 10M)")
+    ap.add_argument("--text-cpu-sample", type=int, default=2_000_000, help="posts / titles the CPU oracle is timed on")
     ap.add_argument("--settle-steps", type=int, default=0,
                     help="untimed steps (x the number of ranks) before the warm-up (an experiment: no effect measured, round 4); 0 = none")
     ap.add_argument("--no-stream-side", action="store_true", help="skip the f32-stream screen's side measurement (f32_stream_scorer)")
@@ -237,7 +423,17 @@ def main():
     sr = sharded.make_hip_sharded(ctx, idx, dev)
     if force_dist:
         sr.exchange = True
-    sr.finalize()                                      # all-reduce of df / N / tokens when world > 1
+    native_comm = None
+    if args.exchange == "native" and (world > 1 or force_dist):
+        # RCCL inside the library (oi_comm_*): the 128-byte id goes from rank 0 to the others over the process group that
+        # launched the ranks -- control plane only; statistics, all-gathers and lanes are the library's from here on
+        ids = [oi.NativeComm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
+        native_comm = oi.NativeComm(ctx, ids[0], rank, world)
+        idx.finalize_sharded(native_comm)              # ncclAllReduce of df / N / tokens inside the library
+    else:
+        sr.finalize()                                  # all-reduce of df / N / tokens when world > 1
     _, df_local = idx.local_stats()                    # for the BM25 leg's algorithmic bytes (rank 0 reports)
     rows_owned_b, screen_copy_b, bm25_index_b = idx.index_bytes()
     # what the default scorer's screen streams on this rank: the index's bf16 screening copy if finalize made it
@@ -268,7 +464,49 @@ def main():
     # independent batches, one all-gather each, same results); the latency loop below runs the batches one at a time.
     pipe = None
     lane_ctxs = []
-    if (world > 1 or force_dist or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment)
+    fuse_ctx = None
+
+    class NativePipe:
+        """oi_pipeline_* behind the handful of names the loops below use of sharded.ShardedPipeline (submit -> slot, results,
+        drain, close, lanes, calibration) and of a HipContext (profile_*, synchronize, workspace_bytes)."""
+
+        def __init__(self, lanes):
+            self.p = oi.NativePipeline(idx, lanes=lanes, max_queries=args.batch, max_query_terms=4, depth=args.depth, k=args.k,
+                                       comm=native_comm)
+            self.n_slots, self.n, self.calibration = 8, 0, None
+            self.lanes = [(None, None)] * lanes
+            self.results = [oi.SearchResult(torch.zeros((args.batch, args.k), dtype=torch.float32, device=dev),
+                                            torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
+                                            torch.zeros((args.batch,), dtype=torch.int32, device=dev)) for _ in range(self.n_slots)]
+
+        def submit(self, qv, qt, qo):
+            slot = self.n % self.n_slots
+            self.n += 1
+            self.p.submit(qv, qt, qo, out=self.results[slot])
+            return slot
+
+        def drain(self):
+            self.p.drain()
+
+        synchronize = drain
+
+        def profile_reset(self, enable):
+            self.p.profile_reset(int(enable))
+
+        def profile_read(self, tag):
+            return self.p.profile_read(tag)
+
+        def workspace_bytes(self):
+            return self.p.workspace_bytes()
+
+        def close(self):
+            self.p.close()
+
+    native_pipe = args.exchange == "native" and (world > 1 or force_dist) and not args.no_pipeline
+    if native_pipe:
+        pipe = NativePipe(max(1, args.lanes))
+        lane_ctxs = [pipe]                                   # (its lanes' contexts are the library's: profiled through the pipeline)
+    elif (world > 1 or force_dist or os.environ.get("OI_BENCH_PIPELINE_N1")) and not args.no_pipeline:   # (the env switch: an experiment, DESIGN section 7)
         fuse_ctx = oi.HipContext(local_rank)
         pipe = sharded.ShardedPipeline(sr, fuse_ctx, args.batch, args.depth, args.k)
         if args.lanes > 1:
@@ -288,6 +526,8 @@ def main():
             return out.docs
         if pipe is not None and pipelined[0]:
             return pipe.results[pipe.submit(qv, qt, qo)].docs
+        if native_comm is not None:
+            return idx.search_sharded(native_comm, qv, qt, qo, k=args.k, depth=args.depth, out=out).docs   # one C-ABI call, RCCL inside
         return sr.search(qv, qt, qo, args.k, args.depth, check=False)[1]  # overflow flag checked after the loops
 
     pipelined = [False]
@@ -334,7 +574,7 @@ def main():
     # every rank's own set-up and clock (rank 0 prints them all: a scaling number can be tied to the lanes that produced it)
     mine = {"rank": rank, "docs_per_gpu": n_local, "doc_id_base": lo, "own_elapsed_ms_per_step": float(tm_own) / args.steps * 1e3,
             "lane_calibration": pipe.calibration if pipe is not None else None,
-            "lanes": (len(pipe.lanes) if pipe is not None else 1),
+            "lanes": (len(pipe.lanes) if pipe is not None else 1), "exchange": args.exchange if (world > 1 or force_dist) else None,
             # HBM of the searching contexts' workspaces on this rank (the index itself not counted)
             "workspace_GB": round(sum(c.workspace_bytes()[0] for c in [ctx] + lane_ctxs) / 1e9, 3)}
     per_rank = [mine]
@@ -412,6 +652,37 @@ def main():
                                    "exact f32 rescoring, identical lists (tests/test_gpu_prefilter.py); the screen converts the f32 rows on the fly "
                                    "(4 d bytes per row and batch)"}
 
+    # N = 1: the same K steps through the library's own two-lane pipeline (oi_pipeline_*: what a serving host on the C ABI would
+    # run for throughput) -- batch i+1's corpus stream beside the selects / rescoring / fusion of batch i.  A side number: the
+    # headline stays one oi_search call per batch, one batch in flight, as in every earlier round.
+    pipelined_side = None
+    if world == 1 and not force_dist and not args.no_pipelined_side and args.batch > 8:
+        npipe = oi.NativePipeline(idx, lanes=2, max_queries=args.batch, max_query_terms=4, depth=args.depth, k=args.k)
+        outs = [oi.SearchResult(torch.zeros((args.batch, args.k), dtype=torch.float32, device=dev),
+                                torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
+                                torch.zeros((args.batch,), dtype=torch.int32, device=dev)) for _ in range(8)]
+        for i in range(8):
+            npipe.submit(*batches[i % NB], out=outs[i])
+        npipe.drain()
+        same = True
+        for i in range(min(NB, 8)):
+            idx.search(*batches[i], k=args.k, depth=args.depth, out=out)
+            ctx.synchronize()
+            same = same and bool(torch.equal(out.docs, outs[i].docs)) and bool(torch.equal(out.scores, outs[i].scores))
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            npipe.submit(*batches[i % NB], out=outs[i % 8])
+        npipe.drain()
+        torch.cuda.synchronize()
+        pp_elapsed = time.perf_counter() - t1
+        pipelined_side = {"ms_per_step": pp_elapsed / args.steps * 1e3, "queries_per_s": args.batch * args.steps / pp_elapsed,
+                          "steps": args.steps, "lanes": 2, "bit_identical_to_oi_search": same,
+                          "workspace_GB": round(npipe.workspace_bytes()[0] / 1e9, 3),
+                          "note": "oi_pipeline_create(idx, NULL, 2 lanes) / oi_pipeline_submit x K / oi_pipeline_drain: two batches in flight "
+                                  "through lanes the library owns; NOT the headline (value = one oi_search call per batch, one batch in flight)"}
+        npipe.close()
+
     # ---------------------------------------------------------------- latency: >= 200 timed batches after 20 warm-ups,
     # whatever --steps says.  (a) device-resident: HIP events on the launch stream around ONE batch at a time (queries and
     # results in HBM), plus the host's wall clock around the same batch (call + sync); (b) host-inclusive: the OI_HOST entry
@@ -447,6 +718,8 @@ def main():
         qv, qt, qo = host_batches[i % NB]
         if world == 1 and not force_dist:
             return idx.search(qv, qt, qo, k=args.k, depth=args.depth).docs     # OI_HOST: numpy in, numpy out, synchronous
+        if native_comm is not None:
+            return idx.search_sharded(native_comm, qv, qt, qo, k=args.k, depth=args.depth).docs       # OI_HOST through the library
         d = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) for x in (qv, qt, qo)]
         return sr.search(d[0], d[1], d[2], args.k, args.depth, check=False)[1].cpu().numpy()
 
@@ -527,11 +800,11 @@ def main():
         roof["step_level"] = {"achieved": bytes_step * passes * args.steps / elapsed / 1e9, "unit": "GB/s",
                               "frac": bytes_step * passes * args.steps / elapsed / 1e9 / PEAK_HBM_GBS,
                               "note": "this rank's corpus bytes streamed / the whole timed region (everything else included)"}
-        if len(lane_ctxs) > 1 and pipe is not None:
+        if pipe is not None and len(pipe.lanes) > 1:
             # two batches' screens share the chip: each launch's duration includes the time it ran beside the other lane's,
             # so the per-launch figure above understates the rate the corpus is streamed at; the step-level figure does not
             roof["overlapped_launches"] = ("%d batches in flight per rank: launch durations overlap and are summed as measured "
-                                           "(frac understates the kernel); see step_level and isolated" % len(lane_ctxs))
+                                           "(frac understates the kernel); see step_level and isolated" % len(pipe.lanes))
         roof["isolated"] = {"avg_launch_ms": iso_ms / max(1, iso_launches),
                             "frac": (flops_step if roof["bound"] == "mfma" else bytes_step) * iso_steps / (iso_ms / 1e3)
                             / (1e12 if roof["bound"] == "mfma" else 1e9) / roof["peak"],
@@ -565,8 +838,9 @@ def main():
                                     "screening_copy": screen_copy_b / 1e9, "bm25_structures": bm25_index_b / 1e9},
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
-                                      ("; %d batches' lists in flight per rank, each through its own view of the shard" % len(lane_ctxs)
-                                       if len(lane_ctxs) > 1 else ""),
+                                      ("; %d batches' lists in flight per rank, each through its own view of the shard" % len(pipe.lanes)
+                                       if pipe is not None and len(pipe.lanes) > 1 else "") +
+                                      ("; lanes, streams and the RCCL all-gather inside the library (oi_pipeline_*, oi_comm_*)" if native_pipe else ""),
                        "backend": (backend if (world > 1 or force_dist) else None),
                        "forced_process_group_of_one": force_dist,
                        "per_rank": per_rank},
@@ -610,15 +884,22 @@ def main():
             line["screen_fell_back_to_exact"] = screen_fallback
             if stream_side is not None:
                 line["f32_stream_scorer"] = stream_side
+        if pipelined_side is not None:
+            line["pipelined_native"] = pipelined_side
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.docs, args.dim, args.vocab, args.depth, args.k,
                                                 args.cpu_sample_docs, args.cpu_sample_queries)
+        if not args.no_text_paths and world == 1:    # the reference-pinned paths, on rank 0 at N=1 (their own inputs; outside the timed region)
+            line.update(text_paths(oi, ctx, dev, args.text_items, 10, args.text_cpu_sample))
         line["library"] = os.path.relpath(_oil.LIB_PATH, ROOT)   # what was measured (the package loader has no override)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if pipe is not None:
         pipe.close()
-        fuse_ctx.close()
+        if fuse_ctx is not None:
+            fuse_ctx.close()
+    if native_comm is not None:
+        native_comm.close()
     if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()

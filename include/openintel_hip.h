@@ -430,6 +430,54 @@ int oi_search_sharded(oi_index *idx, oi_comm *comm, const float *query_vecs, con
                       const uint32_t *q_term_offsets, uint32_t n_queries, uint32_t depth, uint32_t k, int location,
                       float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 
+/* ------------------------------------------------------------------------- */
+/* The pipelined query behind the C ABI: several batches in flight             */
+/* ------------------------------------------------------------------------- */
+/*
+ * Throughput mode of oi_search / oi_search_sharded for a host without streams or a collective library of its own (the
+ * reference's port is one synchronous call -- src/domain/ports/post_analyzer.rs:7-11, `Send + Sync`, borrowed in / owned
+ * out; composition root src/main.rs:17-39 -- so this has no reference counterpart).  Batches are independent: batch n is
+ * scored on lane n % lanes (every lane = a context, a stream and a view of the index inside the library), its exchange
+ * (ONE RCCL all-gather when `comm` is given, none otherwise) and its fusion run on a further stream, and the next batch's
+ * corpus stream overlaps the selects / rescoring / fusion of the previous one.  Per batch: the same kernels on the same
+ * data as oi_search (comm == NULL) / oi_search_sharded -- bit-identical results (tests/test_gpu_pipeline.py).
+ *
+ *   oi_pipeline_create(idx, comm_or_NULL, lanes, max_queries, max_query_terms, depth, k, &p)
+ *        idx finalized, not a view; lanes in [1,4] (2 is the measured optimum on one MI355X); every later batch has at most
+ *        max_queries queries of at most max_query_terms terms each (sizes of the staging buffers).  HBM: one set of search
+ *        workspaces per lane (oi_pipeline_workspace_bytes).
+ *   oi_pipeline_submit(p, queries..., n_queries, location, scores_out, docs_out, counts_out, &ticket)
+ *        asynchronous in BOTH locations; tickets count from 1.
+ *        OI_DEVICE: inputs were produced on the index's context stream (oi_set_stream) and must stay unmodified until the
+ *                   batch is waited for; outputs (n_queries x k, k as created) are written by the pipeline's streams.
+ *        OI_HOST:   inputs are copied during the call (reusable at return); the host output arrays are filled by
+ *                   oi_pipeline_wait(ticket) -- or, if nobody waits, when the slot is reused 2 x lanes (>= 4) submits later
+ *                   or at drain -- and must stay valid until then.
+ *   oi_pipeline_wait(p, ticket, host_sync)
+ *        host_sync != 0: returns when that batch's outputs are complete (host outputs delivered).
+ *        host_sync == 0 (OI_DEVICE batches): no host stall -- orders the index's context stream after the batch, so work
+ *                   queued there afterwards may read the outputs.
+ *   oi_pipeline_drain(p)      everything submitted is complete; a candidate-pool overflow in any lane is reported here.
+ *   oi_pipeline_destroy(p)    drains, then frees the lanes (before the index and the communicator).
+ * With a communicator every rank must submit the same batches in the same order from ONE host thread (the collectives
+ * are issued in submission order on one stream), as with oi_search_sharded.  One submitting thread per pipeline; wait /
+ * drain may be called from another.
+ */
+typedef struct oi_pipeline oi_pipeline;
+int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, uint32_t max_queries, uint32_t max_query_terms,
+                       uint32_t depth, uint32_t k, oi_pipeline **out);
+void oi_pipeline_destroy(oi_pipeline *p);
+int oi_pipeline_submit(oi_pipeline *p, const float *query_vecs, const uint32_t *query_terms, const uint32_t *q_term_offsets,
+                       uint32_t n_queries, int location, float *scores_out, uint32_t *docs_out, uint32_t *counts_out,
+                       uint64_t *ticket_out);
+int oi_pipeline_wait(oi_pipeline *p, uint64_t ticket, int host_sync);
+int oi_pipeline_drain(oi_pipeline *p);
+int oi_pipeline_workspace_bytes(oi_pipeline *p, uint64_t *device_bytes_out, uint64_t *pinned_host_bytes_out);
+/* oi_profile_reset / oi_profile_read (below) over the pipeline's lanes, summed (the lanes' contexts are the library's own).
+ * Two lanes' launches overlap in time: the summed durations then exceed the wall time they covered. */
+int oi_pipeline_profile_reset(oi_pipeline *p, int enable);
+int oi_pipeline_profile_read(oi_pipeline *p, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out);
+
 /* Diagnostics of the OI_COSINE_SCREEN mode (tests/test_gpu_prefilter.py; not on the query path).  For host
  * queries [n_queries][dim] against rows [row_begin, row_begin + n_rows) of an f32 index:
  *   screen_scores_out[q * n_rows + r]  the screen's raw score s~ (bf16 operands, the screen's own conversion and

@@ -97,6 +97,25 @@ int main(void) {
             fprintf(stderr, "abi_check: hybrid query returned %u docs, first %u (expected 10, 123)\n", counts[0], docs[0]);
             return 1;
         }
+        { /* the pipelined query (oi_pipeline_*): the same batch three times through two lanes the library owns; every
+           * result must be oi_search's, bit for bit */
+            oi_pipeline *pipe = NULL;
+            float s2[3][10];
+            uint32_t d2[3][10], c2[3];
+            uint64_t ticket[3];
+            int b;
+            if ((rc = oi_pipeline_create(idx, NULL, 2, 1, 8, 100, K, &pipe)) != OI_OK) return fail("oi_pipeline_create", rc);
+            for (b = 0; b < 3; ++b)
+                if ((rc = oi_pipeline_submit(pipe, q, qt, qo, 1, OI_HOST, s2[b], d2[b], &c2[b], &ticket[b])) != OI_OK) return fail("oi_pipeline_submit", rc);
+            if ((rc = oi_pipeline_wait(pipe, ticket[1], 1)) != OI_OK) return fail("oi_pipeline_wait", rc);
+            if ((rc = oi_pipeline_drain(pipe)) != OI_OK) return fail("oi_pipeline_drain", rc);
+            for (b = 0; b < 3; ++b)
+                if (c2[b] != counts[0] || memcmp(d2[b], docs, sizeof(uint32_t) * K) != 0 || memcmp(s2[b], scores, sizeof(float) * K) != 0) {
+                    fprintf(stderr, "abi_check: pipelined batch %d differs from oi_search\n", b);
+                    return 1;
+                }
+            oi_pipeline_destroy(pipe);
+        }
         oi_destroy(ctx); /* any destruction order is fine: the ctx first ... */
         ctx = NULL;
         oi_index_destroy(idx); /* ... the index after it */

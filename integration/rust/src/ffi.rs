@@ -12,6 +12,10 @@ pub struct OiIndex {
     _p: [u8; 0],
 }
 #[repr(C)]
+pub struct OiPipeline {
+    _p: [u8; 0],
+}
+#[repr(C)]
 pub struct OiComm {
     _p: [u8; 0],
 }
@@ -136,6 +140,20 @@ extern "C" {
     pub fn oi_search_sharded(idx: *mut OiIndex, comm: *mut OiComm, query_vecs: *const f32, query_terms: *const u32,
                              q_term_offsets: *const u32, n_queries: u32, depth: u32, k: u32, location: c_int,
                              scores_out: *mut f32, docs_out: *mut u32, counts_out: *mut u32) -> c_int;
+
+    pub fn oi_pipeline_create(idx: *mut OiIndex, comm: *mut OiComm, lanes: u32, max_queries: u32, max_query_terms: u32,
+                              depth: u32, k: u32, out: *mut *mut OiPipeline) -> c_int;
+    pub fn oi_pipeline_destroy(p: *mut OiPipeline);
+    pub fn oi_pipeline_submit(p: *mut OiPipeline, query_vecs: *const f32, query_terms: *const u32,
+                              q_term_offsets: *const u32, n_queries: u32, location: c_int, scores_out: *mut f32,
+                              docs_out: *mut u32, counts_out: *mut u32, ticket_out: *mut u64) -> c_int;
+    pub fn oi_pipeline_wait(p: *mut OiPipeline, ticket: u64, host_sync: c_int) -> c_int;
+    pub fn oi_pipeline_drain(p: *mut OiPipeline) -> c_int;
+    pub fn oi_pipeline_workspace_bytes(p: *mut OiPipeline, device_bytes_out: *mut u64,
+                                       pinned_host_bytes_out: *mut u64) -> c_int;
+    pub fn oi_pipeline_profile_reset(p: *mut OiPipeline, enable: c_int) -> c_int;
+    pub fn oi_pipeline_profile_read(p: *mut OiPipeline, kernel_tag: *const c_char, total_ms_out: *mut f64,
+                                    launches_out: *mut u64) -> c_int;
 
     pub fn oi_screen_probe(idx: *mut OiIndex, query_vecs: *const f32, n_queries: u32, row_begin: u64, n_rows: u32,
                            screen_scores_out: *mut f32, eps_out: *mut f32) -> c_int;

@@ -14,7 +14,7 @@ from .domain import (Alignment, AnalyzerMismatch, Confidence, DomainError, Engin
                      PostSignal, PostText, SocialPost, SourceFailure, SourceKind, Ticker)
 from .engine import SpeculationEngine
 from .sharded import ShardedAnalyzer, ShardedPipeline, ShardedRetriever, make_hip_sharded, make_hip_sharded_analyzer, shard_bounds
-from .retriever import (HybridIndex, NativeComm, PostRetriever, SearchResult, fuse_packed, merge_lists, pack_query_terms,
+from .retriever import (HybridIndex, NativeComm, NativePipeline, PostRetriever, SearchResult, fuse_packed, merge_lists, pack_query_terms,
                         packed_words, rrf_fuse, unpack_lists)
 
 __all__ = [
@@ -23,5 +23,5 @@ __all__ = [
     "unpack_lists", "HeadlineScanner", "company_name_forms", "Alignment",
     "AnalyzerMismatch", "Confidence", "DomainError", "EngineConfig", "MarketSnapshot", "PostSignal", "PostText",
     "SocialPost", "SourceFailure", "SourceKind", "Ticker", "ShardedAnalyzer", "ShardedPipeline", "ShardedRetriever", "make_hip_sharded",
-    "make_hip_sharded_analyzer", "shard_bounds", "NativeComm",
+    "make_hip_sharded_analyzer", "shard_bounds", "NativeComm", "NativePipeline",
 ]

@@ -16,6 +16,15 @@ void oi_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Hardware queues.  HIP spreads the streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams
+// that share a queue run one after the other whatever their events allow.  A two-lane pipeline (oi_pipeline_*, or a host that
+// drives views of an index itself) has seven streams in play -- the caller's, two lanes, the fusing stream, a BM25 side stream
+// each -- so with 4 queues some share, and the lanes' overlap is lost: 0.55 ms per batch at a 1.25M-row shard against 0.465
+// with 8 queues, ten runs each, tools/r05_pipeline_probe.py.  The runtime reads the variable when it initialises, so it is set
+// when this library is LOADED (never overriding the host's own choice); a host that initialises HIP before loading the library
+// sets it itself (bench.py and tests/conftest.py do).  It changes scheduling only, never a result.
+__attribute__((constructor)) static void oi_ask_for_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+
 extern "C" const char *oi_last_error(void) { return g_err; }
 extern "C" int oi_abi_version(void) { return OI_ABI_VERSION; }
 
@@ -274,9 +283,10 @@ extern "C" int oi_create(int device_ordinal, oi_ctx **out) {
         c->cosine_mode = strcmp(m, "split") == 0 ? OI_COSINE_SPLIT : strcmp(m, "exact") == 0 ? OI_COSINE_EXACT
                          : strcmp(m, "screen-copy") == 0 ? OI_COSINE_SCREEN_COPY
                          : strcmp(m, "screen-stream") == 0 ? OI_COSINE_SCREEN_STREAM : OI_COSINE_SCREEN;
-    // best effort: without these the two legs of a query simply run one after the other
-    // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
-    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) c->side_stream = nullptr;
+    // best effort: without these the two legs of a query simply run one after the other.  The side stream itself is made by
+    // the first hybrid search of the context (ensure_side_stream): a context that never runs one -- the fusing context of a
+    // pipeline, a lexicon-only host -- does not take one of the process's few hardware queues (HIP hands streams of one priority
+    // out over GPU_MAX_HW_QUEUES = 4 of them; two streams on one queue run one after the other whatever the events say).
     // (fork / join ORDER the side stream's kernels against the main stream's through hipStreamWaitEvent: they keep the default
     // fence -- hipEventDisableSystemFence is documented for timing events only; the ~12 us it saved per step in round 4 rested
     // on the kernels' own release semantics, an implementation detail of the runtime)
@@ -1194,6 +1204,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
     // leaves, instead of running after it.  OI_NO_OVERLAP=1 serialises them (A/B runs).
     static const bool no_overlap = oi_ablation_env("OI_NO_OVERLAP") != nullptr;
+    if (cos_s && bm_s && !ctx->side_stream && !ctx->side_stream_failed && ctx->overlap_legs && !no_overlap) {
+        // (default priority: at the lowest one the BM25 leg stretched over the whole cosine leg and the step was no shorter)
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { ctx->side_stream = nullptr; ctx->side_stream_failed = true; }
+    }
     const bool overlap = cos_s && bm_s && ctx->side_stream && ctx->ev_fork && ctx->ev_join && ctx->overlap_legs && !no_overlap;
     // ---- BM25 list
     auto bm25_leg = [&]() -> int {

@@ -26,6 +26,10 @@
 #include "oi_device.h"
 #include "oi_internal.h"
 
+#ifndef OI_BF16_SIB_DEFAULT
+#define OI_BF16_SIB_DEFAULT 0
+#endif
+
 typedef float cb_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 cb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t cb_u32x4 __attribute__((ext_vector_type(4)));
@@ -401,10 +405,28 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_pair(
 template <int D, int DBG = 0> // DBG (ablation builds): 1 = no reduction / epilogue / barriers (streaming + MFMA only), 2 = no epilogue work
 __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
-    const uint16_t *__restrict__ queries, // bf16 [128][D], zero padded
+    const uint16_t *__restrict__ queries, // bf16 [128 (x 2 with siblings)][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
-    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow, uint32_t sib) {
     constexpr int NQT = 4;
+    // SIBLINGS (round 5).  256 queries at d = 1024 are two passes of this kernel over the corpus; one CU cannot hold more than
+    // 128 queries (the 256 x 1024 bf16 block IS the register file of a CU).  With sib != 0 the two passes run as ONE launch:
+    // the grid is cut into pairs of workgroups that walk the SAME tile sequence, one with queries 0..127 and one with 128..255
+    // (own pool segments, own thresholds), so a tile fetched from HBM by whichever sibling gets there first is read by the other
+    // out of cache -- HBM sees the corpus once per 256 queries instead of twice.  A sibling that hits cache runs faster until
+    // it leads and misses: the pair stays together by itself, nothing synchronises them.
+    //   sib == 1: siblings are blockIdx 2j, 2j + 1 (dispatched to neighbouring XCDs: they share the memory-side Infinity Cache)
+    //   sib == 2: siblings are 16 a + x and 16 a + 8 + x (x = blockIdx % 8: the SAME XCD under round-robin dispatch -- they share its L2)
+    uint32_t half = 0, wg = blockIdx.x, n_wg = gridDim.x;
+    if (sib == 1) { half = blockIdx.x & 1u; wg = blockIdx.x >> 1; n_wg = gridDim.x >> 1; }
+    else if (sib == 2) { half = (blockIdx.x >> 3) & 1u; wg = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u); n_wg = gridDim.x >> 1; }
+    if (half) { // (uniform) the second 128 queries: their block of every per-query array
+        queries += (uint64_t)128 * D;
+        pools += (uint64_t)128 * pool_stride;
+        seg_cnt += (uint64_t)128 * seg_cnt_stride;
+        tau_keys += 128;
+        n_queries = n_queries > 128u ? n_queries - 128u : 0u;
+    } else if (sib && n_queries > 128u) n_queries = 128u;
     constexpr int KQ = D / 4;                 // K of one wave
     constexpr int NKC = KQ / CB_SLOT_K;       // ring slots per tile and wave
     constexpr int NBUF = NKC;
@@ -438,12 +460,12 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     if (tid < 32 * NQT) seg_fill[tid] = 0;
     __syncthreads();
 
-    // ---- tiles of this WORKGROUP: blockIdx.x, + gridDim.x, ...
+    // ---- tiles of this WORKGROUP (of this sibling pair): wg, + n_wg, ...
     const uint64_t n_rows = row_end - row_begin;
     const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
-    const uint64_t first = blockIdx.x, stride = gridDim.x;
+    const uint64_t first = wg, stride = n_wg;
     const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
-    uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)wg * seg_cap;
 
     uint32_t voff[4];
 #pragma unroll
@@ -602,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     __syncthreads();
     if (tid < 32 * NQT && tid < n_queries) {
         const uint32_t c = seg_fill[tid];
-        seg_cnt[(uint64_t)tid * seg_cnt_stride + blockIdx.x] = c < seg_cap ? c : seg_cap;
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + wg] = c < seg_cap ? c : seg_cap;
     }
 }
 
@@ -637,10 +659,18 @@ static uint32_t cb_group(uint32_t dim, uint32_t left) {
 
 // Pool geometry of one chunk.  Segments are per workgroup; a workgroup's waves take 4 tiles per round
 // (solo kernel) or 2 (pair kernel) -- the cap below covers both.
-void oi_cosine_bf16_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap) {
+// How 256 queries at d = 1024 take their two passes of 128 (the quad kernel): 0 = two launches one after the other (rounds
+// 2-4), 1 / 2 = ONE launch of sibling workgroups sharing every tile through the Infinity Cache / the XCD's L2 (see the kernel).
+static uint32_t cb_sibling_mode() {
+    const char *e = oi_ablation_env("OI_BF16_SIB");
+    return e ? (uint32_t)atoi(e) : OI_BF16_SIB_DEFAULT;
+}
+void oi_cosine_bf16_geometry(const oi_ctx *ctx, uint64_t n_rows, uint32_t *n_segs, uint32_t *seg_cap, bool siblings) {
     const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
     const uint64_t quads = (n_tiles + 3) / 4;
-    const uint64_t grid = quads < (uint64_t)ctx->num_cus ? (quads ? quads : 1) : (uint64_t)ctx->num_cus;
+    const uint64_t cus = siblings ? std::max<uint64_t>(8, ((uint64_t)ctx->num_cus / 16) * 8) : (uint64_t)ctx->num_cus; // pairs of workgroups: half the grid, whole XCD rounds
+    uint64_t grid = quads < cus ? (quads ? quads : 1) : cus;
+    if (siblings && grid >= 8) grid -= grid % 8; // (the same-XCD pairing addresses workgroups in groups of 16 = 8 pairs)
     *n_segs = (uint32_t)grid;
     *seg_cap = (uint32_t)((quads + grid - 1) / grid) * 4 * CB_TILE_ROWS;
 }
@@ -674,7 +704,8 @@ static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
 
 template <int D>
 static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
-                            uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+                            uint32_t nq, uint32_t doc_id_base, const PoolView &p, uint32_t sib = 0) {
+    const uint32_t grid = sib ? 2u * p.n_segs : p.n_segs; // (siblings: p.n_segs pairs, one pool segment per pair and query half)
     constexpr int NKC = D / 4 / CB_SLOT_K;
     constexpr size_t smem = 4 * NKC * CB_SLOT_BYTES + 16 * (16 * 64) * 4 + 128 * 4;
     static_assert(smem <= 160 * 1024, "LDS");
@@ -684,16 +715,16 @@ static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
     if (dbg >= 1 && dbg <= 3) {
         auto kern = dbg == 1 ? cosine_bf16_quad<D, 1> : dbg == 2 ? cosine_bf16_quad<D, 2> : cosine_bf16_quad<D, 3>;
         OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(kern), (size_t)(smem)));
-        hipLaunchKernelGGL(kern, dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq, doc_id_base, p.keys,
-                           p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap, p.overflow);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq, doc_id_base, p.keys,
+                           p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap, p.overflow, sib);
         OI_HIP_CHECK(hipGetLastError());
         return OI_OK;
     }
 #endif
     OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_quad<D>), (size_t)(smem)));
-    hipLaunchKernelGGL((cosine_bf16_quad<D>), dim3(p.n_segs), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
+    hipLaunchKernelGGL((cosine_bf16_quad<D>), dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
                        doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap,
-                       p.overflow);
+                       p.overflow, sib);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
@@ -702,7 +733,12 @@ static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
 int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, uint32_t dim,
                                 const float *d_queries, uint32_t n_queries, uint32_t doc_id_base, PoolView &pool) {
     OI_REQUIRE(oi_cosine_bf16_supported(dim), "cosine (bf16 corpus): dim %u not instantiated (384, 768, 1024)", dim);
-    oi_cosine_bf16_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap);
+    // siblings: every group of this batch is a full pair of 128-query passes (256, 512, ... queries at d = 1024) and the chunk
+    // is long enough to give every pair of workgroups a tile
+    const uint32_t sib_mode = cb_sibling_mode();
+    const bool siblings = sib_mode != 0 && dim == 1024 && n_queries >= 256 && n_queries % 256 == 0 &&
+                          row_end > row_begin && (row_end - row_begin) >= (uint64_t)CB_TILE_ROWS * ctx->num_cus;
+    oi_cosine_bf16_geometry(ctx, row_end > row_begin ? row_end - row_begin : 0, &pool.n_segs, &pool.seg_cap, siblings);
     OI_REQUIRE(pool.n_segs <= pool.seg_cnt_stride && pool.carry_cap + (uint64_t)pool.n_segs * pool.seg_cap <= pool.stride,
                "cosine (bf16 corpus): chunk does not fit the candidate pool");
     if (row_end <= row_begin || n_queries == 0) return OI_OK;
@@ -723,6 +759,7 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
         const uint32_t left = n_queries - q0;
         uint32_t group = solo_only ? (dim == 1024 ? 32u : 64u) : cb_group(dim, left);
         if (no_quad && group > 96u) group = 96u;
+        if (siblings) group = 256u;
         const uint32_t nq_here = std::min(group, left);
         const uint32_t nqt = (nq_here + 31u) / 32u; // query tiles of 32 in this launch
         PoolView p = pool;
@@ -735,7 +772,8 @@ int oi_launch_cosine_bf16_chunk(oi_ctx *ctx, const uint16_t *rows, uint64_t row_
 #define CB_PAIR(DD, T) OI_CHECK((launch_bf16_pair<DD, T>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)))
         const bool pair = nq_here > (dim == 1024 ? 32u : 64u);
         if (dim == 1024) {
-            if (nq_here > 96u) OI_CHECK((launch_bf16_quad<1024>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
+            if (nq_here > 128u) OI_CHECK((launch_bf16_quad<1024>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p, sib_mode)));
+            else if (nq_here > 96u) OI_CHECK((launch_bf16_quad<1024>(ctx, rows, row_begin, row_end, qptr, nq_here, doc_id_base, p)));
             else if (!pair) CB_SOLO(1024, 1);
             else if (nqt == 2) CB_PAIR(1024, 2);
             else CB_PAIR(1024, 3);

@@ -118,7 +118,8 @@ struct oi_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg
+    hipStream_t side_stream = nullptr;     // the BM25 leg of a hybrid query runs here, beside the cosine leg (made by the first hybrid search)
+    bool side_stream_failed = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap_legs = true;              // oi_set_overlap
     int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default),

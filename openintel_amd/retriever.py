@@ -325,6 +325,79 @@ class NativeComm:
             pass
 
 
+class NativePipeline:
+    """Several batches in flight through the library's own lanes (oi_pipeline_*): the pipelined -- and, with a NativeComm,
+    row-sharded -- query without torch streams or torch.distributed on the data path.
+
+        pipe = NativePipeline(idx, lanes=2, max_queries=64, max_query_terms=4, depth=1000, k=100)   # comm=NativeComm(...) to shard
+        t = pipe.submit(qv, qt, qo, out=result_slot)     # asynchronous (device tensors or numpy arrays)
+        pipe.wait(t)                                     # that batch's outputs are complete
+        pipe.drain(); pipe.close()
+
+    Device batches: `out` (a SearchResult of device tensors, shape (n_queries, k)) must be a distinct buffer per batch in
+    flight; inputs stay unmodified until wait().  Results are bit-identical to HybridIndex.search / search_sharded."""
+
+    def __init__(self, index: "HybridIndex", lanes: int = 2, max_queries: int = 64, max_query_terms: int = 16,
+                 depth: int = DEFAULT_DEPTH, k: int = DEFAULT_K, comm: Optional["NativeComm"] = None):
+        self.index, self.lib, self.comm = index, index.lib, comm
+        self.k, self.depth, self.max_queries = int(k), int(depth), int(max_queries)
+        h = C.c_void_p()
+        _lib.check(self.lib.oi_pipeline_create(index.handle, comm.handle if comm is not None else None, int(lanes),
+                                               int(max_queries), int(max_query_terms), int(depth), int(k), C.byref(h)))
+        self.handle = h
+        self._keep = {}   # ticket -> (inputs, outputs): host arrays / tensors the library still reads or writes
+
+    def submit(self, query_vecs, query_terms, q_term_offsets, out: Optional[SearchResult] = None):
+        dev, B, qv, qt, qo = self.index._queries(query_vecs, query_terms, q_term_offsets)
+        if out is None:
+            out = SearchResult(self.index._alloc(dev, (B, self.k), np.float32), self.index._alloc(dev, (B, self.k), np.uint32),
+                               self.index._alloc(dev, (B,), np.uint32))
+        t = C.c_uint64()
+        _lib.check(self.lib.oi_pipeline_submit(self.handle, _lib.ptr(qv), _lib.ptr(qt), _lib.ptr(qo), B,
+                                               _lib.OI_DEVICE if dev else _lib.OI_HOST, _lib.ptr(out.scores), _lib.ptr(out.docs),
+                                               _lib.ptr(out.counts), C.byref(t)))
+        self._keep[int(t.value)] = ((qv, qt, qo), out)
+        if len(self._keep) > 64:
+            for old in sorted(self._keep)[:-32]:      # (slots that old were reused long ago: the library is done with them)
+                del self._keep[old]
+        return int(t.value), out
+
+    def wait(self, ticket: int, host_sync: bool = True) -> None:
+        _lib.check(self.lib.oi_pipeline_wait(self.handle, int(ticket), 1 if host_sync else 0))
+        if host_sync:
+            self._keep.pop(int(ticket), None)
+
+    def drain(self) -> None:
+        _lib.check(self.lib.oi_pipeline_drain(self.handle))
+        self._keep.clear()
+
+    def workspace_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _lib.check(self.lib.oi_pipeline_workspace_bytes(self.handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def profile_reset(self, enable) -> None:
+        _lib.check(self.lib.oi_pipeline_profile_reset(self.handle, int(enable)))
+
+    def profile_read(self, tag: str):
+        """(summed ms, launches) of the lanes' launches with that tag since the last reset (oi_pipeline_profile_read)."""
+        ms, n = C.c_double(), C.c_uint64()
+        _lib.check(self.lib.oi_pipeline_profile_read(self.handle, tag.encode(), C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.oi_pipeline_destroy(self.handle)
+            self.handle = None
+            self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------- list-level ops (any ctx)
 def rrf_fuse(ctx: HipContext, docs_a, counts_a, docs_b, counts_b, k: int) -> SearchResult:
     dev = _is_dev(docs_a)

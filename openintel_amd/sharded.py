@@ -116,6 +116,40 @@ class ShardedRetriever:
             ctx.synchronize()
 
 
+def calibrate_lanes(lane0, period: Callable, make_lane: Callable, drop_lane: Callable, use: Callable, placements: int,
+                    max_lanes: int):
+    """The decision loop of ShardedPipeline.calibrate, free of streams and devices so that its ONE invariant can be tested
+    with gloo on CPU (tests/test_sharded_gloo.py): the number of period() calls -- each of which runs a fixed number of
+    batches, i.e. of all-gathers -- is 1 + (max_lanes - 1) * placements on every rank, whatever the timings say.
+
+    period() -> ms per batch with the lanes last given to use(lanes); make_lane() -> a fresh lane; drop_lane(lane) frees one.
+    Returns (kept lanes, best ms, the list of trials)."""
+    kept = [lane0]
+    use(kept)
+    tried = [{"lanes": 1, "ms": period()}]
+    best_ms = tried[0]["ms"]
+    searching = True
+    for n_lanes in range(2, max(2, int(max_lanes)) + 1):
+        best_lane = None
+        for p in range(max(0, int(placements))):
+            lane = make_lane()
+            use(kept + [lane])
+            ms = period()                                  # (run on EVERY rank, adopted or not: the collectives stay in step)
+            tried.append({"lanes": n_lanes, "placement": p, "ms": ms, "considered": searching})
+            if searching and ms < 0.97 * best_ms:          # another lane has to earn its keep
+                if best_lane is not None:
+                    drop_lane(best_lane)
+                best_ms, best_lane = ms, lane
+            else:
+                drop_lane(lane)
+        if best_lane is None:
+            searching = False                              # later levels are still timed (and discarded), see above
+        else:
+            kept.append(best_lane)
+        use(kept)
+    return kept, best_ms, tried
+
+
 class ShardedPipeline:
     """Throughput mode of the sharded query (GPU only).  Batches are independent, so
       * the exchange + fusion of batch i run on a second stream (`fuse_ctx`) while the shard's lists of batch i+1 are
@@ -249,13 +283,15 @@ class ShardedPipeline:
         """Choose the number of lanes EMPIRICALLY, and each added lane's stream with it.
 
         Whether another lane pays depends on which hardware queue its stream lands on (HIP streams share a handful of
-        queues, handed out round-robin at creation; measured at a 1.25M-row shard, same code: 0.745-0.82 ms per batch
-        when the two lanes' streams do not share a queue with each other's corpus passes, 0.88-0.92 -- no gain -- or worse
-        when they do).  So: time `reps` batches with lane 0 alone, then -- lane by lane up to
-        `max_lanes` -- with each of `placements` freshly created (context, stream, view) as the next lane; a lane is kept if
-        its best placement is at least 3 % faster than the set-up without it, the search stops at the first lane that is not.
-        Every rank runs the same number of batches (the collectives stay in step); the choice itself is local to the rank.
-        `make_ctx()` returns a new HipContext of this device, configured like the retriever's."""
+        queues; measured at a 1.25M-row shard, same code: 0.745-0.82 ms per batch when the two lanes' streams do not share
+        a queue with each other's corpus passes, 0.88-0.92 -- no gain -- or worse when they do; round 5:
+        bench.py and the library ask for 8 hardware queues, GPU_MAX_HW_QUEUES, which makes the good placement the rule).
+        So: time `reps` batches with lane 0 alone, then -- lane by lane up to `max_lanes` -- with each of `placements`
+        freshly created (context, stream, view) as the next lane; a lane is kept if its best placement is at least 3 % faster
+        than the set-up without it; a rank that stopped adopting lanes still RUNS every later trial (and throws it away).
+        EVERY RANK RUNS THE SAME NUMBER OF BATCHES, whatever it decides: each batch is one all-gather when world > 1, so the
+        collective counts must not depend on a rank's own timings (they did for max_lanes >= 3).  The choice
+        itself is local to the rank.  `make_ctx()` returns a new HipContext of this device, configured like the retriever's."""
         import time
 
         import torch
@@ -273,33 +309,22 @@ class ShardedPipeline:
             torch.cuda.synchronize(self.dev)
             return (time.perf_counter() - t0) / reps * 1e3
 
-        kept = [self.lanes[0]]
-        tried = [{"lanes": 1, "ms": period()}]
-        best_ms = tried[0]["ms"]
-        searching = True
-        for n_lanes in range(2, max(2, int(max_lanes)) + 1):
-            best_lane = None
-            for p in range(max(0, placements) if searching else 0):   # (a rank that stopped still runs no further trials: every
-                c = make_ctx()                                        # rank's collectives are its own batches', nothing is shared)
-                st = torch.cuda.Stream(device=self.dev)
-                c.set_stream(st)
-                c.set_graph_replay(self.graphs)
-                lane = (self.r.local.view(c), st)
-                self.lanes = kept + [lane]
-                ms = period()
-                tried.append({"lanes": n_lanes, "placement": p, "ms": ms})
-                if ms < 0.97 * best_ms:            # another lane has to earn its keep
-                    if best_lane is not None:
-                        best_lane[0].close()
-                        best_lane[0].ctx.close()
-                    best_ms, best_lane = ms, lane
-                else:
-                    lane[0].close()
-                    c.close()
-            if best_lane is None:
-                searching = False
-            else:
-                kept.append(best_lane)
+        def make_lane():
+            c = make_ctx()
+            st = torch.cuda.Stream(device=self.dev)
+            c.set_stream(st)
+            c.set_graph_replay(self.graphs)
+            return (self.r.local.view(c), st)
+
+        def drop_lane(lane):
+            c = lane[0].ctx
+            lane[0].close()
+            c.close()
+
+        def use(lanes):
+            self.lanes = lanes
+
+        kept, best_ms, tried = calibrate_lanes(self.lanes[0], period, make_lane, drop_lane, use, placements, max_lanes)
         self.lanes = kept
         self.calibration = {"chosen_lanes": len(self.lanes), "period_ms": best_ms, "tried": tried}
         return self.calibration

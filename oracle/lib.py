@@ -183,12 +183,17 @@ def lexicon_score(text: bytes | str):
     return pol.value, bool(spec.value), bull.value, bear.value
 
 
-def lexicon_analyze(blob: np.ndarray, offsets: np.ndarray):
+def lexicon_analyze(blob: np.ndarray, offsets: np.ndarray, n_threads: int = 1):
+    """(polarity f64[n], speculative u8[n]).  n_threads > 1: the same scalar `score` per post on that many host threads
+    (bench.py's all-cores baseline; the reference itself maps on one thread, lexicon.rs:82-87)."""
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = offsets.size - 1
     pol = np.empty(n, dtype=np.float64)
     spec = np.empty(n, dtype=np.uint8)
+    if n_threads > 1:
+        _L().oio_lexicon_analyze_mt(_p(blob), _p(offsets), C.c_uint64(n), _p(pol), _p(spec), C.c_int(n_threads))
+        return pol, spec
     rc = _L().oio_lexicon_analyze(_p(blob), _p(offsets), C.c_uint64(n), _p(pol), _p(spec))
     assert rc == 0
     return pol, spec
@@ -209,8 +214,9 @@ def pack_forms(forms: Sequence[bytes | str]):
     return blob, offs
 
 
-def headline_scan(blob: np.ndarray, offsets: np.ndarray, ticker: bytes | str, forms: Sequence[bytes | str]):
-    """(mask u16[n], order u64[n], about u8[n]) over a batch of titles."""
+def headline_scan(blob: np.ndarray, offsets: np.ndarray, ticker: bytes | str, forms: Sequence[bytes | str], n_threads: int = 1):
+    """(mask u16[n], order u64[n], about u8[n]) over a batch of titles (n_threads > 1: the same scalar functions per title on
+    that many host threads -- bench.py's all-cores baseline)."""
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     if blob.size == 0:
         blob = np.zeros(1, np.uint8)
@@ -222,6 +228,10 @@ def headline_scan(blob: np.ndarray, offsets: np.ndarray, ticker: bytes | str, fo
     mask = np.zeros(n, np.uint16)
     order = np.zeros(n, np.uint64)
     about = np.zeros(n, np.uint8)
+    if n_threads > 1:
+        _L().oio_headline_scan_mt(_p(blob), _p(offsets), C.c_uint64(n), _p(tkb), C.c_uint64(len(tk)), _p(fblob),
+                                  _p(foffs), C.c_uint32(len(forms)), _p(mask), _p(order), _p(about), C.c_int(n_threads))
+        return mask, order, about
     _L().oio_headline_scan(_p(blob), _p(offsets), C.c_uint64(n), _p(tkb), C.c_uint64(len(tk)), _p(fblob),
                            _p(foffs), C.c_uint32(len(forms)), _p(mask), _p(order), _p(about))
     return mask, order, about

@@ -734,3 +734,51 @@ int oio_hybrid_search_batch_blocked(const float *rows, uint64_t n_docs, uint32_t
     free(df_local);
     return used;
 }
+
+/* ---- all-cores drivers of the two text paths for the CPU baseline (bench.py) ---------------------------------------
+ * The reference maps `score` over the posts on ONE thread (lexicon.rs:82-87) and scans titles one by one (dip.rs:247-272);
+ * posts and titles are independent, so the all-cores baseline runs the SAME scalar function per item on n_threads threads
+ * (static chunks of posts, outputs index-aligned as the port requires -- post_analyzer.rs:9).  Returns the threads used. */
+int oio_lexicon_analyze_mt(const uint8_t *blob, const uint64_t *offsets, uint64_t n, double *polarity_out,
+                           uint8_t *speculative_out, int n_threads) {
+    int used = 1;
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+#endif
+        for (int64_t i = 0; i < (int64_t)n; i++)
+            oio_lexicon_score(blob + offsets[i], offsets[i + 1] - offsets[i], &polarity_out[i], &speculative_out[i], NULL, NULL);
+    }
+    return used;
+}
+
+int oio_headline_scan_mt(const uint8_t *blob, const uint64_t *offsets, uint64_t n, const uint8_t *ticker, uint64_t ticker_len,
+                         const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms, uint16_t *mask_out,
+                         uint64_t *order_out, uint8_t *about_out, int n_threads) {
+    int used = 1;
+    if (n_threads < 1) n_threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(n_threads)
+#endif
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#pragma omp for schedule(static)
+#endif
+        for (int64_t i = 0; i < (int64_t)n; i++) {
+            const uint8_t *t = blob + offsets[i];
+            const uint64_t l = offsets[i + 1] - offsets[i];
+            oio_catalyst_hits(t, l, &mask_out[i], &order_out[i]);
+            about_out[i] = (uint8_t)oio_headline_mentions_company(t, l, ticker, ticker_len, forms_blob, form_offsets, n_forms);
+        }
+    }
+    return used;
+}
+

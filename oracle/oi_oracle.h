@@ -283,6 +283,13 @@ int oio_hybrid_search_batch_blocked(const float *rows, uint64_t n_docs, uint32_t
                             int n_threads, float *scores_out, uint32_t *docs_out, uint32_t *counts_out);
 /* Host threads OpenMP would use by default (1 when built without it). */
 int oio_max_threads(void);
+/* The two text paths on n_threads host threads (bench.py's all-cores CPU baselines): the same scalar function per post /
+ * title as oio_lexicon_analyze / oio_headline_scan, static chunks, index-aligned outputs.  Return the threads used. */
+int oio_lexicon_analyze_mt(const uint8_t *blob, const uint64_t *offsets, uint64_t n, double *polarity_out,
+                           uint8_t *speculative_out, int n_threads);
+int oio_headline_scan_mt(const uint8_t *blob, const uint64_t *offsets, uint64_t n, const uint8_t *ticker, uint64_t ticker_len,
+                         const uint8_t *forms_blob, const uint32_t *form_offsets, uint32_t n_forms, uint16_t *mask_out,
+                         uint64_t *order_out, uint8_t *about_out, int n_threads);
 
 #ifdef __cplusplus
 }

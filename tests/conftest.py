@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # as the library asks when it is loaded first (csrc/api.hip): before HIP initialises
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -276,3 +276,58 @@ def test_two_ranks_ticker_shards_equal_the_unsharded_per_ticker_sums(n, n_ticker
     ref = _oracle_records(texts, src, _ticker_cuts(n, n_tickers, 5))
     assert ret[0] == ret[1] == ref.tobytes()
 
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ShardedPipeline.calibrate(max_lanes >= 3) let ranks run different numbers of batches -- a rank whose
+# second lane had not earned its 3 % ran no trials at the third level, one that kept it ran `placements` more -- and every
+# batch is one all-gather: RCCL hangs, gloo mispairs.  The decision loop (sharded.calibrate_lanes) now times every level on
+# every rank and discards what a stopped rank measures.  Here two gloo ranks DISAGREE (rank 0's second lane pays, rank 1's
+# does not) with a period() that is a real collective: the counts must match, nobody may hang, and each keeps its own choice.
+def _calibrate_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openintel_amd.sharded import calibrate_lanes
+        state = {"lanes": None, "periods": 0, "made": 0, "dropped": 0}
+        # scripted ms per (number of lanes): rank 0 gains 20 % from a second lane and nothing from a third; rank 1 gains nothing
+        script = {0: {1: 1.00, 2: 0.80, 3: 0.79}, 1: {1: 1.00, 2: 0.99, 3: 0.60}}[rank]
+
+        def period():
+            state["periods"] += 1
+            mine = torch.tensor([rank * 1000 + state["periods"]], dtype=torch.int64)
+            allv = torch.zeros(world, dtype=torch.int64)
+            dist.all_gather_into_tensor(allv, mine)                       # the collective every batch of the real period() runs
+            assert [int(x) % 1000 for x in allv] == [state["periods"]] * world, "ranks are at different trials"
+            return script[len(state["lanes"])]
+
+        def make_lane():
+            state["made"] += 1
+            return ("lane", state["made"])
+
+        def drop_lane(lane):
+            state["dropped"] += 1
+
+        def use(lanes):
+            state["lanes"] = list(lanes)
+
+        kept, best, tried = calibrate_lanes(("lane", 0), period, make_lane, drop_lane, use, placements=3, max_lanes=3)
+        ret[rank] = {"kept": len(kept), "best": best, "periods": state["periods"], "made": state["made"], "dropped": state["dropped"],
+                     "considered": [t.get("considered", True) for t in tried]}
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibrate_runs_the_same_number_of_collectives_on_ranks_that_disagree():
+    import torch.multiprocessing as mp
+    ret = mp.Manager().dict()
+    mp.spawn(_calibrate_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["periods"] == b["periods"] == 1 + 2 * 3                  # one lane, then 3 placements at each of two levels: on BOTH ranks
+    assert a["kept"] == 2 and abs(a["best"] - 0.80) < 1e-12           # rank 0: the second lane pays, the third (0.79 vs 0.80: < 3 %) does not
+    assert b["kept"] == 1 and abs(b["best"] - 1.00) < 1e-12           # rank 1: stopped at one lane -- its 0.60 at three lanes was timed and DISCARDED
+    assert b["considered"] == [True, True, True, True, False, False, False]
+    assert a["made"] == b["made"] == 6 and a["dropped"] == 5 and b["dropped"] == 6   # every rejected lane is closed
