@@ -335,6 +335,9 @@ def main():
                          "the C ABI gets; torch.distributed then only ships the communicator's 128-byte id)")
     ap.add_argument("--no-pipelined-side", action="store_true",
                     help="N = 1: skip the side measurement of the native two-lane pipeline (pipelined_native)")
+    ap.add_argument("--lane-bm25", choices=["side", "inline"], default="inline",
+                    help="N > 1, lanes > 1 (torch exchange): a lane's BM25 leg on a side stream of its own (as in oi_search) or inside the "
+                         "lane's stream (fewer streams contending for the hardware queues; the other lane's corpus stream is what it overlaps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-text-paths", action="store_true",
                     help="N = 1: skip the reference-pinned paths' blocks (lexicon_path, headline_path: SURVEY 8 rows A1-A4, f-3)")
@@ -404,22 +407,7 @@ def main():
     lo, hi = sharded.shard_bounds(args.docs, world, rank)
     n_local = hi - lo
     t_build = time.perf_counter()
-    rows = synth.embeddings_torch(n_local, args.dim, dev, seed=synth.SEED_EMB + rank)
-    terms, offs = synth.forward_index_torch(n_local, dev, vocab=args.vocab, seed=synth.SEED_TEXT + rank)
     idx = oi.HybridIndex(ctx, n_local, args.dim, args.vocab, doc_id_base=lo)
-    if args.corpus == "bf16":
-        rows = rows.to(torch.bfloat16)                 # stored as bf16 (unit norm up to the rounding)
-        idx.set_embeddings_bf16(rows)
-    else:
-        idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
-    if args.no_screen_copy_index:
-        idx.set_screen_copy(idx.SCREEN_COPY_NEVER)
-    idx.set_forward(terms, offs)
-    idx.set_max_query_terms(4)                          # the synthetic queries have exactly 4 terms
-    idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE, "stream": idx.BM25_STREAM}[args.bm25])
-    n_tokens_local = int(offs[-1].item())
-    del terms, offs
-    torch.cuda.empty_cache()
     sr = sharded.make_hip_sharded(ctx, idx, dev)
     if force_dist:
         sr.exchange = True
@@ -431,11 +419,47 @@ def main():
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
         native_comm = oi.NativeComm(ctx, ids[0], rank, world)
-        idx.finalize_sharded(native_comm)              # ncclAllReduce of df / N / tokens inside the library
+
+    def set_text():
+        terms, offs = synth.forward_index_torch(n_local, dev, vocab=args.vocab, seed=synth.SEED_TEXT + rank)
+        idx.set_forward(terms, offs)
+        idx.set_max_query_terms(4)                      # the synthetic queries have exactly 4 terms
+        idx.set_bm25_mode({"scan": idx.BM25_SCAN, "taat": idx.BM25_TAAT, "wave": idx.BM25_WAVE, "stream": idx.BM25_STREAM}[args.bm25])
+        nt = int(offs[-1].item())
+        del terms, offs
+        torch.cuda.empty_cache()
+        return nt
+
+    def finalize_index():
+        if native_comm is not None:
+            idx.finalize_sharded(native_comm)          # ncclAllReduce of df / N / tokens inside the library
+        else:
+            sr.finalize()                              # all-reduce of df / N / tokens when world > 1
+
+    if args.corpus == "bf16":
+        # configs[4]'s regime, sized for one GPU's 288 GB (100M x 1024 bf16 = 204.8 GB of rows): the text index is
+        # built and finalized FIRST -- its build scratch (sort keys twice, unique keys, tf: ~36 B per token) is gone before the
+        # rows exist -- and the rows are generated in slices straight into their bf16 matrix (a whole f32 copy would not fit)
+        n_tokens_local = set_text()
+        finalize_index()
+        torch.cuda.empty_cache()
+        rows = torch.empty((n_local, args.dim), dtype=torch.bfloat16, device=dev)
+        slice_rows = 2_500_000
+        for r in range(0, n_local, slice_rows):
+            e = min(n_local, r + slice_rows)           # (unit norm up to the rounding; every slice its own seed)
+            rows[r:e] = synth.embeddings_torch(e - r, args.dim, dev, seed=synth.SEED_EMB + rank + 1000003 * (r // slice_rows)).to(torch.bfloat16)
+        torch.cuda.empty_cache()
+        idx.set_embeddings_bf16(rows)
     else:
-        sr.finalize()                                  # all-reduce of df / N / tokens when world > 1
+        rows = synth.embeddings_torch(n_local, args.dim, dev, seed=synth.SEED_EMB + rank)
+        idx.set_embeddings(rows, normalize=False)      # rows are generated unit-norm
+        if args.no_screen_copy_index:
+            idx.set_screen_copy(idx.SCREEN_COPY_NEVER)
+        n_tokens_local = set_text()
+        finalize_index()                               # (and the bf16 screening copy, budget permitting)
     _, df_local = idx.local_stats()                    # for the BM25 leg's algorithmic bytes (rank 0 reports)
     rows_owned_b, screen_copy_b, bm25_index_b = idx.index_bytes()
+    hbm_free_b, hbm_total_b = torch.cuda.mem_get_info(dev)     # after the index is resident, before the search workspaces exist
     # what the default scorer's screen streams on this rank: the index's bf16 screening copy if finalize made it
     copy_streamed = (args.corpus == "f32" and args.cosine in ("screen", "screen-copy") and args.batch > 8 and args.dim in (384, 768)
                      and (screen_copy_b > 0 or args.cosine == "screen-copy"))
@@ -514,7 +538,11 @@ def main():
             def make_lane_ctx():
                 c = oi.HipContext(local_rank)
                 c.set_cosine_mode(MODES[args.cosine])
+                if args.lane_bm25 == "inline":
+                    c.set_overlap(False)
                 return c
+            if args.lane_bm25 == "inline":
+                pipe.lane0_ctx.set_overlap(False)
             pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4, max_lanes=args.lanes)
         lane_ctxs = [index.ctx for index, _ in pipe.lanes]   # every lane scores on a context of its own (lane 0 too)
 
@@ -559,6 +587,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enqueued = time.perf_counter() - t0    # (host time of the K calls alone: shows a host-bound loop)
     fence()
     elapsed = time.perf_counter() - t0
     tm_own = elapsed
@@ -573,6 +602,7 @@ def main():
         return
     # every rank's own set-up and clock (rank 0 prints them all: a scaling number can be tied to the lanes that produced it)
     mine = {"rank": rank, "docs_per_gpu": n_local, "doc_id_base": lo, "own_elapsed_ms_per_step": float(tm_own) / args.steps * 1e3,
+            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "lane_calibration": pipe.calibration if pipe is not None else None,
             "lanes": (len(pipe.lanes) if pipe is not None else 1), "exchange": args.exchange if (world > 1 or force_dist) else None,
             # HBM of the searching contexts' workspaces on this rank (the index itself not counted)
@@ -784,6 +814,11 @@ def main():
         if args.corpus == "bf16":
             roof["kernel"] = "cosine over the bf16 corpus (bf16 MFMA, all corpus-chunk launches of a batch)"
         roof["corpus_passes_per_batch"] = passes
+        if args.corpus == "bf16" and args.dim == 1024 and args.batch >= 256 and args.batch % 256 == 0:
+            roof["sibling_workgroups"] = ("every 256 queries are ONE launch of sibling workgroups (cosine_bf16_quad<.., SIB=2>): two workgroups of an XCD walk "
+                                          "the same tile sequence with 128 queries each and share every tile through that XCD's L2 -- the CUs stream the "
+                                          "corpus twice (corpus_passes_per_batch), HBM sees it once (FETCH_SIZE: 25.63 GB per batch at 12.5M x 1024, "
+                                          "profiles/r05_config4_sibling_pmc.txt)")
         roof["hbm_GBs_streamed"] = bytes_step * passes * args.steps / (cos_ms / 1e3) / 1e9
         if args.cosine in ("screen", "screen-copy", "screen-stream") and roof["bound"] == "hbm" and args.batch > 8 and args.corpus == "f32":
             roof["kernel"] = ("cosine_copy_screen (bf16 MFMA over the index's bf16 screening copy, all corpus-chunk launches of a batch)" if copy_streamed
@@ -835,7 +870,8 @@ def main():
                                         if args.corpus == "f32" and args.batch > 8 else "exact",
                        "index_GB": {"rows_owned_by_library": rows_owned_b / 1e9, "rows_borrowed_from_caller": (0.0 if rows_owned_b else
                                     (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim / 1e9),
-                                    "screening_copy": screen_copy_b / 1e9, "bm25_structures": bm25_index_b / 1e9},
+                                    "screening_copy": screen_copy_b / 1e9, "bm25_structures": bm25_index_b / 1e9,
+                                    "hbm_free_after_build": hbm_free_b / 1e9, "hbm_total": hbm_total_b / 1e9},
                        "parallelism": "row-shard x%d + all-gather of per-shard lists" % world +
                                       ("; exchange + fusion of batch i overlap the lists of batch i+1 (two streams)" if pipe is not None else "") +
                                       ("; %d batches' lists in flight per rank, each through its own view of the shard" % len(pipe.lanes)

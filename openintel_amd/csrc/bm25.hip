@@ -292,6 +292,11 @@ int oi_bm25_finalize(oi_index *idx, uint64_t global_n, uint64_t global_tokens, c
     }
     std::vector<float> idf(idx->vocab);
     const double N = (double)global_n;
+    // Every idf must be >= 0: the stream kernel's first threshold (max_t idf_t x floor_t, the impact floors below) is a valid
+    // lower bound of the depth-th best score only then.  df_t <= N makes it so; a caller's global df vector that says otherwise
+    // is refused here rather than silently dropping docs.
+    for (uint32_t t = 0; t < idx->vocab; ++t)
+        OI_REQUIRE((uint64_t)df[t] <= global_n, "bm25: df[%u] = %u exceeds global_n_docs = %llu", t, df[t], (unsigned long long)global_n);
     for (uint32_t t = 0; t < idx->vocab; ++t) {
         const double d = (double)df[t];
         idf[t] = (float)std::log(1.0 + (N - d + 0.5) / (d + 0.5));

@@ -304,15 +304,22 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         const uint32_t thr = (uint32_t)((prefix << shift) >> 32); // every kept key is >= prefix << shift
         t_tau = thr > t_tau ? thr : t_tau;
     };
+    // stage[] (and accdoc[] / acc[] below) are exchanges between the lanes of one wave through LDS, like head[]: a lane reads
+    // what OTHER lanes wrote.  The compiler barriers keep every such read behind the writes it depends on and in front of the
+    // next round's writes (with plain accesses only, that rested on hipcc never forwarding a lane's own earlier store
+    // to its load here -- the transformation that caused round 4's fault at head[]; cosine_prefilter.hip's PF_FLUSH does the same).
     auto flush64 = [&]() __attribute__((always_inline)) { // 64 staged keys leave for the segment
         if (out_n + 64u > seg_cap) prune();
+        asm volatile("" ::: "memory");
         t_seg[out_n + lane] = stage[lane];
         out_n += 64u;
         if (TIMING) ++t_stores;
         const uint32_t rem = st_n - 64u; // < 64
         uint64_t k0 = 0;
         if (lane < rem) k0 = stage[64u + lane];
+        asm volatile("" ::: "memory");
         if (lane < rem) stage[lane] = k0;
+        asm volatile("" ::: "memory");
         st_n = rem;
     };
     auto emit1 = [&](bool k, uint32_t score_bits, uint32_t doc) __attribute__((always_inline)) { // all lanes call; score > 0: its key is bits | sign
@@ -333,7 +340,9 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     auto end_task = [&]() __attribute__((always_inline)) {
         if (st_n) {
             if (out_n + st_n > seg_cap) prune();
+            asm volatile("" ::: "memory");
             if (lane < st_n) t_seg[out_n + lane] = stage[lane];
+            asm volatile("" ::: "memory");
             out_n += st_n;
             st_n = 0;
         }
@@ -344,6 +353,7 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
     // ranks [lo, lo + BS_CAP) of the window's multi docs: emit and clear their accumulators
     auto emit_multi = [&](uint32_t lo) __attribute__((always_inline)) {
         const uint32_t cnt = t_M - lo < BS_CAP ? t_M - lo : BS_CAP;
+        asm volatile("" ::: "memory"); // (acc[] / accdoc[] were written by whichever lane held the posting: add_multi)
         for (uint32_t b = 0; b < cnt; b += 64) {
             const uint32_t r = b + lane;
             const bool ok = r < cnt;
@@ -490,8 +500,12 @@ __global__ __launch_bounds__(BS_WPB * 64) void bm25_stream_kernel(const BsArgs a
         // VOLATILE: lanes talk to each other through these words.  With plain accesses hipcc forwards a lane's own
         // "head[lane] = 0" to its read below (legal for unsynchronised threads) and the marks of the other lanes are lost:
         // chunks land in the wrong run, positions run past the end of a posting list -- a memory fault (round 4, found in the ISA).
+        // Round 5: and a wave barrier on either side of the scatter, so that a later hipcc cannot move the accesses across it
+        // either (the exchange is between lanes of ONE wave: LDS operations of a wave execute in program order).
         head[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
         if (n) head[excl] = lane + 1u;
+        __builtin_amdgcn_wave_barrier();
         uint32_t h = head[lane];
         h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x111, 0xf, 0xf, false));
         h = max(h, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x112, 0xf, 0xf, false));

@@ -27,7 +27,10 @@
 #include "oi_internal.h"
 
 #ifndef OI_BF16_SIB_DEFAULT
-#define OI_BF16_SIB_DEFAULT 0
+#define OI_BF16_SIB_DEFAULT 2 // (round 5: 256-query batches at d = 1024 take their two passes as sibling workgroups on one XCD)
+#endif
+#ifndef CB_QUAD_NBUF
+#define CB_QUAD_NBUF 6 // ring slots per wave of the quad kernel (4 = one tile's worth, rounds 2-4; 6 is what the LDS holds)
 #endif
 
 typedef float cb_f32x16 __attribute__((ext_vector_type(16)));
@@ -52,21 +55,35 @@ __device__ __forceinline__ cb_u32x4 cb_make_srd(const uint16_t *base, uint64_t b
 }
 // One 1-KiB LDS-DMA piece (8 rows x 128 B).  Lanes past the descriptor's end read as zero: the ragged
 // last tile needs no clamping.  hipcc does not see these loads: they are ordered by cb_wait<N>().
+// STREAM = true: the once-read policy of oi_device.h (non-temporal).  STREAM = false: the default cache policy -- the quad
+// kernel's sibling workgroups (below) read every tile TWICE on one XCD and want the first read to stay in its L2.
+template <bool STREAM = true>
 __device__ __forceinline__ void cb_issue_piece(const cb_u32x4 &srd, uint32_t voff, uint32_t soff, uint32_t lds_dst,
                                                bool skip) {
     if (skip) return;
     uint32_t keep;
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
     const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %4\n\t"
-        "s_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %2, %3 offen " OI_DMA_NT "lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(srd), "s"(so), "s"(d)
-        : "memory");
+    if constexpr (STREAM)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %1, %2, %3 offen " OI_DMA_NT "lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(srd), "s"(so), "s"(d)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(srd), "s"(so), "s"(d)
+            : "memory");
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void cb_static_for(F &&f) {
@@ -402,13 +419,16 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_pair(
 // the three partial tiles it does not own in LDS, and after one barrier adds the other waves' partials of ITS tile to its
 // own (K quarters in order 0..3) and filters.  A second barrier lets the buffer be reused (the four epilogues are the
 // same size, so nobody waits long at it; the DMA ring keeps the loads of the next tile in flight across both).
-template <int D, int DBG = 0> // DBG (ablation builds): 1 = no reduction / epilogue / barriers (streaming + MFMA only), 2 = no epilogue work
+template <int D, int DBG = 0, int SIB = 0> // DBG (ablation builds): 1 = no reduction / epilogue / barriers (streaming + MFMA only), 2 = no epilogue work
 __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
     const uint16_t *__restrict__ queries, // bf16 [128 (x 2 with siblings)][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
-    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow, uint32_t sib) {
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
     constexpr int NQT = 4;
+    constexpr uint32_t sib = SIB;
+    constexpr bool STREAM = SIB == 0; // siblings: default cache policy (HBM then sees every tile ONCE: 25.63 GB per 256-query batch
+                                      // at 12.5M x 1024 by the FETCH_SIZE counter, against 42 GB with non-temporal loads and 51.2 GB without siblings)
     // SIBLINGS (round 5).  256 queries at d = 1024 are two passes of this kernel over the corpus; one CU cannot hold more than
     // 128 queries (the 256 x 1024 bf16 block IS the register file of a CU).  With sib != 0 the two passes run as ONE launch:
     // the grid is cut into pairs of workgroups that walk the SAME tile sequence, one with queries 0..127 and one with 128..255
@@ -429,18 +449,25 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     } else if (sib && n_queries > 128u) n_queries = 128u;
     constexpr int KQ = D / 4;                 // K of one wave
     constexpr int NKC = KQ / CB_SLOT_K;       // ring slots per tile and wave
-    constexpr int NBUF = NKC;
+    // Round 5: the ring is SIX slots deep and indexed at run time (as cosine_screen_copy.hip's), where rounds 2-4 had the four
+    // slots of one tile: 3 slots = 12 KB in flight per wave against 16 KB consumed per tile, and no refill is issued while a
+    // wave parks / waits at the two barriers of a tile -- the kernel was bound by HBM LATENCY, not bandwidth: 12 KB x 1024 waves
+    // per 2.2 us of loaded latency = the 5.6 TB/s it streamed at (tools/r05_sib_ab.py: 7080 cycles per tile, 2048 of them MFMA).
+    // Five slots ahead (20 KB) is what the LDS has room for once the park buffer holds only the 12 partial tiles that are
+    // actually parked (48 KB; it was laid out for 16).
+    constexpr int NBUF = CB_QUAD_NBUF;
     constexpr int P = NBUF - 1;
     constexpr int KSTEPS = KQ / 16;
     constexpr int RED = 16 * 64;              // floats of one parked partial query tile (32 rows x 32 queries)
-    static_assert(KQ % CB_SLOT_K == 0 && P >= 1, "unsupported D");
+    constexpr uint32_t RING = NBUF * CB_SLOT_BYTES;
+    static_assert(KQ % CB_SLOT_K == 0 && P >= NKC && P <= 2 * NKC, "unsupported ring depth");
     static_assert(NQT * KSTEPS * 4 <= 400, "the query block must fit the register file");
     static_assert(NKC * 4 == 16, "the epilogue is spread over 16 MFMA groups");
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char *ring = smem;                                                      // [4][NBUF][4 KiB]
-    float *red = reinterpret_cast<float *>(smem + 4 * NBUF * CB_SLOT_BYTES);         // [4 writers][4 query tiles][RED]
-    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 16 * RED);               // [128]
+    float *red = reinterpret_cast<float *>(smem + 4 * RING);                         // [4 writers][3 foreign query tiles][RED]
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 12 * RED);               // [128]
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // K quarter, and the query tile this wave finishes
@@ -473,26 +500,30 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
         const uint32_t prow = 8 * m + (lane >> 3);
         voff[m] = prow * (uint32_t)(D * 2) + w * (uint32_t)(KQ * 2) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
     }
-    const uint32_t ring_w = cb_lds_addr(ring) + w * (NBUF * CB_SLOT_BYTES);
-    const unsigned char *ring_rd = ring + w * (NBUF * CB_SLOT_BYTES);
+    const uint32_t ring_w = cb_lds_addr(ring) + w * RING;
+    const unsigned char *ring_rd = ring + w * RING;
     uint32_t frag_off[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
 
     auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)CB_TILE_ROWS; };
-    auto tile_srd = [&](uint64_t ti) {
+    auto tile_srd = [&](uint64_t ti) { // past this workgroup's last tile: an EMPTY descriptor (loads return zeros)
         const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
-        return cb_make_srd(rows + r0 * D, (row_end - r0) * (uint64_t)(D * 2));
+        return cb_make_srd(rows + r0 * D, ti < my_nt ? (row_end - r0) * (uint64_t)(D * 2) : 0ull);
     };
-    cb_u32x4 cur = tile_srd(0), nxt = tile_srd(1);
+    cb_u32x4 s0 = tile_srd(0), s1 = tile_srd(1), s2 = tile_srd(2);
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only: retire every load hipcc knows about, here
     if (my_nt) {
-#pragma unroll
-        for (int kc = 0; kc < P; ++kc)
+        cb_static_for<0, P>([&](auto j_) { // prologue: logical slots 0..P-1 (tile j / NKC, slot j % NKC) into ring slots 0..P-1
+            constexpr int j = decltype(j_)::value;
+            constexpr int tj = j / NKC, kj = j % NKC;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                cb_issue_piece(cur, voff[m], kc * 128, ring_w + (kc % NBUF) * CB_SLOT_BYTES + m * 1024, false);
+                cb_issue_piece<STREAM>(tj == 0 ? s0 : s1, voff[m], kj * 128, ring_w + j * CB_SLOT_BYTES + m * 1024, false);
+        });
     }
+    // ring offsets (bytes, wave-uniform): the slot being consumed, and the one vacated before it = the refill target
+    uint32_t rd_off = 0, wr_off = (NBUF - 1) * CB_SLOT_BYTES;
 
     // The epilogue of tile i-1 (sum of the four K quarters of this wave's query tile, filter, append) is spread over the
     // 16 MFMA groups of tile i: it runs in the shadow of the matrix pipe and of the DMA instead of holding both up
@@ -511,10 +542,14 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     uint32_t rows_prev = 0; // rows of the previous tile inside the chunk (32 but for the last)
     typedef float cb_f32x4 __attribute__((ext_vector_type(4)));
     cb_f32x4 *red4 = reinterpret_cast<cb_f32x4 *>(red); // [writer][query tile][rb][lane]
-    cb_f32x4 *park_base = red4 + (w * 16) * 64 + lane;          // + (t * 4 + rb) * 64
-    const cb_f32x4 *rd_base[3];                                 // writer (w + 1 + j) % 4, query tile w: + rb * 64
+    // [writer x][the three query tiles x does not own, in tile order][rb][lane]: tile t sits at index t (t < x) or t - 1 (t > x)
+    cb_f32x4 *park_base = red4 + (w * 12) * 64 + lane;          // + ((t < w ? t : t - 1) * 4 + rb) * 64
+    const cb_f32x4 *rd_base[3];                                 // writer x = (w + 1 + j) % 4, query tile w: + rb * 64
 #pragma unroll
-    for (int j = 0; j < 3; ++j) rd_base[j] = red4 + ((((w + 1 + j) & 3u) * 4 + w) * 4) * 64 + lane;
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t x = (w + 1 + j) & 3u;
+        rd_base[j] = red4 + ((x * 3 + (w < x ? w : w - 1u)) * 4) * 64 + lane;
+    }
     cb_f32x16 own; // this wave's partial of its own query tile, previous tile
     auto finish_block = [&](auto rb_, const cb_f32x4 (&p)[3]) {
         constexpr int rb = decltype(rb_)::value;
@@ -543,43 +578,55 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
         }
     };
 
+    // The fragments of a WHOLE slot (4 x 16 B per lane) are read one slot ahead of the matrix pipe (round 5): a group is four
+    // MFMAs = 128 cycles, and a fragment read issued one group ahead (rounds 2-4) came back later than that whenever the LDS
+    // pipe was busy with the four waves' DMA writes and partial-tile traffic -- the wave then sat at lgkmcnt(0) in front of
+    // every group (stream + MFMA alone: 4500 cycles per tile for 2048 of MFMA, with HBM no longer the limit once siblings
+    // share the tiles).  The ring is continuous across tiles, so the next tile's first slot is read during this tile's last.
+    cb_bf16x8 fr_cur[4], fr_nxt[4];
+    if (my_nt) {
+        cb_wait<4 * (P - 1)>();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fr_cur[g] = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + rd_off + frag_off[g]);
+    }
     for (uint64_t ti = 0; ti < my_nt; ++ti) {
-        const bool has_next_tile = ti + 1 < my_nt;
         cb_f32x16 acc[NQT];
         {
-            cb_wait<4 * (P - 1)>();
-            cb_bf16x8 a_cur = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + frag_off[0]);
+            // Slot kc of this tile sits at rd_off, its fragments in fr_cur.  Per slot: the counted wait that retires slot
+            // kc + 1 (P - 2 younger slots stay in flight), its four fragment reads, then per MFMA group (kc, g) four MFMAs and
+            // DMA piece g of logical slot kc + P (one or two tiles ahead; an empty descriptor past the last tile: the refill
+            // ALWAYS issues, so every counted wait is the same constant) into the slot vacated last (wr_off).
             cb_f32x4 pp[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             cb_static_for<0, NKC * 4>([&](auto gi_) {
                 constexpr int gi = decltype(gi_)::value;
                 constexpr int kc = gi / 4, g = gi % 4;
                 constexpr int sn = kc + P;
+                constexpr int tn = sn / NKC, kn = sn % NKC; // tn is 1 or 2 (P >= NKC)
                 constexpr int rb = gi / 4, ej = gi % 4; // the previous tile's epilogue: register block rb, step ej
-                cb_bf16x8 a_nxt = a_cur;
+                if constexpr (g == 0) {
+                    const uint32_t nx_off = rd_off + CB_SLOT_BYTES == RING ? 0u : rd_off + CB_SLOT_BYTES;
+                    cb_wait<4 * (P - 2)>();
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) fr_nxt[h] = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + nx_off + frag_off[h]);
+                }
                 if constexpr ((DBG == 0 || DBG == 3) && ej < 3) { // a foreign partial of block rb: read before the MFMAs
                     if (have_prev) pp[ej] = rd_base[ej][rb * 64];
                 }
-                if constexpr (g < 3)
-                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + (kc % NBUF) * CB_SLOT_BYTES + frag_off[g + 1]);
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
-                    if constexpr (gi == 0) cb_mfma_agpr_first(acc[t], a_cur, qreg[t][gi]);
-                    else cb_mfma_agpr(acc[t], a_cur, qreg[t][gi]);
+                    if constexpr (gi == 0) cb_mfma_agpr_first(acc[t], fr_cur[g], qreg[t][gi]);
+                    else cb_mfma_agpr(acc[t], fr_cur[g], qreg[t][gi]);
                 }
-                if constexpr (sn < NKC)
-                    cb_issue_piece(cur, voff[g], sn * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024, false);
-                else
-                    cb_issue_piece(nxt, voff[g], (sn - NKC) * 128, ring_w + (sn % NBUF) * CB_SLOT_BYTES + g * 1024,
-                                   !has_next_tile);
+                cb_issue_piece<STREAM>(tn == 1 ? s1 : s2, voff[g], kn * 128, ring_w + wr_off + g * 1024, false);
                 if constexpr ((DBG == 0 || DBG == 3) && ej == 3) { // ... block rb summed, filtered, appended
                     if (have_prev) finish_block(std::integral_constant<int, rb>{}, pp);
                 }
-                if constexpr (g == 3 && kc + 1 < NKC) {
-                    if (kc + P < NKC || has_next_tile) cb_wait<4 * (P - 1)>();
-                    else cb_wait<4 * (NKC - 2 - kc)>();
-                    a_nxt = *reinterpret_cast<const cb_bf16x8 *>(ring_rd + ((kc + 1) % NBUF) * CB_SLOT_BYTES + frag_off[0]);
+                if constexpr (g == 3) {
+                    wr_off = rd_off;
+                    rd_off = rd_off + CB_SLOT_BYTES == RING ? 0u : rd_off + CB_SLOT_BYTES;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) fr_cur[h] = fr_nxt[h];
                 }
-                a_cur = a_nxt;
             });
             cb_mfma_drain(); // the accumulators are read (parked / copied) next
         }
@@ -588,8 +635,9 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
 #pragma unroll
             for (int t = 0; t < NQT; ++t) x += acc[t][0] + acc[t][7] + acc[t][15];
             if (x == 12345.678f) *overflow = 2u;
-            cur = nxt;
-            nxt = tile_srd(ti + 2);
+            s0 = s1;
+            s1 = s2;
+            s2 = tile_srd(ti + 3);
             continue;
         }
         __syncthreads(); // everyone has consumed the parked partials of the previous tile
@@ -600,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     cb_f32x4 v = {acc[t][4 * rb], acc[t][4 * rb + 1], acc[t][4 * rb + 2], acc[t][4 * rb + 3]};
-                    park_base[(t * 4 + rb) * 64] = v;
+                    park_base[(((uint32_t)t < w ? t : t - 1) * 4 + rb) * 64] = v;
                 }
             } else {
                 own = acc[t];
@@ -610,9 +658,11 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
         rows_prev = row_end - row0_prev < 32 ? (uint32_t)(row_end - row0_prev) : 32u;
         have_prev = true;
         __syncthreads(); // parked: readable during the next tile's MFMA groups
-        cur = nxt;
-        nxt = tile_srd(ti + 2);
+        s0 = s1;
+        s1 = s2;
+        s2 = tile_srd(ti + 3);
     }
+    cb_wait<0>(); // the zero-filling refills issued past the last tile have landed before the LDS goes back
     if ((DBG == 0 || DBG == 3) && have_prev) // the last tile's epilogue has no MFMA loop to hide in
         cb_static_for<0, 4>([&](auto rb_) {
             constexpr int rb = decltype(rb_)::value;
@@ -702,31 +752,34 @@ static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
     return OI_OK;
 }
 
+template <int D, int DBG, int SIB>
+static int launch_bf16_quad_k(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                              uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    const uint32_t grid = SIB ? 2u * p.n_segs : p.n_segs; // (siblings: p.n_segs pairs, one pool segment per pair and query half)
+    constexpr size_t smem = 4 * CB_QUAD_NBUF * CB_SLOT_BYTES + 12 * (16 * 64) * 4 + 128 * 4;
+    static_assert(smem <= 160 * 1024, "LDS");
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_quad<D, DBG, SIB>), (size_t)(smem)));
+    hipLaunchKernelGGL((cosine_bf16_quad<D, DBG, SIB>), dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
+                       doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap,
+                       p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 template <int D>
 static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
                             uint32_t nq, uint32_t doc_id_base, const PoolView &p, uint32_t sib = 0) {
-    const uint32_t grid = sib ? 2u * p.n_segs : p.n_segs; // (siblings: p.n_segs pairs, one pool segment per pair and query half)
-    constexpr int NKC = D / 4 / CB_SLOT_K;
-    constexpr size_t smem = 4 * NKC * CB_SLOT_BYTES + 16 * (16 * 64) * 4 + 128 * 4;
-    static_assert(smem <= 160 * 1024, "LDS");
 #ifdef OI_ABLATION
     static const char *dbg_s = oi_ablation_env("OI_QUAD_DBG");
     const int dbg = dbg_s ? atoi(dbg_s) : 0;
-    if (dbg >= 1 && dbg <= 3) {
-        auto kern = dbg == 1 ? cosine_bf16_quad<D, 1> : dbg == 2 ? cosine_bf16_quad<D, 2> : cosine_bf16_quad<D, 3>;
-        OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(kern), (size_t)(smem)));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq, doc_id_base, p.keys,
-                           p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap, p.overflow, sib);
-        OI_HIP_CHECK(hipGetLastError());
-        return OI_OK;
-    }
+    if (dbg == 1) return sib ? launch_bf16_quad_k<D, 1, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
+                             : launch_bf16_quad_k<D, 1, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+    if (dbg == 3) return sib ? launch_bf16_quad_k<D, 3, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
+                             : launch_bf16_quad_k<D, 3, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+    if (sib == 1) return launch_bf16_quad_k<D, 0, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 #endif
-    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_quad<D>), (size_t)(smem)));
-    hipLaunchKernelGGL((cosine_bf16_quad<D>), dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
-                       doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap,
-                       p.overflow, sib);
-    OI_HIP_CHECK(hipGetLastError());
-    return OI_OK;
+    if (sib) return launch_bf16_quad_k<D, 0, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
+    return launch_bf16_quad_k<D, 0, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 }
 
 // All queries of a batch over rows [row_begin, row_end) of a bf16 corpus.  d_queries: f32 [n_queries][dim].

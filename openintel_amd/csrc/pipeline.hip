@@ -18,6 +18,7 @@
 // Collectives are issued from the submitting host thread in submission order on ONE stream: every rank must submit the
 // same batches in the same order (as with oi_search_sharded).
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "oi_internal.h"
@@ -56,6 +57,9 @@ struct oi_pipeline {
     std::vector<Slot> slots;
     uint64_t n_submitted = 0;
     std::mutex mu;
+    // OI_PIPELINE_TRACE=1: host time of submit by phase (us, summed), printed to stderr at destroy -- a host-bound pipeline shows here
+    bool trace = false;
+    double t_phase[5] = {0, 0, 0, 0, 0}; // wait/stage, lists, exchange, fuse, rest
 };
 
 namespace {
@@ -168,6 +172,13 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
         PL_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
         p->lane_st.push_back(st);
         PL_OI(oi_set_stream(c, st));
+        // With two or more lanes the BM25 leg of a batch runs IN its lane's stream, not on a side stream of its own: the other
+        // lane's corpus stream is what it overlaps with, and every further stream is one more contender for the few hardware
+        // queues that really dispatch at the same time.  OI_PIPELINE_LANE_OVERLAP=1 (A/B): side streams as in oi_search.
+        {
+            const char *lo = getenv("OI_PIPELINE_LANE_OVERLAP");
+            if (lanes >= 2 && !(lo && atoi(lo) != 0)) PL_OI(oi_set_overlap(c, 0));
+        }
         oi_index *v = nullptr;
         PL_OI(oi_index_view(idx, c, &v));
         p->lane_idx.push_back(v);
@@ -189,6 +200,7 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
         PL_HIP(hipEventCreateWithFlags(&s.fused, hipEventDisableTiming));
     }
     PL_HIP(hipDeviceSynchronize());
+    { const char *tr = getenv("OI_PIPELINE_TRACE"); p->trace = tr && atoi(tr) != 0; }
 #undef PL_HIP
 #undef PL_OI
     *out = p;
@@ -197,6 +209,10 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
 
 extern "C" void oi_pipeline_destroy(oi_pipeline *p) {
     if (!p) return;
+    if (p->trace && p->n_submitted)
+        fprintf(stderr, "[oi_pipeline] %llu submits; host us per submit: wait/stage %.1f, lists %.1f, exchange %.1f, fuse %.1f\n",
+                (unsigned long long)p->n_submitted, p->t_phase[0] / p->n_submitted, p->t_phase[1] / p->n_submitted,
+                p->t_phase[2] / p->n_submitted, p->t_phase[3] / p->n_submitted);
     {
         std::lock_guard<std::mutex> g(p->mu);
         for (Slot &s : p->slots) (void)retire(p, s);
@@ -211,6 +227,9 @@ extern "C" int oi_pipeline_submit(oi_pipeline *p, const float *qv, const uint32_
     OI_REQUIRE(qv && qo && scores_out && docs_out && counts_out, "pipeline submit: null buffer");
     OI_REQUIRE(B >= 1 && B <= p->B_max, "pipeline submit: n_queries=%u outside [1,%u] (oi_pipeline_create's max_queries)", B, p->B_max);
     std::lock_guard<std::mutex> g(p->mu);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto t0 = now();
     oi_ctx *cctx = p->src->ctx; // the caller's context: its stream is where device inputs were produced
     OI_HIP_CHECK(hipSetDevice(cctx->device));
     const uint64_t n = p->n_submitted;
@@ -249,12 +268,15 @@ extern "C" int oi_pipeline_submit(oi_pipeline *p, const float *qv, const uint32_
         d_qo = reinterpret_cast<const uint32_t *>(s.q_dev + off_o);
     }
     // the shard's two lists, packed, on the lane
+    const auto t1 = now();
     OI_CHECK(oi_search_lists_packed(p->lane_idx[lane], d_qv, d_qt, d_qo, B, p->depth, OI_DEVICE, s.packed));
+    const auto t2 = now();
     OI_HIP_CHECK(hipEventRecord(s.lists_done, lst));
     // exchange + fusion on the fusing stream
     OI_HIP_CHECK(hipStreamWaitEvent(p->fuse_st, s.lists_done, 0));
     const size_t W = (size_t)OI_PACKED_WORDS(B, p->depth), K = (size_t)B * p->k;
     if (p->comm) OI_CHECK(oi_rccl_all_gather_u32(p->comm->nccl, s.packed, s.flat, W, p->fuse_st)); // the ONE exchange of the batch
+    const auto t3 = now();
     if (location == OI_DEVICE) {
         OI_CHECK(oi_fuse_packed(p->fuse_ctx, s.flat, p->world, B, p->depth, p->k, OI_DEVICE, scores_out, docs_out, counts_out));
     } else {
@@ -265,6 +287,10 @@ extern "C" int oi_pipeline_submit(oi_pipeline *p, const float *qv, const uint32_
         OI_HIP_CHECK(hipMemcpyAsync(s.out_pin, o_s, (2 * K + B) * 4, hipMemcpyDeviceToHost, p->fuse_st));
     }
     OI_HIP_CHECK(hipEventRecord(s.fused, p->fuse_st));
+    if (p->trace) {
+        const auto t4 = now();
+        p->t_phase[0] += us(t0, t1); p->t_phase[1] += us(t1, t2); p->t_phase[2] += us(t2, t3); p->t_phase[3] += us(t3, t4);
+    }
     s.ticket = n + 1;
     s.B = B;
     s.location = location;

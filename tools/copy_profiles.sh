@@ -25,5 +25,9 @@ for k in bench config4 bm25 headline lexicon; do
 done
 cp $S/pmc/pmc_summary.json $D/${N}_pmc_summary.json
 cp $S/pmc_exact/pmc_summary.json $D/${N}_exact_pmc_summary.json
-python3 $R/tools/make_pmc_traffic.py $D/${N}_pmc_summary.json $D/${N}_exact_pmc_summary.json $N > /dev/null
+cp $S/pmc_stream/pmc_summary.json $D/${N}_stream_pmc_summary.json
+cp $S/pipeline_probe_shard.json $D/${N}_pipeline_probe_shard_1_25M.json
+cp $S/pipeline_probe_10M.json $D/${N}_pipeline_probe_10M.json
+cp $S/native_world1_shard.json $D/${N}_native_world1_shard_1_25M.json
+python3 $R/tools/make_pmc_traffic.py $D/${N}_pmc_summary.json $D/${N}_exact_pmc_summary.json $N $D/${N}_stream_pmc_summary.json > /dev/null
 ls $D | grep "^${N}_" | wc -l

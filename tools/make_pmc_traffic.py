@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json (what bench.py's roofline.traffic reads) from two tools/pmc_profile.sh summaries:
-    python tools/make_pmc_traffic.py <default-mode pmc_summary.json> <--cosine exact pmc_summary.json> <tag>
-The default-mode run supplies the screen kernel and the BM25 kernel, the exact-mode run the f32 MFMA kernel (in a
-default-mode run that kernel also has one gated launch per batch that exits at once and would dilute the averages)."""
+"""profiles/pmc_traffic.json (what bench.py's roofline.traffic reads) from three tools/pmc_profile.sh summaries:
+    python tools/make_pmc_traffic.py <default-mode pmc_summary.json> <--cosine exact pmc_summary.json> <tag> [<--cosine screen-stream pmc_summary.json>]
+The default-mode run supplies the screen kernel over the screening copy (round 5's default) and the BM25 kernel, the exact-mode
+run the f32 MFMA kernel (in a default-mode run that kernel also has gated launches per batch that exit at once and would dilute
+the averages), the screen-stream run the f32-stream screen (rounds 1-4's default)."""
 import json
 import os
 import sys
@@ -11,18 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(sys.argv[1]))
 x = json.load(open(sys.argv[2]))
 tag = sys.argv[3]
+st = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 ALG = 10_000_000 * 768 * 4
-sc = d["cosine_screen"]
+ALG_COPY = 10_000_000 * 768 * 2
+sc = d["cosine_copy_screen"]
 out = {
     "source": "profiles/%s_pmc_summary.json (tools/pmc_profile.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes over "
               "bench.py --steps 3 --warmup 1 --latency-batches 1 --latency-warmup 0, default scorer; collected on the round's code: the tag says which)" % tag,
     "correction": "HBM read bytes = FETCH_SIZE*1024*2 (gfx950 tallies 128-B requests at 64 B on wide coalesced streams, "
                   "MI355X_MICROARCH.md section HBM); write bytes = WRITE_SIZE*1024",
-    "kernel": "cosine_screen_filter<768,2>",
+    "kernel": "cosine_copy_screen<768,2,8>",
     "cosine_launches": sc["launches"],
     "cosine_hbm_bytes_per_launch": (sc["hbm_read_bytes"] + sc.get("hbm_write_bytes", 0.0)) / sc["launches"],
     "cosine_hbm_read_bytes_per_step": sc["hbm_read_bytes"] / sc["launches"] * 4,
-    "cosine_algorithmic_bytes_per_step": ALG,
+    "cosine_algorithmic_bytes_per_step": ALG_COPY,
     "cosine_eff_clock_GHz": sc.get("eff_clock_GHz"),
     "cosine_lds_bank_conflict_cycles_frac": sc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, sc.get("SQ_LDS_IDX_ACTIVE", 1.0)),
 }
@@ -57,6 +60,18 @@ out["exact_kernel"] = {
     "cosine_eff_clock_GHz": ex.get("eff_clock_GHz"),
     "cosine_lds_bank_conflict_cycles_frac": ex.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, ex.get("SQ_LDS_IDX_ACTIVE", 1.0)),
 }
+if st and "cosine_screen" in st:
+    fs = st["cosine_screen"]
+    out["f32_stream_kernel"] = {
+        "kernel": "cosine_screen_filter<768,2>",
+        "cosine_launches": fs["launches"],
+        "cosine_hbm_bytes_per_launch": (fs["hbm_read_bytes"] + fs.get("hbm_write_bytes", 0.0)) / fs["launches"],
+        "cosine_hbm_read_bytes_per_step": fs["hbm_read_bytes"] / fs["launches"] * 4,
+        "cosine_algorithmic_bytes_per_step": ALG,
+        "cosine_eff_clock_GHz": fs.get("eff_clock_GHz"),
+        "cosine_lds_bank_conflict_cycles_frac": fs.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, fs.get("SQ_LDS_IDX_ACTIVE", 1.0)),
+    }
+    out["f32_stream_kernel_source"] = "profiles/%s_stream_pmc_summary.json (the same passes over bench.py --cosine screen-stream)" % tag
 out["exact_kernel_source"] = ("profiles/%s_exact_pmc_summary.json (the same passes over bench.py --cosine exact --steps 3 --warmup 1; "
                               "the kernel with non-temporal loads)" % tag)
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)

@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
-KEEP = ("cosine_screen", "cosine_ksplit", "cosine", "bm25_stream", "bm25_plan", "bm25_wave", "bm25_block", "bm25_scan", "select_flat", "select_topk", "pf_rescore", "rrf_kernel",
+KEEP = ("cosine_copy_screen", "cosine_screen", "cosine_ksplit", "cosine_bf16_quad", "cosine", "bm25_stream", "bm25_plan", "bm25_wave", "bm25_block", "bm25_scan", "select_flat", "select_topk", "pf_rescore", "rrf_kernel",
         "lexicon_kernel", "lists_to_pool", "headline_scan", "social_summary")   # first match wins
 agg = defaultdict(lambda: defaultdict(float))
 for f in sorted(glob.glob(out + "/pass*/*/*counter_collection.csv")):

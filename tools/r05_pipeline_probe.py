@@ -17,8 +17,21 @@ from openintel_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+flags = sys.argv[3:]
+with_comm = "comm" in flags     # an RCCL communicator of one rank: the real ncclAllGather per batch
+with_dist = "dist" in flags     # a torch.distributed process group of one rank (nccl) alive in the process, as under bench.py
+with_prof = "prof" in flags     # HIP events around the lanes' cosine launches, as in bench.py's timed region
 B, DIM, DEPTH, K = 64, 768, 1000, 100
 dev = torch.device("cuda:0")
+if with_dist:
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 ctx = oi.HipContext(0)
 ctx.use_torch_current_stream()
 rows = synth.embeddings_torch(n, DIM, dev)
@@ -27,7 +40,12 @@ idx = oi.HybridIndex(ctx, n, DIM, synth.VOCAB)
 idx.set_embeddings(rows, normalize=False)
 idx.set_forward(terms, offs)
 idx.set_max_query_terms(4)
-idx.finalize()
+comm = None
+if with_comm:
+    comm = oi.NativeComm(ctx, oi.NativeComm.unique_id(), 0, 1)
+    idx.finalize_sharded(comm)
+else:
+    idx.finalize()
 del terms, offs
 NB = 4
 batches = [synth.query_batch_torch(B, DIM, dev, seed=synth.SEED_QUERY + 7919 * i) for i in range(NB)]
@@ -45,23 +63,27 @@ for i in range(steps):
 torch.cuda.synchronize()
 res["serial_oi_search_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
 for lanes in (1, 2, 3):
-    pipe = oi.NativePipeline(idx, lanes=lanes, max_queries=B, max_query_terms=4, depth=DEPTH, k=K)
+    pipe = oi.NativePipeline(idx, lanes=lanes, max_queries=B, max_query_terms=4, depth=DEPTH, k=K, comm=comm)
     outs = [mk() for _ in range(8)]
     for i in range(8):
         pipe.submit(*batches[i % NB], out=outs[i])
     pipe.drain()
     ok = all(torch.equal(outs[i].docs, ref[i % NB].docs) and torch.equal(outs[i].scores, ref[i % NB].scores) for i in range(8))
-    best = None
+    best, host = None, None
+    if with_prof:
+        pipe.profile_reset(2)
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             pipe.submit(*batches[i % NB], out=outs[i % 8])
+        th = (time.perf_counter() - t0) / steps * 1e3
         pipe.drain()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        best = ms if best is None else min(best, ms)
+        if best is None or ms < best:
+            best, host = ms, th
     ok = ok and all(torch.equal(outs[i].docs, ref[((steps - 8 + i) if False else i) % NB].docs) for i in range(0))
-    res["pipeline_lanes_%d" % lanes] = {"ms_per_batch": round(best, 4), "bit_identical": bool(ok),
+    res["pipeline_lanes_%d" % lanes] = {"ms_per_batch": round(best, 4), "host_ms_per_submit": round(host, 4), "bit_identical": bool(ok),
                                         "workspace_GB": round(pipe.workspace_bytes()[0] / 1e9, 3)}
     pipe.close()
 print(json.dumps(res))

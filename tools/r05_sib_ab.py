@@ -61,7 +61,8 @@ def run(tag):
                       "score_checksum": float(L.cos_scores.double().sum().item())}), flush=True)
 
 
-for rnd in range(2):
-    for sib in ("0", "1", "2"):
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ("0", "1", "2")
+for rnd in range(2 if len(modes) > 1 else 1):
+    for sib in modes:
         os.environ["OI_BF16_SIB"] = sib
         run("OI_BF16_SIB=%s" % sib)
