@@ -301,6 +301,69 @@ impl HipIndex {
     }
 }
 
+/// Several batches in flight through lanes the LIBRARY owns (oi_pipeline_*): the throughput form of `search` /
+/// `search_sharded` for a host without streams of its own.  Results are bit-identical to the one-call forms.
+pub struct HipPipeline {
+    p: *mut ffi::OiPipeline,
+    dim: usize,
+    k: usize,
+    _idx: Arc<HipIndex>,
+}
+unsafe impl Send for HipPipeline {}
+impl Drop for HipPipeline {
+    fn drop(&mut self) {
+        unsafe { ffi::oi_pipeline_destroy(self.p) } // drains first
+    }
+}
+/// The owned output buffers of one submitted batch; filled when `HipPipeline::wait(ticket)` returns.
+pub struct PendingBatch {
+    pub ticket: u64,
+    n: usize,
+    scores: Vec<f32>,
+    docs: Vec<u32>,
+    counts: Vec<u32>,
+}
+impl HipPipeline {
+    /// `comm`: None = one shard, no exchange; Some = row-sharded, ONE ncclAllGather per batch inside the library.
+    pub fn create(idx: Arc<HipIndex>, comm: Option<&HipComm>, lanes: u32, max_queries: u32, max_query_terms: u32, depth: u32, k: u32)
+                  -> Result<Self, HipError> {
+        let mut p = std::ptr::null_mut();
+        let c = comm.map(|c| c.comm).unwrap_or(std::ptr::null_mut());
+        check(unsafe { ffi::oi_pipeline_create(idx.idx, c, lanes, max_queries, max_query_terms, depth, k, &mut p) })?;
+        Ok(Self { p, dim: idx.dim, k: k as usize, _idx: idx })
+    }
+    /// Asynchronous: the inputs are copied during the call, the returned buffers are written by `wait`.
+    pub fn submit(&self, query_vecs: &[f32], query_terms: &[Vec<u32>]) -> Result<PendingBatch, HipError> {
+        let b = query_terms.len();
+        assert_eq!(query_vecs.len(), b * self.dim);
+        let mut flat = Vec::new();
+        let mut offs = vec![0u32];
+        for t in query_terms {
+            flat.extend_from_slice(t);
+            offs.push(flat.len() as u32);
+        }
+        if flat.is_empty() {
+            flat.push(0);
+        }
+        let mut out = PendingBatch { ticket: 0, n: b, scores: vec![0f32; b * self.k], docs: vec![0u32; b * self.k], counts: vec![0u32; b] };
+        check(unsafe {
+            ffi::oi_pipeline_submit(self.p, query_vecs.as_ptr(), flat.as_ptr(), offs.as_ptr(), b as u32, ffi::OI_HOST,
+                                    out.scores.as_mut_ptr(), out.docs.as_mut_ptr(), out.counts.as_mut_ptr(), &mut out.ticket)
+        })?;
+        Ok(out) // (the Vecs' heap buffers do not move with the struct: the library's pointers stay valid until wait)
+    }
+    pub fn wait(&self, batch: PendingBatch) -> Result<Vec<Vec<RankedPost>>, HipError> {
+        check(unsafe { ffi::oi_pipeline_wait(self.p, batch.ticket, 1) })?;
+        let k = self.k;
+        Ok((0..batch.n)
+            .map(|q| (0..batch.counts[q] as usize).map(|i| RankedPost { doc_id: batch.docs[q * k + i], score: batch.scores[q * k + i] }).collect())
+            .collect())
+    }
+    pub fn drain(&self) -> Result<(), HipError> {
+        check(unsafe { ffi::oi_pipeline_drain(self.p) })
+    }
+}
+
 /// The adapter for the reference: `impl PostAnalyzer for HipLexiconAnalyzer`.
 #[cfg(feature = "reference")]
 pub mod adapter {
