@@ -26,6 +26,9 @@
 #include "oi_device.h"
 #include "oi_internal.h"
 
+#ifndef OI_TILE_CONTIG
+#define OI_TILE_CONTIG 0
+#endif
 #ifndef OI_BF16_SIB_DEFAULT
 #define OI_BF16_SIB_DEFAULT 2 // (round 5: 256-query batches at d = 1024 take their two passes as sibling workgroups on one XCD)
 #endif
@@ -678,6 +681,266 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     }
 }
 
+// ------------------------------------------------------------------ 128 queries per pass, split by QUERY (round 5)
+// The quad kernel above splits K over the four waves, so every 32 x 128 score tile exists as four partial tiles that meet
+// through LDS: 48 KB parked and read back per tile, two barriers, three adds per score -- 2.2 of its 8.3 ms per 256-query
+// batch at a 12.5M-row shard once sibling workgroups had taken HBM out of the way.  Here the four waves split
+// the QUERIES: wave w holds queries 32 w .. 32 w + 31 over the WHOLE K (32 x 1024 bf16 = 64 KB = 256 AGPRs), every tile is
+// DMA'd into LDS once (each wave loads a quarter of it) and read by all four waves.  A wave's accumulators then hold complete
+// scores: no partial tiles, no reduction, and a score is one MFMA accumulation chain in K order -- the same bits whatever the
+// query's slot in the batch.  The price is LDS read traffic: every fragment feeds ONE MFMA instead of four, 256 KB of
+// ds_read_b128 per tile and CU = 2048 LDS cycles beside 2048 matrix-pipe cycles per wave; the kernel is built to keep both busy:
+//   * the tile moves as two HALF tiles (512 k = 8 slots of 4 KiB, 32 KB) through a ring of CQ_NHB half-tile buffers; wave w
+//     issues the DMA pieces of slots 2 w, 2 w + 1 of every half tile, three half tiles ahead;
+//   * ONE barrier per half tile does both jobs: every wave has waited for its own pieces of half tile h (counted vmcnt) before
+//     it, so after it all of h is in LDS; and every wave has finished reading h - 1, whose buffer is refilled right after;
+//   * fragments are read a whole slot (4 x 16 B per lane) ahead of the matrix pipe.
+// Sibling workgroups (SIB = 2: two workgroups of one XCD, 128 queries each, same tile sequence, default cache policy) as in
+// the quad kernel: HBM sees the corpus once per 256 queries.
+#define CQ_HT_SLOTS 8
+#define CQ_HT_BYTES (CQ_HT_SLOTS * CB_SLOT_BYTES)
+#ifndef CQ_NHB
+#define CQ_NHB 4
+#endif
+#define CQ_STAGE 256
+#define CQ_STAGE_FLUSH 64u
+#define CQ_LDS (CQ_NHB * CQ_HT_BYTES + 128 * 4 + 4 * CQ_STAGE * 12)
+
+__device__ __forceinline__ uint32_t cq_incl_scan(uint32_t v) { // wave-wide inclusive prefix sum (DPP, no LDS)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+template <int SIB>
+__global__ __launch_bounds__(256, 1) void cosine_bf16_qsplit(
+    const uint16_t *__restrict__ rows, uint64_t row_begin, uint64_t row_end,
+    const uint16_t *__restrict__ queries, // bf16 [128 (x 2 with siblings)][1024], zero padded
+    uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
+    const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
+    constexpr int D = 1024, NHB = CQ_NHB;
+    constexpr bool STREAM = SIB == 0;
+    constexpr uint32_t RING = NHB * CQ_HT_BYTES;
+    static_assert(NHB == 4 && CQ_LDS <= 160 * 1024, "the refill of half tile h + NHB is addressed as tile ti + 2: NHB = 4");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char *ring = smem;                                                  // [NHB][8 slots][4 KiB]: shared by the four waves
+    uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + RING);              // [128]
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);                 // the query tile of this wave
+    const uint32_t li = lane & 31, lh = lane >> 5;
+    uint64_t *stage_keys = reinterpret_cast<uint64_t *>(smem + RING + 512) + w * CQ_STAGE;
+    uint32_t *stage_q = reinterpret_cast<uint32_t *>(smem + RING + 512 + 4 * CQ_STAGE * 8) + w * CQ_STAGE;
+    uint32_t st_head = 0, st_n = 0;
+
+    uint32_t half = 0, wg = blockIdx.x, n_wg = gridDim.x; // siblings: see cosine_bf16_quad
+    if (SIB == 1) { half = blockIdx.x & 1u; wg = blockIdx.x >> 1; n_wg = gridDim.x >> 1; }
+    else if (SIB == 2) { half = (blockIdx.x >> 3) & 1u; wg = ((blockIdx.x >> 4) << 3) | (blockIdx.x & 7u); n_wg = gridDim.x >> 1; }
+    if (half) {
+        queries += (uint64_t)128 * D;
+        pools += (uint64_t)128 * pool_stride;
+        seg_cnt += (uint64_t)128 * seg_cnt_stride;
+        tau_keys += 128;
+        n_queries = n_queries > 128u ? n_queries - 128u : 0u;
+    } else if (SIB && n_queries > 128u) n_queries = 128u;
+
+    // ---- this wave's 32 queries over the whole K, in registers: B[k = 16 s + 8 lh + 0..7][n = li]
+    cb_bf16x8 qreg[64];
+#pragma unroll
+    for (int s = 0; s < 64; ++s)
+        qreg[s] = *reinterpret_cast<const cb_bf16x8 *>(queries + (uint64_t)(32 * w + li) * D + 16 * s + 8 * lh);
+    const uint32_t my_q = 32u * w + li;
+    const uint32_t my_tau = my_q < n_queries ? tau_keys[my_q] : 0xFFFFFFFFu;
+    const float tau_f = my_tau <= 0x007FFFFFu ? -__builtin_inff() : oi_key_f32(my_tau); // (no query in the slot: NaN, nothing passes)
+    if (tid < 128) seg_fill[tid] = 0;
+
+    const uint64_t n_rows = row_end - row_begin;
+    const uint64_t n_tiles = (n_rows + CB_TILE_ROWS - 1) / CB_TILE_ROWS;
+#if OI_TILE_CONTIG // A/B: every workgroup (pair) owns a CONTIGUOUS run of tiles instead of every n_wg-th tile
+    const uint64_t per_ = (n_tiles + n_wg - 1) / n_wg;
+    const uint64_t first = (uint64_t)wg * per_, stride = 1;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first < per_ ? n_tiles - first : per_) : 0;
+#else
+    const uint64_t first = wg, stride = n_wg;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+#endif
+    uint64_t *my_seg = pools + carry_cap + (uint64_t)wg * seg_cap;
+
+    // per-lane source of the 4 DMA pieces of a slot (piece m: tile rows 8m..8m+7; the swizzle of the other kernels)
+    uint32_t voff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const uint32_t prow = 8 * m + (lane >> 3);
+        voff[m] = prow * (uint32_t)(D * 2) + (((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+    }
+    const uint32_t ring_w = cb_lds_addr(ring);
+    uint32_t frag_off[4]; // fragment of MFMA group g of a slot: row li, logical 16-B column 2 g + lh
+#pragma unroll
+    for (int g = 0; g < 4; ++g) frag_off[g] = li * 128 + (((2 * g + lh) ^ ((li >> 1) & 7)) << 4);
+
+    auto tile_row0 = [&](uint64_t ti) { return row_begin + (first + ti * stride) * (uint64_t)CB_TILE_ROWS; };
+    auto tile_srd = [&](uint64_t ti) { // past this workgroup's last tile: an EMPTY descriptor (loads return zeros)
+        const uint64_t r0 = tile_row0(ti < my_nt ? ti : 0);
+        return cb_make_srd(rows + r0 * D, ti < my_nt ? (row_end - r0) * (uint64_t)(D * 2) : 0ull);
+    };
+    // this wave's pieces of one half tile (slots 2 w and 2 w + 1): K half `hh` of the tile described by `srd`
+    auto issue_slot = [&](const cb_u32x4 &srd, uint32_t hh, uint32_t jj, uint32_t buf_off) __attribute__((always_inline)) {
+        const uint32_t j = 2u * w + jj;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            cb_issue_piece<STREAM>(srd, voff[m], hh * 1024u + j * 128u, ring_w + buf_off + j * CB_SLOT_BYTES + m * 1024, false);
+    };
+    cb_u32x4 s0 = tile_srd(0), s1 = tile_srd(1), s2 = tile_srd(2);
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only: retire every load hipcc knows about, here
+    __syncthreads();                    // seg_fill is zero before any wave appends
+    // The slot stream is continuous over half tiles and tiles.  Fragments are read THREE slots ahead of the matrix pipe (a slot
+    // is four MFMAs = 128 cycles; one slot ahead, the LDS reads -- four waves' fragment traffic plus the DMA writes on one LDS
+    // pipe -- came back after ~250 cycles and every slot waited for them: stream and MFMA time ADDED UP, 5.3 + 2.8 ms per batch
+    // at a 12.5M-row shard with and without the matrix instructions).  So the reads of half tile h + 1 begin at slot 5 of half
+    // tile h, and the ONE barrier per half tile sits there: before it a wave waits for its own DMA pieces of h + 1 (counted
+    // vmcnt) -- after it all of h + 1 is in LDS; and every read of half tile h has been issued (the last ones at slot 4) and,
+    // by the barrier's lgkmcnt(0), completed -- its buffer is refilled with half tile h + NHB right after the barrier.
+    cb_bf16x8 fr[4][4]; // fragments of slots g, g + 1, g + 2 (and the one being read): slot g lives in fr[g % 4]
+    if (my_nt) {
+        cb_static_for<0, NHB>([&](auto h_) { // prologue: half tiles 0 .. NHB - 1 (tile h / 2, K half h % 2) fill the ring
+            constexpr int h = decltype(h_)::value;
+            issue_slot(h / 2 == 0 ? s0 : s1, h % 2, 0, h * CQ_HT_BYTES);
+            issue_slot(h / 2 == 0 ? s0 : s1, h % 2, 1, h * CQ_HT_BYTES);
+        });
+        cb_wait<8 * (NHB - 1)>(); // this wave's pieces of half tile 0 ...
+    }
+    __syncthreads();              // ... and everyone's
+    if (my_nt) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) fr[j][g] = *reinterpret_cast<const cb_bf16x8 *>(ring + j * CB_SLOT_BYTES + frag_off[g]);
+    }
+    uint32_t rd_off = 0; // the buffer of the half tile the matrix pipe is on
+
+    for (uint64_t ti = 0; ti < my_nt; ++ti) {
+        cb_f32x16 acc;
+        cb_static_for<0, 2>([&](auto hh_) {
+            constexpr int hh = decltype(hh_)::value;
+            const uint32_t nx_off = rd_off + CQ_HT_BYTES == RING ? 0u : rd_off + CQ_HT_BYTES;
+            cb_static_for<0, CQ_HT_SLOTS>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
+                if constexpr (j == 5) {
+                    cb_wait<8 * (NHB - 2)>(); // this wave's pieces of the NEXT half tile are in LDS ...
+                    __syncthreads();          // ... and everyone's; everyone has finished reading THIS half tile's buffer
+                }
+#ifdef CQ_NOMFMA // (variant builds, timings only: the stream and the LDS traffic without the matrix pipe)
+                if constexpr (hh == 0 && j == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] += (float)fr[j % 4][g][0];
+#else
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (hh == 0 && j == 0) { if (g == 0) cb_mfma_agpr_first(acc, fr[0][0], qreg[0]); else cb_mfma_agpr(acc, fr[0][g], qreg[g]); }
+                    else cb_mfma_agpr(acc, fr[j % 4][g], qreg[hh * 32 + j * 4 + g]);
+                }
+#endif
+                // fragments of the slot three ahead: this half tile's, or (from slot 5 on) the next one's.  AFTER this slot's MFMAs
+                // in program order: the registers they go to fed the PREVIOUS slot's MFMAs, all issued a slot ago.
+                {
+                    const unsigned char *src = j + 3 < CQ_HT_SLOTS ? ring + rd_off + (j + 3) * CB_SLOT_BYTES
+                                                                   : ring + nx_off + (j + 3 - CQ_HT_SLOTS) * CB_SLOT_BYTES;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) fr[(j + 3) % 4][g] = *reinterpret_cast<const cb_bf16x8 *>(src + frag_off[g]);
+                }
+                // the refill of THIS half tile's buffer (free since the barrier): half tile h + NHB = K half hh of tile ti + NHB / 2
+                if constexpr (j == 5) issue_slot(s2, hh, 0, rd_off);
+                if constexpr (j == 6) issue_slot(s2, hh, 1, rd_off);
+            });
+            rd_off = nx_off;
+        });
+        cb_mfma_drain(); // the accumulators are read next
+
+        // ---- filter + append (cosine_screen_filter's epilogue with one query tile): register r holds
+        // D[row (r&3) + 8 (r>>2) + 4 lh][query 32 w + li]
+        const uint64_t row0 = tile_row0(ti);
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= acc[r] >= tau_f ? 1u << r : 0u;
+        if (row_end - row0 < (uint64_t)CB_TILE_ROWS) { // the ragged last tile: rows past the end read as zeros
+            const uint32_t left = (uint32_t)(row_end - row0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * lh >= left) m &= ~(1u << r);
+        }
+        if (__builtin_amdgcn_ballot_w64(m != 0u) != 0ull) {
+            const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+            const uint32_t incl = cq_incl_scan(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total <= CQ_STAGE - CQ_STAGE_FLUSH) { // sparse tile: staged in LDS, 64 keys leave with one store instruction
+                uint32_t idx = st_head + st_n + incl - cnt;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (m & (1u << r)) {
+                        const uint32_t row = (uint32_t)row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        stage_keys[idx & (CQ_STAGE - 1)] = oi_rank_key(acc[r], doc_id_base + row);
+                        stage_q[idx & (CQ_STAGE - 1)] = my_q;
+                        ++idx;
+                    }
+                st_n += total;
+                while (st_n >= CQ_STAGE_FLUSH) {
+                    asm volatile("" ::: "memory");
+                    {
+                        const uint32_t i_ = (st_head + lane) & (CQ_STAGE - 1);
+                        const uint64_t key_ = stage_keys[i_];
+                        const uint32_t q_ = stage_q[i_];
+                        const uint32_t pos_ = atomicAdd(&seg_fill[q_], 1u);
+                        if (pos_ < seg_cap) my_seg[(uint64_t)q_ * pool_stride + pos_] = key_;
+                        else *overflow = 1u;
+                    }
+                    asm volatile("" ::: "memory");
+                    st_head = (st_head + CQ_STAGE_FLUSH) & (CQ_STAGE - 1);
+                    st_n -= CQ_STAGE_FLUSH;
+                }
+            } else { // dense tile (no threshold yet): straight to the pool
+                uint32_t pos = atomicAdd(&seg_fill[my_q], cnt);
+                uint64_t *dst = my_seg + (uint64_t)my_q * pool_stride;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (m & (1u << r)) {
+                        const uint32_t row = (uint32_t)row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (pos < seg_cap) dst[pos] = oi_rank_key(acc[r], doc_id_base + row);
+                        else *overflow = 1u;
+                        ++pos;
+                    }
+            }
+        }
+        s0 = s1;
+        s1 = s2;
+        s2 = tile_srd(ti + 3);
+    }
+    if (st_n) { // the staged rest
+        asm volatile("" ::: "memory");
+        if (lane < st_n) {
+            const uint32_t i_ = (st_head + lane) & (CQ_STAGE - 1);
+            const uint64_t key_ = stage_keys[i_];
+            const uint32_t q_ = stage_q[i_];
+            const uint32_t pos_ = atomicAdd(&seg_fill[q_], 1u);
+            if (pos_ < seg_cap) my_seg[(uint64_t)q_ * pool_stride + pos_] = key_;
+            else *overflow = 1u;
+        }
+        asm volatile("" ::: "memory");
+    }
+    cb_wait<0>(); // the zero-filling refills issued past the last tile have landed before the LDS goes back
+    __syncthreads();
+    if (tid < 128 && tid < n_queries) {
+        const uint32_t c = seg_fill[tid];
+        seg_cnt[(uint64_t)tid * seg_cnt_stride + wg] = c < seg_cap ? c : seg_cap;
+    }
+}
+
 // ------------------------------------------------------------------ query staging: f32 -> bf16 (RNE), zero padded
 __global__ __launch_bounds__(256) void cb_stage_queries(const float *__restrict__ q, uint32_t n_queries, uint32_t n_padded,
                                                         uint32_t dim, uint16_t *__restrict__ out) {
@@ -752,6 +1015,19 @@ static int launch_bf16_pair(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
     return OI_OK;
 }
 
+template <int SIB>
+static int launch_bf16_qsplit(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
+                              uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
+    const uint32_t grid = SIB ? 2u * p.n_segs : p.n_segs;
+    constexpr size_t smem = CQ_LDS;
+    OI_CHECK(oi_dyn_lds(ctx, reinterpret_cast<const void *>(cosine_bf16_qsplit<SIB>), (size_t)(smem)));
+    hipLaunchKernelGGL((cosine_bf16_qsplit<SIB>), dim3(grid), dim3(256), smem, ctx->stream, rows, row_begin, row_end, q, nq,
+                       doc_id_base, p.keys, p.seg_cnt, p.seg_cnt_stride, p.tau_keys, p.stride, p.carry_cap, p.seg_cap,
+                       p.overflow);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 template <int D, int DBG, int SIB>
 static int launch_bf16_quad_k(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begin, uint64_t row_end, const uint16_t *q,
                               uint32_t nq, uint32_t doc_id_base, const PoolView &p) {
@@ -778,6 +1054,10 @@ static int launch_bf16_quad(oi_ctx *ctx, const uint16_t *rows, uint64_t row_begi
                              : launch_bf16_quad_k<D, 3, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
     if (sib == 1) return launch_bf16_quad_k<D, 0, 1>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 #endif
+    // Round 5: 128 queries per pass split by QUERY over the waves (cosine_bf16_qsplit) instead of by K.  OI_BF16_QUAD=1 (A/B): the K split.
+    static const bool k_split = oi_ablation_env("OI_BF16_QUAD") != nullptr;
+    if (D == 1024 && !k_split) return sib ? launch_bf16_qsplit<2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p)
+                                          : launch_bf16_qsplit<0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
     if (sib) return launch_bf16_quad_k<D, 0, 2>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
     return launch_bf16_quad_k<D, 0, 0>(ctx, rows, row_begin, row_end, q, nq, doc_id_base, p);
 }

@@ -33,6 +33,9 @@ typedef float sc_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 sc_bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t sc_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef OI_TILE_CONTIG
+#define OI_TILE_CONTIG 0
+#endif
 #define SC_TILE_ROWS 32
 #define SC_SLOT_K 64                 // bf16 of K per ring slot row (128 B)
 #define SC_SLOT_BYTES (SC_TILE_ROWS * 128)
@@ -153,8 +156,14 @@ __global__ __launch_bounds__(256, 1) void cosine_copy_screen(
     // ---- tiles of this WAVE: (blockIdx.x * 4 + w), + 4 * gridDim.x, ...
     const uint64_t n_rows = row_end - row_begin;
     const uint64_t n_tiles = (n_rows + SC_TILE_ROWS - 1) / SC_TILE_ROWS;
+#if OI_TILE_CONTIG // A/B: every wave owns a CONTIGUOUS run of tiles (sequential pages) instead of every stride-th tile
+    const uint64_t n_waves_ = (uint64_t)gridDim.x * 4, per_ = (n_tiles + n_waves_ - 1) / n_waves_;
+    const uint64_t first = ((uint64_t)blockIdx.x * 4 + w) * per_, stride = 1;
+    const uint64_t my_nt = first < n_tiles ? (n_tiles - first < per_ ? n_tiles - first : per_) : 0;
+#else
     const uint64_t first = (uint64_t)blockIdx.x * 4 + w, stride = (uint64_t)gridDim.x * 4;
     const uint64_t my_nt = first < n_tiles ? (n_tiles - first + stride - 1) / stride : 0;
+#endif
     uint64_t *my_seg = pools + carry_cap + (uint64_t)blockIdx.x * seg_cap;
 
     if (my_nt) {
