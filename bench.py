@@ -497,7 +497,10 @@ def main():
         def __init__(self, lanes):
             self.p = oi.NativePipeline(idx, lanes=lanes, max_queries=args.batch, max_query_terms=4, depth=args.depth, k=args.k,
                                        comm=native_comm)
-            self.n_slots, self.n, self.calibration = 8, 0, None
+            self.n_slots, self.n = 8, 0
+            cs = self.p.concurrent_streams()
+            self.calibration = {"chosen_lanes": lanes, "streams_measured_concurrent": cs[0], "streams": cs[1],
+                                "note": "oi_pipeline_create draws candidate streams until lanes + 1 run at the same time (measured with a spin kernel)"}
             self.lanes = [(None, None)] * lanes
             self.results = [oi.SearchResult(torch.zeros((args.batch, args.k), dtype=torch.float32, device=dev),
                                             torch.zeros((args.batch, args.k), dtype=torch.int32, device=dev),
@@ -583,11 +586,26 @@ def main():
     # ---------------------------------------------------------------- timed region: exactly K steps
     for c in [ctx] + lane_ctxs:
         c.profile_reset(0 if os.environ.get("OI_BENCH_NO_LIVE_EVENTS") else 2)   # HIP events around the dominant kernel's launches only (each pair costs stream time)
+    # The interpreter's cyclic garbage collector stays out of the K steps: a generation-2 pass over this process's heap (torch,
+    # numpy, the corpus generators' leftovers) is a 60 ms host stall, and one landed inside the 47 ms timed region of the native
+    # exchange in every run (its K calls cost 0.1 ms each on the host) -- round 5's "native is slower under bench.py" was that.
+    import gc
+    gc.collect()
+    if not os.environ.get("OI_BENCH_KEEP_GC"):
+        gc.disable()
     fence()
     t0 = time.perf_counter()
+    step_host, step_at = [], []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        step_host.append(time.perf_counter() - ts)
+        step_at.append(ts - t0)
     t_enqueued = time.perf_counter() - t0    # (host time of the K calls alone: shows a host-bound loop)
+    gc.enable()
+    if os.environ.get("OI_BENCH_STEP_TIMES"):
+        sys.stderr.write("[bench] host us per step() call: " + " ".join("%d" % (x * 1e6) for x in step_host) + "\n")
+        sys.stderr.write("[bench] step() entered at us: " + " ".join("%d" % (x * 1e6) for x in step_at) + "\n")
     fence()
     elapsed = time.perf_counter() - t0
     tm_own = elapsed
@@ -709,6 +727,7 @@ def main():
         pipelined_side = {"ms_per_step": pp_elapsed / args.steps * 1e3, "queries_per_s": args.batch * args.steps / pp_elapsed,
                           "steps": args.steps, "lanes": 2, "bit_identical_to_oi_search": same,
                           "workspace_GB": round(npipe.workspace_bytes()[0] / 1e9, 3),
+                          "streams_measured_concurrent": "%d of %d" % npipe.concurrent_streams(),
                           "note": "oi_pipeline_create(idx, NULL, 2 lanes) / oi_pipeline_submit x K / oi_pipeline_drain: two batches in flight "
                                   "through lanes the library owns; NOT the headline (value = one oi_search call per batch, one batch in flight)"}
         npipe.close()

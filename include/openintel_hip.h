@@ -475,6 +475,10 @@ int oi_pipeline_drain(oi_pipeline *p);
 int oi_pipeline_workspace_bytes(oi_pipeline *p, uint64_t *device_bytes_out, uint64_t *pinned_host_bytes_out);
 /* oi_profile_reset / oi_profile_read (below) over the pipeline's lanes, summed (the lanes' contexts are the library's own).
  * Two lanes' launches overlap in time: the summed durations then exceed the wall time they covered. */
+/* oi_pipeline_create MEASURES which of its streams run at the same time (HIP maps streams onto a few hardware queues, and
+ * which queue a new stream gets depends on every stream the process already has: two lanes on one queue serialise) and
+ * keeps lanes + 1 that do, drawing up to 12 candidates.  This reports how many of the lanes + 1 were pairwise concurrent. */
+int oi_pipeline_concurrent_streams(oi_pipeline *p, uint32_t *concurrent_out, uint32_t *streams_out);
 int oi_pipeline_profile_reset(oi_pipeline *p, int enable);
 int oi_pipeline_profile_read(oi_pipeline *p, const char *kernel_tag, double *total_ms_out, uint64_t *launches_out);
 

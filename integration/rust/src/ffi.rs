@@ -151,6 +151,7 @@ extern "C" {
     pub fn oi_pipeline_drain(p: *mut OiPipeline) -> c_int;
     pub fn oi_pipeline_workspace_bytes(p: *mut OiPipeline, device_bytes_out: *mut u64,
                                        pinned_host_bytes_out: *mut u64) -> c_int;
+    pub fn oi_pipeline_concurrent_streams(p: *mut OiPipeline, concurrent_out: *mut u32, streams_out: *mut u32) -> c_int;
     pub fn oi_pipeline_profile_reset(p: *mut OiPipeline, enable: c_int) -> c_int;
     pub fn oi_pipeline_profile_read(p: *mut OiPipeline, kernel_tag: *const c_char, total_ms_out: *mut f64,
                                     launches_out: *mut u64) -> c_int;

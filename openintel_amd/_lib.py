@@ -107,6 +107,7 @@ SIGNATURES = {
     "oi_pipeline_wait": (_I, [_P, _U64, _I]),
     "oi_pipeline_drain": (_I, [_P]),
     "oi_pipeline_workspace_bytes": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
+    "oi_pipeline_concurrent_streams": (_I, [_P, C.POINTER(_U32), C.POINTER(_U32)]),
     "oi_pipeline_profile_reset": (_I, [_P, _I]),
     "oi_pipeline_profile_read": (_I, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_U64)]),
     "oi_screen_probe": (_I, [_P, _P, _U32, _U64, _U32, _P, _P]),

@@ -23,7 +23,68 @@
 
 #include "oi_internal.h"
 
+// ---- which streams really run at the same time
+// HIP maps streams onto a few hardware queues and two streams on one queue run one after the other, whatever their events
+// allow.  Which queue a new stream gets depends on every stream the PROCESS already has: under bench.py, with a torch process
+// group alive (its stream pools hold references on every queue), both lanes of a pipeline landed on ONE queue and the
+// "pipelined" step was slower than the serial one (0.76 vs 0.58 ms at a 1.25M-row shard; kernel trace: every lane kernel on
+// queue 8, tools/r05_native_trace.sh) while the same pipeline ran at 0.46 ms in a process of its own.  HIP has no call that
+// names a stream's queue, so it is MEASURED: a kernel that spins for 500 us on stream a, an empty kernel on stream b -- if b's
+// is done within 300 us of the launches, the two streams are on different queues.  oi_pipeline_create draws candidate streams
+// until it has lanes + 1 that are pairwise concurrent (at most PL_CANDIDATES; then it takes what it has).
+__global__ void pl_spin_kernel(uint64_t ticks) { // bounded: leaves after `ticks` of the 100 MHz wall clock whatever happens
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void pl_noop_kernel() {}
+
 namespace {
+
+#define PL_CANDIDATES 12
+
+bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t ev) {
+    // by the CLOCK: the empty kernel on b is done ~30 us after its launch if b has a queue of its own, and only after the 500 us
+    // spin if it sits behind it on a's queue.  (hipStreamQuery(a) right after b's event is no test: the runtime may not have
+    // noticed a's completion yet, and two streams on ONE queue then look concurrent -- the first version of this did.)
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(pl_spin_kernel, dim3(1), dim3(64), 0, a, (uint64_t)50000); // 500 us of the 100 MHz clock
+    hipLaunchKernelGGL(pl_noop_kernel, dim3(1), dim3(64), 0, b);
+    bool conc = false;
+    if (hipEventRecord(ev, b) == hipSuccess && hipEventSynchronize(ev) == hipSuccess)
+        conc = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 300.0;
+    (void)hipStreamSynchronize(a);
+    (void)hipGetLastError();
+    return conc;
+}
+
+// `want` pairwise-concurrent streams (as many as could be found among PL_CANDIDATES fresh ones, padded with further fresh
+// streams otherwise); the rest are destroyed.  *found = how many of them are pairwise concurrent.
+int pick_streams(uint32_t want, int prio, std::vector<hipStream_t> *out, uint32_t *found) {
+    std::vector<hipStream_t> keep, drop;
+    hipEvent_t ev = nullptr;
+    OI_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (int c = 0; c < PL_CANDIDATES && keep.size() < want; ++c) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess) break;
+        bool ok = true;
+        for (hipStream_t k : keep)
+            if (!streams_concurrent(k, st, ev)) { ok = false; break; }
+        (ok ? keep : drop).push_back(st);
+    }
+    *found = (uint32_t)keep.size();
+    while (keep.size() < want && !drop.empty()) { keep.push_back(drop.back()); drop.pop_back(); } // (not concurrent with all: still a stream)
+    for (hipStream_t st : drop) (void)hipStreamDestroy(st);
+    (void)hipEventDestroy(ev);
+    while (keep.size() < want) {
+        hipStream_t st = nullptr;
+        OI_HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+        keep.push_back(st);
+    }
+    *out = keep;
+    return OI_OK;
+}
 
 struct Slot {
     uint32_t *packed = nullptr; // device, OI_PACKED_WORDS(B_max, depth)
@@ -56,6 +117,7 @@ struct oi_pipeline {
     hipEvent_t ev_in = nullptr;
     std::vector<Slot> slots;
     uint64_t n_submitted = 0;
+    uint32_t concurrent_streams = 0; // of lanes + 1: how many were measured to run at the same time (oi_pipeline_create)
     std::mutex mu;
     // OI_PIPELINE_TRACE=1: host time of submit by phase (us, summed), printed to stderr at destroy -- a host-bound pipeline shows here
     bool trace = false;
@@ -164,13 +226,15 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const char *prio_env = getenv("OI_PIPELINE_STREAM_PRIORITY");
     const int prio = (prio_env && atoi(prio_env) != 0) ? prio_greatest : 0;
+    std::vector<hipStream_t> picked;
+    PL_OI(pick_streams(lanes + 1, prio, &picked, &p->concurrent_streams));
+    p->fuse_st = picked[lanes]; // (owned by p from here on: destroy() frees it with the lanes')
+    for (uint32_t l = 0; l < lanes; ++l) p->lane_st.push_back(picked[l]);
     for (uint32_t l = 0; l < lanes; ++l) {
         oi_ctx *c = nullptr;
         PL_OI(oi_create_like(ctx, &c));
         p->lane_ctx.push_back(c);
-        hipStream_t st = nullptr;
-        PL_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
-        p->lane_st.push_back(st);
+        hipStream_t st = p->lane_st[l];
         PL_OI(oi_set_stream(c, st));
         // With two or more lanes the BM25 leg of a batch runs IN its lane's stream, not on a side stream of its own: the other
         // lane's corpus stream is what it overlaps with, and every further stream is one more contender for the few hardware
@@ -184,7 +248,6 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
         p->lane_idx.push_back(v);
     }
     PL_OI(oi_create_like(ctx, &p->fuse_ctx));
-    PL_HIP(hipStreamCreateWithPriority(&p->fuse_st, hipStreamNonBlocking, prio));
     PL_OI(oi_set_stream(p->fuse_ctx, p->fuse_st));
     p->slots.resize(std::max<uint32_t>(4, 2 * lanes));
     for (Slot &s : p->slots) {
@@ -210,9 +273,9 @@ extern "C" int oi_pipeline_create(oi_index *idx, oi_comm *comm, uint32_t lanes, 
 extern "C" void oi_pipeline_destroy(oi_pipeline *p) {
     if (!p) return;
     if (p->trace && p->n_submitted)
-        fprintf(stderr, "[oi_pipeline] %llu submits; host us per submit: wait/stage %.1f, lists %.1f, exchange %.1f, fuse %.1f\n",
+        fprintf(stderr, "[oi_pipeline] %llu submits; host us per submit: wait/stage %.1f, lists %.1f, exchange %.1f, fuse %.1f; %u of %zu streams concurrent\n",
                 (unsigned long long)p->n_submitted, p->t_phase[0] / p->n_submitted, p->t_phase[1] / p->n_submitted,
-                p->t_phase[2] / p->n_submitted, p->t_phase[3] / p->n_submitted);
+                p->t_phase[2] / p->n_submitted, p->t_phase[3] / p->n_submitted, p->concurrent_streams, p->lane_st.size() + 1);
     {
         std::lock_guard<std::mutex> g(p->mu);
         for (Slot &s : p->slots) (void)retire(p, s);
@@ -371,5 +434,13 @@ extern "C" int oi_pipeline_profile_read(oi_pipeline *p, const char *kernel_tag, 
     }
     if (total_ms_out) *total_ms_out = ms;
     if (launches_out) *launches_out = n;
+    return OI_OK;
+}
+
+// Diagnostics: how many of the pipeline's lanes + 1 streams were measured to run at the same time when it was created.
+extern "C" int oi_pipeline_concurrent_streams(oi_pipeline *p, uint32_t *concurrent_out, uint32_t *streams_out) {
+    if (!p) { oi_set_error("null pipeline"); return OI_ERR_INVALID_ARG; }
+    if (concurrent_out) *concurrent_out = p->concurrent_streams;
+    if (streams_out) *streams_out = (uint32_t)p->lane_st.size() + 1;
     return OI_OK;
 }

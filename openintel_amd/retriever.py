@@ -376,6 +376,12 @@ class NativePipeline:
         _lib.check(self.lib.oi_pipeline_workspace_bytes(self.handle, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
+    def concurrent_streams(self):
+        """(how many of the pipeline's streams were measured to run at the same time, how many it has): oi_pipeline_concurrent_streams."""
+        a, b = C.c_uint32(), C.c_uint32()
+        _lib.check(self.lib.oi_pipeline_concurrent_streams(self.handle, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def profile_reset(self, enable) -> None:
         _lib.check(self.lib.oi_pipeline_profile_reset(self.handle, int(enable)))
 

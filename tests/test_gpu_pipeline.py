@@ -54,6 +54,8 @@ def test_pipeline_equals_oi_search_bit_for_bit_host_and_device(lanes):
     want = [idx.search(q, qt, qo, k=K, depth=DEPTH) for q, qt, qo in batches]
     pipe = oi.NativePipeline(idx, lanes=lanes, max_queries=64, max_query_terms=4, depth=DEPTH, k=K)
     assert pipe.workspace_bytes()[0] > 0
+    conc, total = pipe.concurrent_streams()
+    assert total == lanes + 1 and 1 <= conc <= total
     # (a) host buffers: submit everything (more batches than slots: early ones are delivered when their slot is reused), then wait
     sub = [pipe.submit(q, qt, qo) for q, qt, qo in batches]
     for t, _ in reversed(sub):
