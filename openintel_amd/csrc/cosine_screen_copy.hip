@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256, 1) void cosine_copy_screen(
     unsigned char *ring = smem;                                          // [4][NBUF][4 KiB]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * RING);  // [64]
 
+    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t li = lane & 31, lh = lane >> 5;

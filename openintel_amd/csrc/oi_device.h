@@ -57,6 +57,24 @@ __device__ __forceinline__ float4 oi_load_stream(const float4 *p) {
 #endif
 }
 
+// A workgroup that streams with LDS-DMA (buffer_load ... lds / global_load_lds) must have its CU to itself.
+// Round 5 found it the hard way: searches through views of one index on streams that really ran at the same time returned, a
+// few times in a thousand batches, a cosine list with ONE wrong exact score -- pf_rescore_kernel's dot product of a (query, row)
+// pair off by 1e-3 .. 1e-2, equal to no other pair's score -- and only when its waves had been co-resident on a CU with a screen
+// workgroup of ANOTHER stream (d = 384: the screen wave takes 304 of the SIMD's 512 registers, so a small kernel's wave fits
+// beside it; never at d = 768, 494 registers; never once the rescoring kernel asked for enough LDS not to fit on such a CU:
+// tools/r05_lane_race.py, 0 of 1800 batches against 17-63 of 900).  A wave doing ordinary vector loads beside a wave doing
+// LDS-DMA on the same CU can get wrong data back.  (Not the M0 hand-back: holding M0 for 30 more cycles after the DMA instruction
+// changed nothing, 42 and 46 of 1350; not the register allocation: the kernel descriptor and the highest v / a register in the
+// ISA agree; not the cross-lane sum, not the non-temporal policy.)  Whatever the mechanism, the cure is exclusivity: every LDS-DMA kernel of this
+// library runs one wave per SIMD and claims the SIMD's WHOLE register file (v255 and a255 touched: 256 + 256 registers
+// allocated), so no other wave -- ours, the runtime's fill / copy kernels, another process's -- can be scheduled beside it.
+#ifdef OI_NO_CLAIM // (variant builds: tools/r05_lane_race.py shows the corruption again with it)
+#define OI_CLAIM_WHOLE_SIMD() do { } while (0)
+#else
+#define OI_CLAIM_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
+#endif
+
 // Order-preserving map f32 -> u32 (ascending).  -0.0 is folded into +0.0 first so
 // that equal scores compare equal; NaN must be rejected by the caller.
 __device__ __forceinline__ uint32_t oi_f32_key(float s) {

@@ -132,3 +132,47 @@ def test_pipeline_survives_any_destruction_order():
     pipe.close()                     # drains
     assert np.array_equal(out2.docs, want_docs)
     idx.close()
+
+
+@pytest.mark.parametrize("mode", ["copy", "stream"])
+def test_concurrent_lanes_return_the_serial_lists_bit_for_bit(mode):
+    """Round 5's co-residency finding (csrc/oi_device.h, OI_CLAIM_WHOLE_SIMD): with lanes that REALLY run at the same time (eight
+    hardware queues), a small kernel's wave scheduled on a CU beside a d = 384 screen workgroup of another lane got wrong data --
+    one wrong exact cosine score in 2-7 % of the batches.  The LDS-DMA kernels now take their CU whole.  Three lanes, their
+    own streams, views of one index, rotating ragged batches, 40 rounds (360 batches; the unfixed library failed 10-25 of them):
+    every packed pair of lists must be the serial call's, word for word."""
+    import torch
+    import openintel_amd as oi
+    from openintel_amd import _lib
+    DEPTH, LANES, ROUNDS = 200, 3, 40
+    rows, terms, offs, batches = _case()                       # d = 384: the screen wave leaves room on its SIMD unless it claims it
+    ctx = oi.HipContext(0)
+    ctx.set_cosine_mode(_lib.OI_COSINE_SCREEN if mode == "copy" else _lib.OI_COSINE_SCREEN_STREAM)
+    idx = _index(ctx, rows, terms, offs)
+    if mode == "copy":
+        assert idx.index_bytes()[1] > 0                        # (made by default at this size)
+    dev = torch.device("cuda:0")
+    dbs = [[torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).to(dev) for x in b] for b in batches]
+    torch.cuda.synchronize()
+    want = [idx.search_lists_packed(*b, depth=DEPTH).clone() for b in dbs]
+    torch.cuda.synchronize()
+    lanes = []
+    for _ in range(LANES):
+        c = oi.HipContext.like(ctx)
+        st = torch.cuda.Stream(device=dev)
+        c.set_stream(st)
+        c.set_overlap(False)
+        lanes.append((idx.view(c), st, c))
+    bad = []
+    for rnd in range(ROUNDS):
+        outs = []
+        for i, b in enumerate(dbs):
+            v, st, _ = lanes[(i + rnd) % LANES]
+            with torch.cuda.stream(st):
+                outs.append(v.search_lists_packed(*b, depth=DEPTH))
+        torch.cuda.synchronize()
+        bad += [(rnd, i) for i, o in enumerate(outs) if not torch.equal(o, want[i])]
+    assert not bad, "batches whose lists differ from the serial call's: %s" % bad[:10]
+    for v, _, c in lanes:
+        v.close(); c.close()
+    idx.close(); ctx.close()
