@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_filter(
     unsigned char *ring = smem;                                                       // [4][NBUF][4 KiB]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * CB_SLOT_BYTES); // [32*NQT]
 
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t li = lane & 31, lh = lane >> 5;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_pair(
     float *red = reinterpret_cast<float *>(smem + 4 * NBUF * CB_SLOT_BYTES);         // [2 pairs][RED]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 2 * RED);                // [32*NQT]
 
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t pr = w >> 1, kh = w & 1;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_quad(
     float *red = reinterpret_cast<float *>(smem + 4 * RING);                         // [4 writers][3 foreign query tiles][RED]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(red + 12 * RED);               // [128]
 
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6); // K quarter, and the query tile this wave finishes
     const uint32_t li = lane & 31, lh = lane >> 5;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_qsplit(
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char *ring = smem;                                                  // [NHB][8 slots][4 KiB]: shared by the four waves
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + RING);              // [128]
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);                 // the query tile of this wave
     const uint32_t li = lane & 31, lh = lane >> 5;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit_filter(
     const float *__restrict__ queries, // [32*NQT][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
     const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     // DBG (diagnostic instantiations only, results are then wrong): 1 = no DMA, 2 = no MFMA, 4 = no epilogue,
     // 8 = every workgroup re-reads the same 64 tiles (DMA served from L2/MALL instead of HBM)
     constexpr int KS = D / 4;            // K-slice of one wave
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void cosine_ksplit16_filter(
     for (int t = 0; t < NQ16; ++t)
 #pragma unroll
         for (int sg = 0; sg < KS / 16; ++sg) {
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
             const f32x4 v = *reinterpret_cast<const f32x4 *>(queries + (uint64_t)(16 * t + li) * D + w * KS + 16 * sg + 4 * kk);
             qreg[t][4 * sg + 0] = v[0]; qreg[t][4 * sg + 1] = v[1]; qreg[t][4 * sg + 2] = v[2]; qreg[t][4 * sg + 3] = v[3];
         }

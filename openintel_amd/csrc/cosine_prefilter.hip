@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void cosine_screen_filter(
     unsigned char *ring = smem;                                                         // [4][NBUF][4 KiB]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * NBUF * PF_SLOT_BYTES); // [64]
 
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t li = lane & 31, lh = lane >> 5;
@@ -584,8 +584,9 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
             for (int u = 0; u < 4; ++u) xv[u] = oi_load_stream(x[u] + v); // (each survivor row is read once)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                a[u] = fmaf(xv[u].x, yv.x, a[u]); a[u] = fmaf(xv[u].y, yv.y, a[u]);
-                a[u] = fmaf(xv[u].z, yv.z, a[u]); a[u] = fmaf(xv[u].w, yv.w, a[u]);
+                // (one v_fma_f32 each, NOT the packed form the vectoriser makes of two chains: oi_device.h, oi_fma_unpacked)
+                a[u] = oi_fma_unpacked(xv[u].x, yv.x, a[u]); a[u] = oi_fma_unpacked(xv[u].y, yv.y, a[u]);
+                a[u] = oi_fma_unpacked(xv[u].z, yv.z, a[u]); a[u] = oi_fma_unpacked(xv[u].w, yv.w, a[u]);
             }
         }
 #pragma unroll

@@ -58,6 +58,14 @@ __device__ __forceinline__ sc_u32x4 sc_make_srd(const uint16_t *base, uint64_t b
 // One 1-KiB LDS-DMA piece (8 rows x 128 B).  Lanes past the descriptor's end read as zero: the ragged last tile and the
 // tiles after the last one (empty descriptor) need no branch.  hipcc does not see these loads: sc_wait<N>() orders them.
 __device__ __forceinline__ void sc_issue_piece(const sc_u32x4 &srd, uint32_t voff, uint32_t soff, uint32_t lds_dst) {
+#if defined(SC_AGG_NO_DMA) && SC_AGG_NO_DMA == 1
+    // (variant builds, tools/r05_victim_probe.py: which trait of this kernel disturbs a neighbour wave?  The same bytes loaded
+    // into registers nobody reads instead of into LDS; the ring is zeroed at the start, every score is 0: results WRONG.)
+    const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
+    asm volatile("buffer_load_dwordx4 a[100:103], %0, %1, %2 offen " OI_DMA_NT : : "v"(voff), "s"(srd), "s"(so) : "memory", "a100", "a101", "a102", "a103");
+#elif defined(SC_AGG_NO_DMA)
+    (void)srd; (void)voff; (void)soff; (void)lds_dst; // (variant builds: no loads at all)
+#else
     uint32_t keep;
     const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
     const uint32_t so = __builtin_amdgcn_readfirstlane(soff);
@@ -70,6 +78,7 @@ __device__ __forceinline__ void sc_issue_piece(const sc_u32x4 &srd, uint32_t vof
         : "=&s"(keep)
         : "v"(voff), "s"(srd), "s"(so), "s"(d)
         : "memory");
+#endif
 }
 template <int I, int N, class F>
 __device__ __forceinline__ void sc_static_for(F &&f) {
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void cosine_copy_screen(
     unsigned char *ring = smem;                                          // [4][NBUF][4 KiB]
     uint32_t *seg_fill = reinterpret_cast<uint32_t *>(smem + 4 * RING);  // [64]
 
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t li = lane & 31, lh = lane >> 5;
@@ -152,6 +161,9 @@ __global__ __launch_bounds__(256, 1) void cosine_copy_screen(
         tauf[t] = k <= 0x007FFFFFu ? -__builtin_inff() : oi_key_f32(k);
     }
     if (tid < 32 * NQT) seg_fill[tid] = 0;
+#ifdef SC_AGG_NO_DMA
+    for (uint32_t i = tid; i < 4 * RING / 4; i += 256) reinterpret_cast<uint32_t *>(ring)[i] = 0u;
+#endif
     __syncthreads(); // the only barrier before the end: seg_fill is zero before any wave appends
 
     // ---- tiles of this WAVE: (blockIdx.x * 4 + w), + 4 * gridDim.x, ...
@@ -221,9 +233,13 @@ __global__ __launch_bounds__(256, 1) void cosine_copy_screen(
                 constexpr int tn = sn / NKC, kn = sn % NKC;
                 sc_bf16x8 a_nxt = a_cur;
                 if constexpr (g < 3) a_nxt = *reinterpret_cast<const sc_bf16x8 *>(ring_rd + rd_off + frag_off[g + 1]);
+#ifndef SC_AGG_NO_MFMA // (variant builds: the stream without the matrix instructions; every score 0, results WRONG)
 #pragma unroll
                 for (int t = 0; t < NQT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_cur, qreg[t][gi], acc[t], 0, 0, 0);
+#else
+                asm volatile("" : : "v"(a_cur));
+#endif
                 sc_issue_piece(tn == 0 ? s0 : (tn == 1 ? s1 : s2), voff[g], kn * 128, ring_w + wr_off + g * 1024);
                 if constexpr (g == 3) {
                     wr_off = rd_off;

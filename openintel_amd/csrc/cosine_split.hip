@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void cosine_split_filter(
     const uint16_t *__restrict__ qsplit, // bf16 [3 planes: H, M, L][32*NQT][D], zero padded
     uint32_t n_queries, uint32_t doc_id_base, uint64_t *pools, uint32_t *seg_cnt, uint32_t seg_cnt_stride,
     const uint32_t *tau_keys, uint64_t pool_stride, uint32_t carry_cap, uint32_t seg_cap, uint32_t *overflow) {
-    OI_CLAIM_WHOLE_SIMD(); // (LDS-DMA kernel: nothing else may run on this CU -- oi_device.h)
+    OI_CLAIM_WHOLE_SIMD(); // (MFMA kernel: nothing else may run on this CU -- oi_device.h)
     constexpr int KS = D / 4;            // K-slice of one wave (floats)
     constexpr int NKC = KS / 32;         // ring slots per tile and wave
     constexpr int NBUF = NKC <= 6 ? NKC : NKC / 2;

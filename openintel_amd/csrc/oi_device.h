@@ -57,23 +57,42 @@ __device__ __forceinline__ float4 oi_load_stream(const float4 *p) {
 #endif
 }
 
-// A workgroup that streams with LDS-DMA (buffer_load ... lds / global_load_lds) must have its CU to itself.
-// Round 5 found it the hard way: searches through views of one index on streams that really ran at the same time returned, a
-// few times in a thousand batches, a cosine list with ONE wrong exact score -- pf_rescore_kernel's dot product of a (query, row)
-// pair off by 1e-3 .. 1e-2, equal to no other pair's score -- and only when its waves had been co-resident on a CU with a screen
-// workgroup of ANOTHER stream (d = 384: the screen wave takes 304 of the SIMD's 512 registers, so a small kernel's wave fits
-// beside it; never at d = 768, 494 registers; never once the rescoring kernel asked for enough LDS not to fit on such a CU:
-// tools/r05_lane_race.py, 0 of 1800 batches against 17-63 of 900).  A wave doing ordinary vector loads beside a wave doing
-// LDS-DMA on the same CU can get wrong data back.  (Not the M0 hand-back: holding M0 for 30 more cycles after the DMA instruction
-// changed nothing, 42 and 46 of 1350; not the register allocation: the kernel descriptor and the highest v / a register in the
-// ISA agree; not the cross-lane sum, not the non-temporal policy.)  Whatever the mechanism, the cure is exclusivity: every LDS-DMA kernel of this
-// library runs one wave per SIMD and claims the SIMD's WHOLE register file (v255 and a255 touched: 256 + 256 registers
-// allocated), so no other wave -- ours, the runtime's fill / copy kernels, another process's -- can be scheduled beside it.
-#ifdef OI_NO_CLAIM // (variant builds: tools/r05_lane_race.py shows the corruption again with it)
+// A matrix-core kernel must have its CUs to itself.  Round 5 found it the hard way: searches through views of one index on streams
+// that really ran at the same time (eight hardware queues) returned, in 2-7 % of the batches, a cosine list with ONE wrong exact
+// score -- pf_rescore_kernel's dot product of a (query, row) pair off by 1e-3 .. 1e-2 -- and only when its waves had been scheduled
+// on a CU beside a screen workgroup of ANOTHER stream (d = 384: the screen wave takes 304 of its SIMD's 512 registers, so a small
+// kernel's wave fits beside it; never at d = 768, 494 registers).  tools/r05_victim_probe.py + tools/r05_victim.hip pin it down
+// with a self-checking victim (pf_rescore_kernel's loop over small-integer rows, every sum exact and known) run beside searches:
+//   * the victim's LOADS are right (row-element and query-element sums per lane are exact); what is lost is one PRODUCT: the
+//     compiler fuses two of the four accumulator chains into v_pk_fma_f32, and the one written  v_pk_fma_f32 ... op_sel:[0,1,0]
+//     (both halves take the HIGH half of src1: the .y term) drops its product in the LOW result of lanes 48..63 -- the last
+//     quarter of the wave -- 180 to 5 300 wrong sums in 1800 launches; ordinary loads, op_sel_hi-only packed forms, single v_fma_f32: 0;
+//   * the neighbour's trait that matters is the MFMA stream, not its LDS-DMA: the screen with its DMA replaced by loads into
+//     unused registers still disturbs the victim (70 wrong sums against 204 in the same session), without its matrix instructions
+//     it does not (0), and holding M0 longer after a DMA instruction changed nothing; non-temporal loads, the cross-lane sum and
+//     the kernel descriptor's register counts were each ruled out on the way.
+// A wave executing that packed form on a SIMD where another workgroup's wave issues MFMAs back to back can lose the product.
+// Nothing in the ISA text we have allows for it, so it is handled from both sides:
+//   (1) every MFMA kernel of this library runs one wave per SIMD and CLAIMS the SIMD's whole register file (v255 and a255 touched:
+//       256 + 256 registers allocated), so no other wave -- ours, the runtime's, another library's -- is ever placed beside it
+//       (free: these kernels were one wave per SIMD by design; tests/test_gpu_pipeline.py runs three concurrent lanes at d = 384);
+//   (2) the exact-score chain of pf_rescore_kernel is written as single v_fma_f32 (oi_fma_unpacked: same fused rounding, bit-identical
+//       scores; without the claim and with it alone: 0 mismatching batches of 2700), so it holds beside a FOREIGN matrix kernel too
+//       (a host application's GEMM on another stream).  profiles/r05_coresidency_probe.txt lists every run.  It is the only
+//       kernel without MFMA in this library that contained an op_sel packed-f32 instruction (ISA survey of every kernel, round 5).
+#ifdef OI_NO_CLAIM // (variant builds: with -DOI_PACKED_RESCORE too, tools/r05_lane_race.py shows the corruption again; the victim probe needs this one only)
 #define OI_CLAIM_WHOLE_SIMD() do { } while (0)
 #else
 #define OI_CLAIM_WHOLE_SIMD() asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a255, 0" ::: "v255", "a255")
 #endif
+__device__ __forceinline__ float oi_fma_unpacked(float x, float y, float a) {
+#ifdef OI_PACKED_RESCORE // (variant builds: the compiler's packed form back, for the tools above)
+    return fmaf(x, y, a);
+#else
+    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));
+    return a;
+#endif
+}
 
 // Order-preserving map f32 -> u32 (ascending).  -0.0 is folded into +0.0 first so
 // that equal scores compare equal; NaN must be rejected by the caller.
