@@ -461,7 +461,8 @@ def main():
     rows_owned_b, screen_copy_b, bm25_index_b = idx.index_bytes()
     hbm_free_b, hbm_total_b = torch.cuda.mem_get_info(dev)     # after the index is resident, before the search workspaces exist
     # what the default scorer's screen streams on this rank: the index's bf16 screening copy if finalize made it
-    copy_streamed = (args.corpus == "f32" and args.cosine in ("screen", "screen-copy") and args.batch > 8 and args.dim in (384, 768)
+    # (round 5: batches of <= 8 queries too -- configs[1] -- half the bytes of the f32 GEMV they used to run)
+    copy_streamed = (args.corpus == "f32" and args.cosine in ("screen", "screen-copy") and args.dim in (384, 768)
                      and (screen_copy_b > 0 or args.cosine == "screen-copy"))
     # Distinct query batches rotated through the steps (step i uses batch i mod NB): no step can profit from the
     # previous step's thresholds, pools or cache contents being those of the same queries.
@@ -698,7 +699,9 @@ def main():
                            "hbm_frac_on_its_bytes": 4.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (st_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
                            "note": "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM): rounds 1-4's headline -- the same bound, the same survivors, the same "
                                    "exact f32 rescoring, identical lists (tests/test_gpu_prefilter.py); the screen converts the f32 rows on the fly "
-                                   "(4 d bytes per row and batch)"}
+                                   "(4 d bytes per row and batch)" if args.batch > 8 else
+                                   "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM) with <= 8 queries: rounds 1-4's exact f32 GEMV over the f32 rows "
+                                   "(cosine_gemv_filter, 4 d bytes per row and batch) -- without a copy to stream a screen would read the same bytes"}
 
     # N = 1: the same K steps through the library's own two-lane pipeline (oi_pipeline_*: what a serving host on the C ABI would
     # run for throughput) -- batch i+1's corpus stream beside the selects / rescoring / fusion of batch i.  A side number: the
@@ -839,7 +842,7 @@ def main():
                                           "corpus twice (corpus_passes_per_batch), HBM sees it once (FETCH_SIZE: 25.63 GB per batch at 12.5M x 1024, "
                                           "profiles/r05_config4_sibling_pmc.txt)")
         roof["hbm_GBs_streamed"] = bytes_step * passes * args.steps / (cos_ms / 1e3) / 1e9
-        if args.cosine in ("screen", "screen-copy", "screen-stream") and roof["bound"] == "hbm" and args.batch > 8 and args.corpus == "f32":
+        if args.cosine in ("screen", "screen-copy", "screen-stream") and roof["bound"] == "hbm" and (args.batch > 8 or copy_streamed) and args.corpus == "f32":
             roof["kernel"] = ("cosine_copy_screen (bf16 MFMA over the index's bf16 screening copy, all corpus-chunk launches of a batch)" if copy_streamed
                               else "cosine_screen_filter (bf16 MFMA over the f32 corpus converted on the fly, all corpus-chunk launches of a batch)")
             roof["algorithmic_bytes_per_launch"] = bytes_step / max(1.0, cos_launches / max(1, args.steps))

@@ -95,8 +95,8 @@ void oi_destroy(oi_ctx *ctx);
 int oi_set_stream(oi_ctx *ctx, void *hip_stream);
 int oi_synchronize(oi_ctx *ctx);
 
-/* How the batch cosine scorer works over an f32 corpus (dim 384 / 768, more than 8 queries; other shapes
- * always use the exact kernels).  The corpus handed to the library stays f32 in HBM in every mode, and every score the
+/* How the batch cosine scorer works over an f32 corpus (dim 384 / 768; more than 8 queries, or -- since round 5 -- any
+ * number of queries when the index holds a screening copy; other shapes always use the exact kernels).  The corpus handed to the library stays f32 in HBM in every mode, and every score the
  * library returns is computed in f32 from those f32 rows.
  *   OI_COSINE_SCREEN (default) a bf16 screen with a proven error bound picks the rows that can reach the list
  *                              (one bf16 MFMA per product: HBM-bound; the bound is built from the MEASURED rounding

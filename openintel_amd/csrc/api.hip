@@ -1465,10 +1465,16 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             // _COPY also makes a missing one now; _STREAM converts the f32 rows on the fly whatever the index holds
             const bool want_copy = ctx->cosine_mode != OI_COSINE_SCREEN_STREAM &&
                                    (idx->screen_copy.p != nullptr || (ctx->cosine_mode == OI_COSINE_SCREEN_COPY && !idx->is_view));
+            // B <= 8 (configs[1]: one query): screened only when there is a copy to stream -- half the bytes of the f32 GEMV, which
+            // is HBM-bound; the f32-stream screen would read what the GEMV reads.  OI_SMALL_BATCH_GEMV=1 (A/B): as before round 5.
+            static const bool small_gemv = oi_ablation_env("OI_SMALL_BATCH_GEMV") != nullptr;
             const bool screen = (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY ||
-                                 ctx->cosine_mode == OI_COSINE_SCREEN_STREAM) && B > 8 && oi_cosine_screen_supported(idx->dim) &&
-                                idx->screen_ok && shape16 && !cos_v1;
-            if (!screen) return exact_pipeline(nullptr, nullptr);
+                                 ctx->cosine_mode == OI_COSINE_SCREEN_STREAM) && (B > 8 || (want_copy && !small_gemv)) &&
+                                oi_cosine_screen_supported(idx->dim) && idx->screen_ok && shape16 && !cos_v1;
+            if (!screen) {
+                ctx->last_screen_gate = nullptr; // (profile "screen_gate": -1 = this search was not screened)
+                return exact_pipeline(nullptr, nullptr);
+            }
 
             // ---- bf16 screen -> margin selects -> exact rescoring -> sorted selection; then the gated exact pipeline
             // (cosine_prefilter.hip).  Its pool keeps up to 4096 keys per query between chunks.

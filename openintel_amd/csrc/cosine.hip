@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void cosine_gemv_filter(const float *__restric
                                                            uint32_t doc_id_base, uint64_t *pools,
                                                            uint32_t *seg_cnt, uint32_t cnt_stride,
                                                            const uint32_t *tau_keys, uint64_t pool_stride,
-                                                           uint32_t seg_cap, uint32_t *overflow) {
+                                                           uint32_t seg_cap, uint32_t *overflow,
+                                                           const uint32_t *run_gate) {
+    // run_gate != null: a launch of the gated exact pipeline behind the screen (cosine_prefilter.hip) -- exits at once unless open
+    if (run_gate && *run_gate == 0u) return;
     // Survivors go to THIS workgroup's segment of the query's pool (LDS fill counter, published once at the
     // end): no global atomic.  With one global counter per query the first chunk -- scored before any
     // threshold exists, every row a survivor -- spent 100 us on 8192 serialised returning atomics.
@@ -251,7 +254,7 @@ int oi_launch_cosine_chunk(oi_ctx *ctx, const float *rows, uint64_t row_begin, u
 #define OI_GEMV(NQ)                                                                                     \
     hipLaunchKernelGGL(cosine_gemv_filter<NQ>, g, b, 0, ctx->stream, rows, row_begin, row_end, dim,     \
                        d_queries, doc_id_base, pool.keys + pool.carry_cap, pool.seg_cnt,                 \
-                       pool.seg_cnt_stride, pool.tau_keys, pool.stride, pool.seg_cap, pool.overflow)
+                       pool.seg_cnt_stride, pool.tau_keys, pool.stride, pool.seg_cap, pool.overflow, ctx->run_gate)
         // queries beyond n_queries are not readable: dispatch on the exact count
         switch (n_queries) {
             case 1: OI_GEMV(1); break;

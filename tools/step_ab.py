@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ms per hybrid step (oi_search, device buffers, 4 rotating batches) at the bench shape, for A/B runs of ablation switches:
-    OI_LIB=ablation [OI_NO_LATE_FORK=1 ...] python tools/step_ab.py [n_docs] [steps]"""
+    OI_LIB=ablation [OI_NO_LATE_FORK=1 ...] python tools/step_ab.py [n_docs] [steps] [batch] [depth]"""
 import json
 import os
 import sys
@@ -15,7 +15,9 @@ from openintel_amd import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-B, DIM, DEPTH, K = 64, 768, 1000, 100
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+DEPTH = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+DIM, K = 768, min(100, DEPTH)
 dev = torch.device("cuda:0")
 ctx = oi.HipContext(0)
 ctx.use_torch_current_stream()
@@ -43,4 +45,4 @@ for rep in range(3):
     torch.cuda.synchronize()
     res.append(a.elapsed_time(b) / steps)
 ctx.synchronize()
-print(json.dumps({"docs": n, "ms_per_step": [round(x, 4) for x in res], "docs_checksum": int(out.docs.sum().item())}))
+print(json.dumps({"docs": n, "batch": B, "depth": DEPTH, "ms_per_step": [round(x, 4) for x in res], "docs_checksum": int(out.docs.sum().item())}))
