@@ -415,6 +415,10 @@ def main():
     if args.exchange == "native" and (world > 1 or force_dist):
         # RCCL inside the library (oi_comm_*): the 128-byte id goes from rank 0 to the others over the process group that
         # launched the ranks -- control plane only; statistics, all-gathers and lanes are the library's from here on
+        if world > 1 and os.environ.get("OI_BENCH_SINGLE_DEVICE"):
+            raise SystemExit("bench.py: --exchange native needs one GPU per rank (RCCL refuses two ranks on one device: "
+                             "ncclInvalidUsage); the one-GPU rehearsals are OI_BENCH_FORCE_DIST=1 --gpus 1 --exchange native, "
+                             "or the torch exchange over gloo")
         ids = [oi.NativeComm.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(ids, src=0)
