@@ -326,9 +326,11 @@ def main():
                     help="oi_index_set_screen_copy(NEVER): the index holds no bf16 screening copy (the default scorer then streams the f32 rows)")
     ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the steps")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: do not overlap exchange + fusion with the next batch's lists")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=None,
                     help="N > 1, pipelined: batches whose lists are scored at once, each through its own view of the shard "
-                         "(own stream and workspaces; sharded.ShardedPipeline); 1 = one at a time")
+                         "(own stream and workspaces); 1 = one at a time.  Default: 2 for the torch exchange (calibrated: the second "
+                         "lane is kept only where it pays), 3 for the native one (measured over three fresh processes each at a "
+                         "1.25M-row shard: 0.470-0.490 ms per step against 0.499-0.513 with 2; tools/r05_lanes_ab.sh)")
     ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
                     help="N > 1: who runs the pipeline and the all-gather -- torch (sharded.ShardedPipeline over torch.distributed, "
                          "the default) or native (oi_pipeline_* + oi_comm_*: lanes, streams and RCCL inside the library, what a host on "
@@ -351,6 +353,8 @@ def main():
     ap.add_argument("--latency-batches", type=int, default=200, help="timed batches of the latency loops (SURVEY 8d: >= 200)")
     ap.add_argument("--latency-warmup", type=int, default=20, help="untimed batches before each latency loop (SURVEY 8d: 20)")
     args = ap.parse_args()
+    if args.lanes is None:
+        args.lanes = 3 if args.exchange == "native" else 2
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
