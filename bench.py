@@ -301,6 +301,48 @@ def self_launch(argv, n_gpus):
     return p.wait()
 
 
+def other_configs():
+    """BASELINE.json's other single-GPU configurations in the driver-run line (N = 1, default workload only): each is THIS script run
+    as a child process on its own workload after the parent's timed region (the same code path as a stand-alone run: own index, own
+    warm-up, own timed region with HIP events); the parent keeps the child's headline fields.  Never fatal: a child that fails or
+    times out leaves {"error": ...}."""
+    import subprocess
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH")) or \
+            any(k.startswith("ROCPROF") for k in os.environ):
+        return {"skipped": "running under rocprofv3: the children would be profiled into this run's statistics"}
+    here = os.path.abspath(__file__)
+    common = ["--no-cpu-baseline", "--no-text-paths", "--no-other-configs", "--no-pipelined-side"]
+    runs = {
+        "config1_single_query": (["--docs", "1000000", "--batch", "1", "--depth", "100", "--steps", "300", "--warmup", "20"],
+                                 "BASELINE configs[1]: 1M posts x 768-d f32, ONE query, hybrid top-100 (per-list depth 100)"),
+        "config4_one_shard": (["--corpus", "bf16", "--dim", "1024", "--batch", "256", "--docs", "12500000", "--steps", "10", "--warmup", "2"],
+                              "one rank's shard of BASELINE configs[4] (100M x 1024-d bf16 over 8 GPUs): 12.5M rows, 256 queries, on one GPU"),
+    }
+    out = {}
+    for name, (argv, what) in runs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, here] + argv + common, capture_output=True, text=True, timeout=400)
+            last = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not last:
+                out[name] = {"workload": what, "error": "rc %d: %s" % (r.returncode, r.stderr.strip()[-300:])}
+                continue
+            d = json.loads(last[-1])
+            roof = d.get("roofline", {})
+            blk = {"workload": what, "argv": " ".join(argv), "queries_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                   "p50_ms": d.get("p50_ms"), "p95_ms": d.get("p95_ms"), "steps": d["steps"], "dtype": d.get("dtype"),
+                   "roofline": {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "corpus_passes_per_batch")},
+                   "wall_s": round(time.perf_counter() - t0, 1)}
+            if "f32_stream_scorer" in d:   # configs[1]: rounds 1-4's path beside it (the f32 GEMV: no copy to stream)
+                blk["without_screening_copy"] = {k: d["f32_stream_scorer"].get(k) for k in ("ms_per_step", "queries_per_s", "hbm_frac_on_its_bytes")}
+            if "exact_scorer" in d:
+                blk["exact_scorer_ms_per_step"] = d["exact_scorer"].get("ms_per_step")
+            out[name] = blk
+        except Exception as e:   # (timeout, a JSON line that does not parse)
+            out[name] = {"workload": what, "error": repr(e)[:300]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +373,10 @@ def main():
                          "(own stream and workspaces); 1 = one at a time.  Default: 2 for the torch exchange (calibrated: the second "
                          "lane is kept only where it pays), 3 for the native one (measured over three fresh processes each at a "
                          "1.25M-row shard: 0.470-0.490 ms per step against 0.499-0.513 with 2; tools/r05_lanes_ab.sh)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, default workload: skip the side blocks that run BASELINE.json's other single-GPU configurations "
+                         "(configs[1]: 1M x 768, one query; one 12.5M-row shard of configs[4]: 1024-d bf16, 256 queries) as child "
+                         "processes of this script after the timed region")
     ap.add_argument("--exchange", choices=["torch", "native"], default="torch",
                     help="N > 1: who runs the pipeline and the all-gather -- torch (sharded.ShardedPipeline over torch.distributed, "
                          "the default) or native (oi_pipeline_* + oi_comm_*: lanes, streams and RCCL inside the library, what a host on "
@@ -686,30 +732,31 @@ def main():
                       "mfma_frac": 2.0 * n_local * args.dim * args.batch * ex_steps / (ex_ms / 1e3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                       "note": "same batch, same K steps, oi_set_cosine_mode(OI_COSINE_EXACT): f32 MFMA for every row (rank 0's clock, outside the headline's timed region)"}
         screen_fallback = gate_opened != 0.0
-        # rounds 1-4's default beside it: the same screen converting the f32 rows on the fly (4 d bytes per row instead of 2 d)
-        stream_side = None
-        if copy_streamed and not args.no_stream_side:
-            ctx.set_cosine_mode(MODES["screen-stream"])
-            step(); step()
-            fence()
-            ctx.profile_reset(2)
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(ex_steps):
-                step()
-            fence()
-            st_elapsed = time.perf_counter() - t1
-            st_ms, st_launches = ctx.profile_read("cosine")
-            ctx.profile_reset(False)
-            ctx.set_cosine_mode(MODES["screen"])
-            stream_side = {"ms_per_step": st_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / st_elapsed, "steps": ex_steps,
-                           "screen_ms_per_step": st_ms / ex_steps,
-                           "hbm_frac_on_its_bytes": 4.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (st_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
-                           "note": "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM): rounds 1-4's headline -- the same bound, the same survivors, the same "
-                                   "exact f32 rescoring, identical lists (tests/test_gpu_prefilter.py); the screen converts the f32 rows on the fly "
-                                   "(4 d bytes per row and batch)" if args.batch > 8 else
-                                   "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM) with <= 8 queries: rounds 1-4's exact f32 GEMV over the f32 rows "
-                                   "(cosine_gemv_filter, 4 d bytes per row and batch) -- without a copy to stream a screen would read the same bytes"}
+    # rounds 1-4's default beside it: the same screen converting the f32 rows on the fly (4 d bytes per row instead of 2 d)
+    # (batches of <= 8 queries too: there the f32 path is the exact GEMV)
+    ex_steps = max(1, args.steps)
+    if copy_streamed and not args.no_stream_side and args.cosine == "screen" and args.corpus == "f32":
+        ctx.set_cosine_mode(MODES["screen-stream"])
+        step(); step()
+        fence()
+        ctx.profile_reset(2)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(ex_steps):
+            step()
+        fence()
+        st_elapsed = time.perf_counter() - t1
+        st_ms, st_launches = ctx.profile_read("cosine")
+        ctx.profile_reset(False)
+        ctx.set_cosine_mode(MODES["screen"])
+        stream_side = {"ms_per_step": st_elapsed / ex_steps * 1e3, "queries_per_s": args.batch * ex_steps / st_elapsed, "steps": ex_steps,
+                       "screen_ms_per_step": st_ms / ex_steps,
+                       "hbm_frac_on_its_bytes": 4.0 * n_local * args.dim * ((args.batch + 63) // 64) * ex_steps / (st_ms / 1e3) / 1e9 / PEAK_HBM_GBS,
+                       "note": "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM): rounds 1-4's headline -- the same bound, the same survivors, the same "
+                               "exact f32 rescoring, identical lists (tests/test_gpu_prefilter.py); the screen converts the f32 rows on the fly "
+                               "(4 d bytes per row and batch)" if args.batch > 8 else
+                               "oi_set_cosine_mode(OI_COSINE_SCREEN_STREAM) with <= 8 queries: rounds 1-4's exact f32 GEMV over the f32 rows "
+                               "(cosine_gemv_filter, 4 d bytes per row and batch) -- without a copy to stream a screen would read the same bytes"}
 
     # N = 1: the same K steps through the library's own two-lane pipeline (oi_pipeline_*: what a serving host on the C ABI would
     # run for throughput) -- batch i+1's corpus stream beside the selects / rescoring / fusion of batch i.  A side number: the
@@ -948,8 +995,8 @@ def main():
                                      "same K steps each; --cosine screen-stream / exact make them the headline.")
             line["exact_scorer"] = exact_side
             line["screen_fell_back_to_exact"] = screen_fallback
-            if stream_side is not None:
-                line["f32_stream_scorer"] = stream_side
+        if stream_side is not None:
+            line["f32_stream_scorer"] = stream_side
         if pipelined_side is not None:
             line["pipelined_native"] = pipelined_side
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N=1 only
@@ -957,6 +1004,9 @@ def main():
                                                 args.cpu_sample_docs, args.cpu_sample_queries)
         if not args.no_text_paths and world == 1:    # the reference-pinned paths, on rank 0 at N=1 (their own inputs; outside the timed region)
             line.update(text_paths(oi, ctx, dev, args.text_items, 10, args.text_cpu_sample))
+        if (not args.no_other_configs and world == 1 and not force_dist and
+                (args.docs, args.dim, args.batch, args.corpus, args.cosine) == (10_000_000, 768, 64, "f32", "screen")):
+            line["other_configs"] = other_configs()
         line["library"] = os.path.relpath(_oil.LIB_PATH, ROOT)   # what was measured (the package loader has no override)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
