@@ -15,7 +15,7 @@ OI_BENCH_FORCE_DIST=1 python3 $R/bench.py --gpus 1 --docs 1250000 --steps 200 --
 OI_BENCH_BACKEND=gloo OI_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 2 --docs 2500000 --steps 100 --warmup 10 --no-cpu-baseline --no-text-paths > $OUT/launcher_gloo2.json 2> $OUT/launcher_gloo2.err && echo "gloo2 ok"
 # (four ranks sharing the card: the box admits six GPU processes and counted five ranks + their launcher as seven, round 4)
 OI_BENCH_BACKEND=gloo OI_BENCH_SINGLE_DEVICE=1 python3 $R/bench.py --gpus 4 --docs 1600000 --steps 50 --warmup 10 --no-cpu-baseline --no-text-paths > $OUT/launcher_gloo4.json 2> $OUT/launcher_gloo4.err && echo "gloo4 ok"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-text-paths --no-other-configs --latency-batches 1 --latency-warmup 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_bench -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-text-paths --no-other-configs --no-pipelined-side --latency-batches 1 --latency-warmup 0 > $OUT/bench_under_rocprof.json 2> $OUT/stats_bench.err && echo "stats bench ok"
 python3 $R/bench.py --cosine exact --steps 10 --no-cpu-baseline --no-text-paths > $OUT/bench_exact.json 2> $OUT/bench_exact.err && echo "exact ok"
 python3 $R/bench.py --docs 1000000 --batch 1 --depth 100 --steps 300 --no-cpu-baseline --no-text-paths > $OUT/bench_b1.json 2> $OUT/bench_b1.err && echo "b1 ok"
 python3 $R/bench.py --corpus bf16 --dim 1024 --batch 256 --docs 12500000 --steps 10 --warmup 2 --no-cpu-baseline --no-text-paths > $OUT/bench_config4_shard.json 2> $OUT/bench_config4_shard.err && echo "config4 shard ok"
