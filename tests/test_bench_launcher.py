@@ -80,3 +80,36 @@ def test_a_rank_does_not_launch_again(monkeypatch):
     except BaseException:
         pass
     assert called == []
+
+
+def test_other_configs_keeps_the_childs_headline_fields_and_never_raises(monkeypatch):
+    """bench.py's `other_configs` block (round 5): configs[1] and one configs[4] shard run as CHILD processes of the default N = 1
+    run.  With stand-in children: the headline fields are carried over, a failing child leaves {"error": ...}, and nothing is
+    started at all under rocprofv3 (the children would be profiled into the run's statistics)."""
+    import json
+    import subprocess as sp
+    for k in [k for k in os.environ if k.startswith("ROCPROF")] + ["LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_PATH"]:
+        monkeypatch.delenv(k, raising=False)
+    calls = []
+
+    def fake_run(cmd, capture_output=True, text=True, timeout=None):
+        calls.append(cmd)
+        assert "--no-other-configs" in cmd and "--no-cpu-baseline" in cmd and cmd[1].endswith("bench.py")
+        if "--corpus" in cmd:            # the configs[4] shard: a child that dies
+            return sp.CompletedProcess(cmd, 3, stdout="", stderr="boom")
+        line = {"value": 2900.0, "ms_per_step": 0.34, "p50_ms": 0.33, "p95_ms": 0.35, "steps": 300, "dtype": "f32",
+                "roofline": {"bound": "hbm", "achieved": 6100.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.76, "kernel": "k", "x": 1},
+                "f32_stream_scorer": {"ms_per_step": 0.55, "queries_per_s": 1800.0, "hbm_frac_on_its_bytes": 0.8, "note": "n"}}
+        return sp.CompletedProcess(cmd, 0, stdout="noise\n" + json.dumps(line) + "\n", stderr="")
+
+    monkeypatch.setattr(sp, "run", fake_run)
+    out = bench.other_configs()
+    assert len(calls) == 2
+    c1 = out["config1_single_query"]
+    assert c1["queries_per_s"] == 2900.0 and c1["ms_per_step"] == 0.34 and c1["roofline"]["frac"] == 0.76 and "x" not in c1["roofline"]
+    assert c1["without_screening_copy"] == {"ms_per_step": 0.55, "queries_per_s": 1800.0, "hbm_frac_on_its_bytes": 0.8}
+    assert "rc 3" in out["config4_one_shard"]["error"] and "boom" in out["config4_one_shard"]["error"]
+    json.dumps(out)
+    monkeypatch.setenv("ROCPROFILER_LIBRARY_PATH", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    calls.clear()
+    assert "skipped" in bench.other_configs() and not calls
