@@ -604,3 +604,48 @@ def test_screen_copy_mode_on_the_tie_rounding_adversary(ctx, O):
     for b in range(B):
         _check(L, b, O.dot_scores(rows, q[b]), depth, n)
     idx.close()
+
+
+def test_fuzz_small_batches_through_the_screen(ctx, O):
+    """Round 5: batches of 1..8 queries take the screen when the index holds a copy (module param "copy"; the f32 GEMV in "stream").
+    Twenty-four random configurations -- corpus sizes around the screen's tile (32 rows), its first chunk (28 672 rows at depth
+    <= 896) and odd ones, both screened dims, depths 1..1000, a zero query, duplicated rows (exact ties at the list's end), a nonzero
+    doc-id base -- against the f64 oracle at the exact kernel's bar, and in "copy" mode the lists of the exact mode on the same index."""
+    from openintel_amd import _lib, synth
+    rng = np.random.default_rng(505)
+    for case in range(24):
+        n = int(rng.choice([1, 31, 33, 1000, 28_671, 28_672, 28_673, 40_000, 120_001]))
+        dim = int(rng.choice([384, 768]))
+        B = int(rng.integers(1, 9))
+        depth = int(rng.choice([1, 10, 100, 1000]))
+        base = int(rng.choice([0, 77, 4_000_000_000]))
+        rows = synth.embeddings_np(n, dim, seed=1000 + case)
+        if n > 64 and case % 3 == 0:
+            rows[n // 2:n // 2 + 20] = rows[5]              # 21 identical rows: ties wherever row 5 ranks
+        q = synth.embeddings_np(B, dim, seed=2000 + case)
+        if case % 4 == 1:
+            q[0] = 0.0                                      # a zero query: every score 0, doc-id order
+        if n > 64:
+            q[B - 1] = rows[5]                              # the tied rows at the top of this query's list
+        terms, offs = _forward(rng, n)
+        idx = _index(ctx, rows, terms, offs, 50, base=base)
+        qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+        L = idx.search_lists(q, qt, qo, depth=depth)
+        g = _gate(ctx)
+        if not _screened(ctx, B):
+            assert g == -1.0, (case, n, dim, B, depth, g)
+        elif case % 4 == 1:
+            assert g in (0.0, 1.0)   # (a zero query ties with every row: whether its survivors fit decides; the lists are checked either way)
+        else:
+            assert g == 0.0, (case, n, dim, B, depth, g)
+        for b in range(B):
+            _check(L, b, O.dot_scores(rows, q[b]), depth, n, base=base)
+        if _screened(ctx, B):
+            ctx.set_cosine_mode(_lib.OI_COSINE_EXACT)
+            Le = idx.search_lists(q, qt, qo, depth=depth)
+            ctx.set_cosine_mode(ctx.screen_mode)
+            assert np.array_equal(L.cos_counts, Le.cos_counts), (case, n, dim, B, depth)
+            for b in range(B):
+                c = int(L.cos_counts[b])
+                assert np.abs(L.cos_scores[b][:c] - Le.cos_scores[b][:c]).max(initial=0.0) <= 5e-7, (case, b)
+        idx.close()
