@@ -837,7 +837,12 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_qsplit(
                     cb_wait<8 * (NHB - 2)>(); // this wave's pieces of the NEXT half tile are in LDS ...
                     __syncthreads();          // ... and everyone's; everyone has finished reading THIS half tile's buffer
                 }
-#ifdef CQ_NOMFMA // (variant builds, timings only: the stream and the LDS traffic without the matrix pipe)
+#if defined(CQ_NOREADS) // (variant builds, timings only: the DMA stream and the barriers alone -- no fragment reads, no matrix pipe)
+                if constexpr (hh == 0 && j == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = -1.f - (float)tile_row0(ti) * 1e-6f; // (falls with the row: nothing passes once a threshold stands)
+                }
+#elif defined(CQ_NOMFMA) // (variant builds, timings only: the stream and the LDS traffic without the matrix pipe)
                 if constexpr (hh == 0 && j == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -853,12 +858,14 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_qsplit(
 #endif
                 // fragments of the slot three ahead: this half tile's, or (from slot 5 on) the next one's.  AFTER this slot's MFMAs
                 // in program order: the registers they go to fed the PREVIOUS slot's MFMAs, all issued a slot ago.
+#ifndef CQ_NOREADS
                 {
                     const unsigned char *src = j + 3 < CQ_HT_SLOTS ? ring + rd_off + (j + 3) * CB_SLOT_BYTES
                                                                    : ring + nx_off + (j + 3 - CQ_HT_SLOTS) * CB_SLOT_BYTES;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) fr[(j + 3) % 4][g] = *reinterpret_cast<const cb_bf16x8 *>(src + frag_off[g]);
                 }
+#endif
                 // the refill of THIS half tile's buffer (free since the barrier): half tile h + NHB = K half hh of tile ti + NHB / 2
                 if constexpr (j == 5) issue_slot(s2, hh, 0, rd_off);
                 if constexpr (j == 6) issue_slot(s2, hh, 1, rd_off);
