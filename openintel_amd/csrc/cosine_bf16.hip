@@ -849,6 +849,9 @@ __global__ __launch_bounds__(256, 1) void cosine_bf16_qsplit(
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[g] += (float)fr[j % 4][g][0];
+#ifdef CQ_SLEEP // (with CQ_NOMFMA: the wave idles for the slot's 128 matrix cycles instead -- is it the pipe or the time that costs?)
+                __builtin_amdgcn_s_sleep(2);
+#endif
 #else
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
