@@ -393,6 +393,8 @@ def main():
     ap.add_argument("--text-cpu-sample", type=int, default=2_000_000, help="posts / titles the CPU oracle is timed on")
     ap.add_argument("--settle-steps", type=int, default=0,
                     help="untimed steps (x the number of ranks) before the warm-up (an experiment: no effect measured, round 4); 0 = none")
+    ap.add_argument("--no-speculation", action="store_true",
+                    help="screen with proven thresholds only (oi_set_screen_speculation(ctx, 0): rounds 2-4's behaviour; A/B runs)")
     ap.add_argument("--no-stream-side", action="store_true", help="skip the f32-stream screen's side measurement (f32_stream_scorer)")
     ap.add_argument("--cpu-sample-docs", type=int, default=400_000)
     ap.add_argument("--cpu-sample-queries", type=int, default=64)
@@ -452,6 +454,8 @@ def main():
     MODES = {"screen": _oil.OI_COSINE_SCREEN, "exact": _oil.OI_COSINE_EXACT, "split": _oil.OI_COSINE_SPLIT,
              "screen-copy": _oil.OI_COSINE_SCREEN_COPY, "screen-stream": _oil.OI_COSINE_SCREEN_STREAM}
     ctx.set_cosine_mode(MODES[args.cosine])
+    if args.no_speculation:
+        ctx.set_screen_speculation(False)   # (lane contexts are made with oi_create_like: they inherit it)
 
     # ---------------------------------------------------------------- corpus shard in HBM
     lo, hi = sharded.shard_bounds(args.docs, world, rank)
@@ -596,6 +600,8 @@ def main():
             def make_lane_ctx():
                 c = oi.HipContext(local_rank)
                 c.set_cosine_mode(MODES[args.cosine])
+                if args.no_speculation:
+                    c.set_screen_speculation(False)
                 if args.lane_bm25 == "inline":
                     c.set_overlap(False)
                 return c

@@ -133,6 +133,15 @@ int oi_set_cosine_mode(oi_ctx *ctx, int mode);
  * runs beside the MFMA-bound cosine leg; enable = 0 runs them one after the other. */
 int oi_set_overlap(oi_ctx *ctx, int enable);
 
+/* Speculative thresholds of the screen (round 5; default on).  Between the corpus chunks of a screened search the threshold is the
+ * proven one -- the k'-th best screen score of the rows seen so far, minus the margin -- which is weak while few rows have been seen.
+ * With speculation the next chunk is screened against the larger of it and a PREDICTION of the final threshold (the r-th best score
+ * so far, r = 3 k' m / n + 12 after m of n rows), and the prediction is checked at the end against the proven final threshold: if it
+ * holds, the survivors are a superset of the proven screen's and the lists are the same; if not (a corpus whose first rows are not a
+ * fair sample of it), the exact pipeline rescores the batch inside the same call -- the same lists, later -- and the ctx stops
+ * speculating for 16, 32, ... 1024 searches.  enable = 0: proven thresholds only (rounds 2-4).  Never used with graph replay. */
+int oi_set_screen_speculation(oi_ctx *ctx, int enable);
+
 /* One device-buffer query call is ~30 kernel launches, memsets and event operations: ~0.3 ms of host time, which at a
  * 1.25M-row shard (one of 8 GPUs) is what limits the rate, not the GPU (0.7 ms of work that two batches in flight overlap).
  * enable != 0: oi_search_lists_packed / oi_fuse_packed / oi_search calls with OI_DEVICE buffers are CAPTURED into a

@@ -60,6 +60,7 @@ extern "C" {
     pub fn oi_synchronize(ctx: *mut OiCtx) -> c_int;
     pub fn oi_set_cosine_mode(ctx: *mut OiCtx, mode: c_int) -> c_int;
     pub fn oi_set_overlap(ctx: *mut OiCtx, enable: c_int) -> c_int;
+    pub fn oi_set_screen_speculation(ctx: *mut OiCtx, enable: c_int) -> c_int;
     pub fn oi_set_graph_replay(ctx: *mut OiCtx, enable: c_int) -> c_int;
 
     pub fn oi_lexicon_analyze(ctx: *mut OiCtx, text_blob: *const u8, offsets: *const u64, n_posts: u64,

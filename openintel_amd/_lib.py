@@ -68,6 +68,7 @@ SIGNATURES = {
     "oi_lexicon_summary_device": (_I, [_P, _P, _P, _U64, _U64, _P, C.c_double, _P, _P, C.POINTER(SocialCounters)]),
     "oi_workspace_bytes": (_I, [_P, C.POINTER(_U64), C.POINTER(_U64)]),
     "oi_set_overlap": (_I, [_P, _I]),
+    "oi_set_screen_speculation": (_I, [_P, _I]),
     "oi_set_graph_replay": (_I, [_P, _I]),
     "oi_set_cosine_mode": (_I, [_P, _I]),
     "oi_catalyst_keyword": (C.c_char_p, [_U32]),

@@ -54,6 +54,16 @@ class HipContext:
         """BM25 leg of a hybrid query beside the cosine leg on a side stream (default) or after it."""
         _lib.check(self.lib.oi_set_overlap(self.handle, 1 if enable else 0))
 
+    def set_screen_speculation(self, enable: bool) -> None:
+        """Speculative screen thresholds (oi_set_screen_speculation; default on): predicted from the rows seen so far, checked at
+        the end, the exact pipeline behind a failed check.  The lists do not depend on it."""
+        _lib.check(self.lib.oi_set_screen_speculation(self.handle, 1 if enable else 0))
+
+    def speculation_state(self):
+        """(failed checks seen, searches that speculated) since the ctx was created."""
+        f, n = self.profile_read("spec_state")
+        return int(f), int(n)
+
     def set_graph_replay(self, enable: bool) -> None:
         """Capture repeated device-buffer query calls into hipGraphs and replay them with one launch (oi_set_graph_replay):
         same kernels, same results, ~0.3 ms less host time per call.  The caller keeps using the same buffers."""

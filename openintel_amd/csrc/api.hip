@@ -135,6 +135,12 @@ extern "C" int oi_profile_read(oi_ctx *ctx, const char *kernel_tag, double *tota
         if (launches_out) *launches_out = kernel_tag[6] == 'r' ? ctx->graph_replays : ctx->graph_captures;
         return OI_OK;
     }
+    if (strcmp(kernel_tag, "spec_state") == 0) { // diagnostics of the speculative screen thresholds: failed checks seen so far, searches that speculated
+        if (ctx->spec_fail_host && *ctx->spec_fail_host) { *ctx->spec_fail_host = 0; ++ctx->spec_failures; ctx->spec_backoff = ctx->spec_backoff ? std::min(1024u, 2 * ctx->spec_backoff) : 16u; ctx->spec_skip = ctx->spec_backoff; }
+        if (total_ms_out) *total_ms_out = (double)ctx->spec_failures;
+        if (launches_out) *launches_out = ctx->spec_searches;
+        return OI_OK;
+    }
     if (strcmp(kernel_tag, "screen_gate") == 0) { // diagnostics: did the last screened search fall back to the exact kernel?
         uint32_t g = 0;                          // (0 no, nonzero yes; -1 when no search has used the screen)
         if (ctx->last_screen_gate) OI_HIP_CHECK(hipMemcpy(&g, ctx->last_screen_gate, 4, hipMemcpyDeviceToHost));
@@ -304,6 +310,7 @@ extern "C" int oi_create_like(oi_ctx *like, oi_ctx **out) {
     std::lock_guard<std::mutex> g(like->mu);
     (*out)->cosine_mode = like->cosine_mode;
     (*out)->overlap_legs = like->overlap_legs;
+    (*out)->speculate = like->speculate;
     (*out)->use_graphs = like->use_graphs;
     return OI_OK;
 }
@@ -320,6 +327,7 @@ static void ctx_release(oi_ctx *ctx) {
     for (auto &kv : ctx->ws) kv.second.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
+    if (ctx->spec_fail_host) (void)hipHostFree(ctx->spec_fail_host);
     delete ctx;
 }
 
@@ -368,6 +376,14 @@ extern "C" int oi_set_overlap(oi_ctx *ctx, int enable) {
     if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
     std::lock_guard<std::mutex> g(ctx->mu);
     ctx->overlap_legs = enable != 0;
+    return OI_OK;
+}
+
+extern "C" int oi_set_screen_speculation(oi_ctx *ctx, int enable) {
+    if (!ctx) { oi_set_error("null ctx"); return OI_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> g(ctx->mu);
+    ctx->speculate = enable != 0;
+    ctx->spec_skip = ctx->spec_backoff = 0;
     return OI_OK;
 }
 
@@ -1194,11 +1210,44 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
     if (pf_stride > pf_carry + n + pf_slack) pf_stride = pf_carry + n + pf_slack;
     Pools P;
     // the bf16 screen's state words (carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][CUs]) ride in the same memset
-    const size_t screen_words = (size_t)B * (4 + (size_t)ctx->num_cus) + 4;
+    const size_t screen_words = (size_t)B * (6 + (size_t)ctx->num_cus) + 4; // (+ spec_tau[B] spec_max[B]: speculative thresholds)
     uint32_t *screen_state = nullptr;
     // (the depth-sized segments of P.bm belong to the workgroup-per-block kernel: no room is set aside for them otherwise)
     OI_CHECK(prepare_pools(ctx, B, std::max<uint64_t>(cos_stride, idx->rows_bf16 ? 0ull : pf_stride), cos_stride, carry_cap,
                            bm25_mode_of(idx) == 1 ? idx->n_blocks : 0, depth, &P, screen_words, &screen_state));
+
+    // Speculative thresholds of the screen (cosine_prefilter.hip, pf_spec_kernel; oi_set_screen_speculation).  Decided here because
+    // the chunk schedule depends on it: with a predicted threshold after the first chunk the second can be large (growth 128: 28 672
+    // rows, then as many as the pool takes -- 10M rows 2.64 -> 2.54 ms, a 1.25M-row shard 0.574 -> 0.540; tools/r05_spec_sched.sh),
+    // with proven thresholds it must stay small (growth 8).  Off: oi_set_screen_speculation(ctx, 0); with graph replay (the host
+    // decides per call); for batches of <= 8 queries (their survivors cost next to nothing, the extra launches 11 us of 0.34 ms);
+    // for spec_skip searches after a failed check.  OI_NO_SPEC=1, OI_SPEC_GROWTH (ablation builds): A/B.
+    bool spec_on = false;
+    uint64_t screen_growth = oi_chunk_growth(B);
+    if (cos_s && idx->rows && !idx->rows_bf16 && B > 8 && idx->screen_ok && oi_cosine_screen_supported(idx->dim) &&
+        (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY || ctx->cosine_mode == OI_COSINE_SCREEN_STREAM)) {
+        static const bool spec_env_off = oi_ablation_env("OI_NO_SPEC") != nullptr;
+        static const uint64_t spec_growth = oi_ablation_env("OI_SPEC_GROWTH") ? std::max(2, atoi(oi_ablation_env("OI_SPEC_GROWTH"))) : 128;
+        if (ctx->spec_fail_host && *ctx->spec_fail_host) { // a batch since the last look failed its check: back off
+            *ctx->spec_fail_host = 0;
+            ++ctx->spec_failures;
+            ctx->spec_backoff = ctx->spec_backoff ? std::min(1024u, 2 * ctx->spec_backoff) : 16u;
+            ctx->spec_skip = ctx->spec_backoff;
+        }
+        spec_on = ctx->speculate && !spec_env_off && !ctx->use_graphs;
+        if (spec_on && ctx->spec_skip) { --ctx->spec_skip; spec_on = false; }
+        if (spec_on && !ctx->spec_fail_host) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&ctx->spec_fail_host), 64, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->spec_fail_host = nullptr;
+                spec_on = false; // (no way to hear of a failed check: no speculation)
+            } else *ctx->spec_fail_host = 0;
+        }
+        if (spec_on) { // does the rank after the FIRST chunk qualify (pf_spec_kernel is launched when 2 r <= k')?  then the long second chunk
+            const uint64_t first = std::min<uint64_t>(n, oi_screen_first_chunk_rows(ctx, depth));
+            if (n && 2 * ((3ull * depth * first + n - 1) / n + 12) <= depth) screen_growth = spec_growth;
+        }
+    }
 
     // The two legs of a hybrid query are independent until fusion: the BM25 leg (latency-bound, 128 KB of
     // LDS per workgroup) is issued on a side stream and fills the issue slots the MFMA-bound cosine leg
@@ -1388,10 +1437,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth), r = 0, last = 0;
             while (r < n) {
                 if (chunk > mc) chunk = mc;
-                const uint64_t e = oi_chunk_end(r, chunk, n, mc, chunk * oi_chunk_growth(B));
+                const uint64_t e = oi_chunk_end(r, chunk, n, mc, chunk * screen_growth);
                 last = e - r;
                 r = e;
-                chunk *= oi_chunk_growth(B);
+                chunk *= screen_growth;
             }
             late = last >= (512u << 10);
         }
@@ -1479,8 +1528,8 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             // ---- bf16 screen -> margin selects -> exact rescoring -> sorted selection; then the gated exact pipeline
             // (cosine_prefilter.hip).  Its pool keeps up to 4096 keys per query between chunks.
             const uint32_t segs = (uint32_t)ctx->num_cus;
-            // state, zeroed with one memset: carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][segs]
-            const size_t words = (size_t)B * (4 + segs) + 4;
+            // state, zeroed with one memset: carry_cnt[B] tau[B] rs_cnt[B] eps2[B] gate[4] seg_cnt[B][segs] spec_tau[B] spec_max[B]
+            const size_t words = (size_t)B * (6 + segs) + 4;
             DevBuf &pk = ctx->buf("pool_cos"), &rk = ctx->buf("screen_rescored"), &qb = ctx->buf("screen_q_bf16");
             OI_REQUIRE(words <= screen_words, "search: screen state does not fit its reservation");
             OI_REQUIRE(pk.cap >= sizeof(uint64_t) * (size_t)B * pf_stride, "search: the shared cosine pool is too small for the screen's view");
@@ -1492,6 +1541,7 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             uint32_t *pf_cnt = w, *pf_tau = w + B, *rs_cnt = w + 2 * (size_t)B;
             float *eps2 = reinterpret_cast<float *>(w + 3 * (size_t)B);
             uint32_t *gate = w + 4 * (size_t)B, *pf_seg = gate + 4;
+            uint32_t *spec_tau = pf_seg + (size_t)B * segs, *spec_max = spec_tau + B;
             PoolView PF{pk.as<uint64_t>(), pf_cnt, pf_seg, pf_tau, pf_stride, pf_carry, 0, 0, segs, P.cos.overflow};
             PoolView RS{rk.as<uint64_t>(), rs_cnt, pf_seg, nullptr, rs_cap, rs_cap, 0, 0, segs, P.cos.overflow};
             OI_CHECK(oi_launch_screen_stage(ctx, d_qv, B, idx->dim, idx->max_row_norm.as<uint32_t>(), qb.as<uint16_t>(),
@@ -1505,20 +1555,41 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 OI_CHECK(idx->screen_copy.ensure(sizeof(uint16_t) * (size_t)n * idx->dim + 64));
                 OI_CHECK(oi_launch_make_screen_copy(ctx, idx->rows, n, idx->dim, idx->screen_copy.as<uint16_t>()));
             }
+            // Speculative thresholds (decided above: spec_on, screen_growth): the next chunk is screened against the larger of
+            // the proven threshold and a prediction from the rows seen so far, checked at the end (a failed check opens the gate).
+            const bool spec = spec_on;
+            bool spec_next = false, spec_any = false;
             uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth);
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
-                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, chunk * oi_chunk_growth(B));
+                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, chunk * screen_growth);
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
                 if (late_pending && e == n) OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (before the last chunk's launch)
-                if (want_copy) OI_CHECK(oi_launch_cosine_screen_copy_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
-                else OI_CHECK(oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF));
+                uint32_t *const proven_tau = PF.tau_keys;
+                if (spec_next) PF.tau_keys = spec_tau; // (this launch only: the selects keep the proven thresholds)
+                const int rc_screen = want_copy ? oi_launch_cosine_screen_copy_chunk(ctx, idx->screen_copy.as<uint16_t>(), r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF)
+                                                : oi_launch_cosine_screen_chunk(ctx, idx->rows, r, e, idx->dim, qb.as<uint16_t>(), B, idx->doc_id_base, PF);
+                PF.tau_keys = proven_tau;
+                OI_CHECK(rc_screen);
                 if (late_pending && e == n) { late_pending = false; OI_CHECK(fork_bm25()); } // ... enqueued after it: the screen's workgroups get their CUs first
                 OI_CHECK(oi_launch_select(ctx, PF, B, depth, /*compact=*/true, nullptr, nullptr, nullptr, depth, &mx));
                 r = e;
-                chunk *= oi_chunk_growth(B);
+                chunk *= screen_growth;
+                spec_next = false;
+                if (spec && r < n) {
+                    // expected rank of the final k'-th among the r rows seen: depth r / n; three times that plus twelve
+                    const uint64_t rank = (3ull * depth * r + n - 1) / n + 12;
+                    if (2 * rank <= depth) {
+                        OI_CHECK(oi_launch_spec_threshold(ctx, PF, B, (uint32_t)rank, eps2, spec_tau, spec_max));
+                        spec_next = spec_any = true;
+                    }
+                }
+            }
+            if (spec_any) {
+                OI_CHECK(oi_launch_spec_check(ctx, pf_tau, spec_max, B, gate, ctx->spec_fail_host));
+                ++ctx->spec_searches;
             }
             OI_CHECK(oi_launch_rescore(ctx, idx->rows, n, idx->dim, idx->doc_id_base, d_qv, B, PF, RS,
                                        idx->n_long ? idx->long_list.as<uint32_t>() : nullptr, idx->n_long));

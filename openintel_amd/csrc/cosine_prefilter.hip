@@ -600,6 +600,104 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
     if (blockIdx.x == 0 && threadIdx.x == 0) out_cnt[q] = c;
 }
 
+// ------------------------------------------------------------------ speculative thresholds (round 5)
+// The screen's threshold after m of n rows is PROVEN: tau~_m - 2 eps, tau~_m the k'-th best screen score of those m rows.  It is
+// weak while m << n (k' of 28 672 rows: 3.5 % of the next chunk pass; the final one passes 0.01 %), and every survivor of a weak
+// threshold costs staging, pool traffic and select time.  What the final threshold will be can be PREDICTED from the same m rows:
+// if they are a fair sample, the k'-th best of n sits near the (k' m / n)-th best of m.  pf_spec_kernel takes the r-th best screen
+// score so far, r = 3 k' m / n + 12 (three times the expected rank plus twelve: for rows in any exchangeable order the chance
+// that fewer than k' of the n rows reach it is < 1e-9 whatever m), lowers it by the same 2 eps, and hands the LARGER of it and the
+// proven threshold to the next chunk.  A prediction is not a bound -- so it is CHECKED: pf_spec_check_kernel compares the largest
+// speculative threshold used for a query with the proven one at the end, tau~_n - 2 eps.  T_spec <= tau~_n - 2 eps means every row
+// the speculation dropped (s~ < T_spec) would have been dropped by the final proven threshold as well: the survivor set still
+// holds every row of the exact list, the lists are the proven screen's.  Otherwise (a corpus whose first rows are not a fair
+// sample: sorted by time or topic) the gate opens and the exact pipeline rescores the batch in the same call, and the host,
+// told through a pinned flag, stops speculating for a while (api.hip: spec_backoff).
+__global__ __launch_bounds__(256) void pf_spec_kernel(const uint64_t *__restrict__ pools, const uint32_t *__restrict__ carry_cnt,
+                                                      uint64_t stride, uint32_t cap, uint32_t r, const float *__restrict__ eps2,
+                                                      const uint32_t *__restrict__ tau_keys, uint32_t *spec_tau, uint32_t *spec_max) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_rank;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    uint32_t c = carry_cnt[q];
+    if (c > cap) c = cap;
+    const uint32_t tau = tau_keys[q];
+    if (r == 0 || c < r) { // (uniform over the workgroup) too few keys kept: the proven threshold as it is
+        if (tid == 0) spec_tau[q] = tau;
+        return;
+    }
+    const uint64_t *k = pools + (uint64_t)q * stride; // the carry region: an unsorted superset of the k' best rank keys so far
+    if (tid == 0) { s_prefix = 0; s_rank = r; }
+    // the r-th LARGEST 32-bit score key: four passes over 8-bit digits, most significant first.  The digit that holds the rank is
+    // found by wave 0 alone (lane l owns digits 4 l .. 4 l + 3; a shuffle suffix sum over the lanes): three barriers per pass.
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, rank = s_rank, himask = shift == 24 ? 0u : 0xFFFFFFFFu << (shift + 8);
+        for (uint32_t i = tid; i < c; i += 256) {
+            const uint32_t sk = (uint32_t)(k[i] >> 32);
+            if ((sk & himask) == prefix) atomicAdd(&hist[(sk >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t own = h0 + h1 + h2 + h3;
+            uint32_t v = own; // -> keys whose digit lies in this lane's four or in a higher lane's
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_down(v, o, 64);
+                if (tid + o < 64) v += t;
+            }
+            uint32_t above = v - own; // keys with a digit above this lane's
+            const uint32_t hd[4] = {h3, h2, h1, h0};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) { // this lane's digits from the top: exactly one digit of one lane holds the rank-th largest
+                if (above < rank && rank <= above + hd[d]) {
+                    s_prefix = prefix | ((uint32_t)(4 * tid + 3 - d) << shift);
+                    s_rank = rank - above;
+                }
+                above += hd[d];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float s = oi_key_f32(s_prefix) - eps2[q]; // (a query without a bound has eps2 = +inf: -inf, no speculation)
+        const uint32_t T = s == s ? oi_f32_key(s) : 0u;
+        const uint32_t st = T > tau ? T : tau;
+        spec_tau[q] = st;
+        if (st > tau && st > spec_max[q]) spec_max[q] = st;
+    }
+}
+// After the last margin select: tau_final[q] = key(tau~_n - 2 eps).  A speculative threshold above it voids the batch's screen.
+__global__ __launch_bounds__(256) void pf_spec_check_kernel(const uint32_t *__restrict__ tau_final, const uint32_t *__restrict__ spec_max,
+                                                            uint32_t n_queries, uint32_t *gate, uint32_t *fail_host) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_queries && spec_max[q] > tau_final[q]) {
+        gate[0] = 1u;
+        if (fail_host) *fail_host = 1u; // (pinned host memory: read by the next search, no synchronisation)
+    }
+}
+
+int oi_launch_spec_threshold(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t r, const float *eps2, uint32_t *spec_tau,
+                             uint32_t *spec_max) {
+    if (n_queries == 0) return OI_OK;
+    ProfScope ps(ctx, "spec");
+    hipLaunchKernelGGL(pf_spec_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, pool.keys, pool.carry_cnt, pool.stride, pool.carry_cap, r,
+                       eps2, pool.tau_keys, spec_tau, spec_max);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+int oi_launch_spec_check(oi_ctx *ctx, const uint32_t *tau_final, const uint32_t *spec_max, uint32_t n_queries, uint32_t *gate,
+                         uint32_t *fail_host) {
+    if (n_queries == 0) return OI_OK;
+    ProfScope ps(ctx, "spec");
+    hipLaunchKernelGGL(pf_spec_check_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, ctx->stream, tau_final, spec_max, n_queries, gate,
+                       fail_host);
+    OI_HIP_CHECK(hipGetLastError());
+    return OI_OK;
+}
+
 // ------------------------------------------------------------------ host
 bool oi_cosine_screen_supported(uint32_t dim) { return dim == 384 || dim == 768; }
 

@@ -649,3 +649,74 @@ def test_fuzz_small_batches_through_the_screen(ctx, O):
                 c = int(L.cos_counts[b])
                 assert np.abs(L.cos_scores[b][:c] - Le.cos_scores[b][:c]).max(initial=0.0) <= 5e-7, (case, b)
         idx.close()
+
+
+@pytest.mark.parametrize("n,dim,B,depth", [(300_000, 768, 64, 1000), (300_000, 768, 64, 100), (120_001, 384, 40, 10), (700_000, 768, 3, 100)])
+def test_speculative_thresholds_leave_the_lists_alone(ctx, O, n, dim, B, depth):
+    """Round 5: between chunks the screen may use a PREDICTED threshold (cosine_prefilter.hip, pf_spec_kernel), checked at the end
+    against the proven one.  On a corpus in random order the check holds (no fallback) and the lists are those of the
+    proven-threshold screen bit for bit -- both survivor sets hold the exact list, the scores are the same exact rescoring."""
+    from openintel_amd import synth
+    rows = synth.embeddings_np(n, dim, seed=91)
+    q = synth.embeddings_np(B, dim, seed=92)
+    rng = np.random.default_rng(9)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50, base=5)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    f0, s0 = ctx.speculation_state()
+    L1 = idx.search_lists(q, qt, qo, depth=depth)
+    g1 = _gate(ctx)
+    f1, s1 = ctx.speculation_state()
+    ctx.set_screen_speculation(False)
+    L0 = idx.search_lists(q, qt, qo, depth=depth)
+    g0 = _gate(ctx)
+    ctx.set_screen_speculation(True)
+    if _screened(ctx, B):
+        assert g1 == 0.0 and g0 == 0.0
+        # (depth 10: the rank 3 k' m / n + 12 is never within k' / 2 -- nothing to gain, no speculation)
+        # (batches of <= 8 queries never speculate: nothing to gain there)
+        assert s1 == s0 + (1 if depth >= 100 and B > 8 else 0) and f1 == f0, "the search must have speculated, and its check must have held"
+    assert np.array_equal(L1.cos_counts, L0.cos_counts)
+    assert np.array_equal(L1.cos_docs, L0.cos_docs) and np.array_equal(L1.cos_scores.view(np.uint32), L0.cos_scores.view(np.uint32))
+    for b in range(min(B, 4)):
+        _check(L1, b, O.dot_scores(rows, q[b]), depth, n, base=5)
+    idx.close()
+
+
+def test_a_failed_speculation_opens_the_gate_and_backs_off(ctx, O):
+    """A corpus whose FIRST rows are not a fair sample: 60 near-copies of every query sit in the first chunk, none after it.  The
+    predicted threshold (the 3 k' m / n + 12 = 21st best of the first 28 672 rows at k' = 100, n = 1M) then sits near 1 while only 60
+    rows of the million reach it: the check at the end fails, the gate opens, the exact pipeline delivers the lists -- still the
+    exact scorer's -- and the ctx stops speculating for the next 16 searches (which are screened with proven thresholds, no gate)."""
+    from openintel_amd import synth
+    n, dim, B, depth = 1_000_000, 768, 16, 100
+    if not _screened(ctx, B):
+        pytest.skip("not reached")
+    rows = synth.embeddings_np(n, dim, seed=93)
+    q = synth.embeddings_np(B, dim, seed=94)
+    rng = np.random.default_rng(10)
+    for b in range(B):                                  # rows 100 + 60 b .. 100 + 60 b + 59: query b plus a little noise, renormalised
+        blk = q[b][None, :] + 0.02 * rng.standard_normal((60, dim)).astype(np.float32) / np.sqrt(dim)
+        rows[100 + 60 * b:160 + 60 * b] = blk / np.linalg.norm(blk, axis=1, keepdims=True)
+    terms, offs = _forward(rng, n)
+    idx = _index(ctx, rows, terms, offs, 50)
+    qt, qo = np.zeros(B, np.uint32), np.arange(B + 1, dtype=np.uint32)
+    ctx.set_screen_speculation(True)                    # (also clears any back-off left by an earlier test)
+    f0, s0 = ctx.speculation_state()
+    L = idx.search_lists(q, qt, qo, depth=depth)
+    assert _gate(ctx) != 0.0, "the speculation must have failed its check"
+    refs = [O.dot_scores(rows, q[b]) for b in range(4)]
+    for b in range(4):
+        _check(L, b, refs[b], depth, n)
+        assert set(range(100 + 60 * b, 160 + 60 * b)) <= set(L.cos_docs[b][:depth].tolist())
+    f1, s1 = ctx.speculation_state()
+    assert f1 == f0 + 1 and s1 == s0 + 1
+    for i in range(3):                                  # backed off: proven thresholds, no fallback, the same lists
+        L2 = idx.search_lists(q, qt, qo, depth=depth)
+        assert _gate(ctx) == 0.0
+        assert np.array_equal(L2.cos_docs, L.cos_docs) or all(
+            np.abs(L2.cos_scores[b] - L.cos_scores[b]).max() <= 5e-7 for b in range(B))
+    f2, s2 = ctx.speculation_state()
+    assert f2 == f1 and s2 == s1, "no speculation while backed off"
+    ctx.set_screen_speculation(True)
+    idx.close()
