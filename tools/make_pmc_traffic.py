@@ -16,6 +16,13 @@ st = json.load(open(sys.argv[4])) if len(sys.argv) > 4 else None
 ALG = 10_000_000 * 768 * 4
 ALG_COPY = 10_000_000 * 768 * 2
 sc = d["cosine_copy_screen"]
+# launches per step (batch): in the single-mode runs every step ends in ONE rrf_kernel launch; the default run mixes three scorers
+# (headline + the f32-stream and exact side blocks), so the copy screen's count is taken from the stream run -- the same chunk
+# schedule (round 5: 3 launches at 10M rows with speculative thresholds, 4 without)
+lps_exact = round(x["cosine_ksplit"]["launches"] / x["rrf_kernel"]["launches"]) if "rrf_kernel" in x else 4
+lps_stream = round(st["cosine_screen"]["launches"] / st["rrf_kernel"]["launches"]) if st and "cosine_screen" in st and "rrf_kernel" in st else 4
+lps_copy = lps_stream
+assert sc["launches"] % lps_copy == 0, (sc["launches"], lps_copy)
 out = {
     "source": "profiles/%s_pmc_summary.json (tools/pmc_profile.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes over "
               "bench.py --steps 3 --warmup 1 --latency-batches 1 --latency-warmup 0, default scorer; collected on the round's code: the tag says which)" % tag,
@@ -24,7 +31,8 @@ out = {
     "kernel": "cosine_copy_screen<768,2,8>",
     "cosine_launches": sc["launches"],
     "cosine_hbm_bytes_per_launch": (sc["hbm_read_bytes"] + sc.get("hbm_write_bytes", 0.0)) / sc["launches"],
-    "cosine_hbm_read_bytes_per_step": sc["hbm_read_bytes"] / sc["launches"] * 4,
+    "cosine_launches_per_step": lps_copy,
+    "cosine_hbm_read_bytes_per_step": sc["hbm_read_bytes"] / sc["launches"] * lps_copy,
     "cosine_algorithmic_bytes_per_step": ALG_COPY,
     "cosine_eff_clock_GHz": sc.get("eff_clock_GHz"),
     "cosine_lds_bank_conflict_cycles_frac": sc.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, sc.get("SQ_LDS_IDX_ACTIVE", 1.0)),
@@ -53,7 +61,8 @@ out["exact_kernel"] = {
     "kernel": "cosine_ksplit16_filter<768,2>",
     "cosine_launches": ex["launches"],
     "cosine_hbm_bytes_per_launch": (ex["hbm_read_bytes"] + ex.get("hbm_write_bytes", 0.0)) / ex["launches"],
-    "cosine_hbm_read_bytes_per_step": ex["hbm_read_bytes"] / ex["launches"] * 4,
+    "cosine_launches_per_step": lps_exact,
+    "cosine_hbm_read_bytes_per_step": ex["hbm_read_bytes"] / ex["launches"] * lps_exact,
     "cosine_algorithmic_bytes_per_step": ALG,
     "cosine_mfma_busy_frac_at_delivered_clock": ex.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, ex.get("GRBM_GUI_ACTIVE", 1.0) / 8 * 1024),
     "cosine_mfma_busy_over_sq_busy": ex.get("mfma_busy_over_sq_busy"),
@@ -66,7 +75,8 @@ if st and "cosine_screen" in st:
         "kernel": "cosine_screen_filter<768,2>",
         "cosine_launches": fs["launches"],
         "cosine_hbm_bytes_per_launch": (fs["hbm_read_bytes"] + fs.get("hbm_write_bytes", 0.0)) / fs["launches"],
-        "cosine_hbm_read_bytes_per_step": fs["hbm_read_bytes"] / fs["launches"] * 4,
+        "cosine_launches_per_step": lps_stream,
+        "cosine_hbm_read_bytes_per_step": fs["hbm_read_bytes"] / fs["launches"] * lps_stream,
         "cosine_algorithmic_bytes_per_step": ALG,
         "cosine_eff_clock_GHz": fs.get("eff_clock_GHz"),
         "cosine_lds_bank_conflict_cycles_frac": fs.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, fs.get("SQ_LDS_IDX_ACTIVE", 1.0)),
