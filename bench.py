@@ -950,7 +950,12 @@ def main():
                                          "exact": "f32 MFMA for every row", "split": "bf16x3 split products",
                                          "screen-copy": "bf16 screen over the bf16 screening copy (made on first use if missing) + exact f32 rescoring",
                                          "screen-stream": "bf16 screen over the f32 rows converted on the fly + exact f32 rescoring (rounds 1-4's default)"}[args.cosine]
-                                        if args.corpus == "f32" and args.batch > 8 else "exact",
+                                        if args.corpus == "f32" and (args.batch > 8 or copy_streamed) else "exact",
+                       "screen_thresholds": ("speculative between the corpus chunks (the r-th best screen score so far, r = 3 k' m / n + 12, minus the margin; "
+                                             "checked on the device against the proven final threshold: a failed check opens the exact pipeline and the "
+                                             "ctx backs off) -- oi_set_screen_speculation, default; --no-speculation: proven only"
+                                             if (args.corpus == "f32" and args.batch > 8 and args.cosine in ("screen", "screen-copy", "screen-stream")
+                                                 and args.dim in (384, 768) and not args.no_speculation) else "proven only"),
                        "index_GB": {"rows_owned_by_library": rows_owned_b / 1e9, "rows_borrowed_from_caller": (0.0 if rows_owned_b else
                                     (2.0 if args.corpus == "bf16" else 4.0) * n_local * args.dim / 1e9),
                                     "screening_copy": screen_copy_b / 1e9, "bm25_structures": bm25_index_b / 1e9,
@@ -1001,6 +1006,11 @@ def main():
                                      "same K steps each; --cosine screen-stream / exact make them the headline.")
             line["exact_scorer"] = exact_side
             line["screen_fell_back_to_exact"] = screen_fallback
+            try:   # (rank 0's ctx: checks of speculative thresholds that failed -- each such batch was rescored by the exact pipeline)
+                sf, sn = ctx.speculation_state()
+                line["screen_speculation"] = {"failed_checks": sf, "searches_that_speculated": sn}
+            except Exception:
+                pass
         if stream_side is not None:
             line["f32_stream_scorer"] = stream_side
         if pipelined_side is not None:
