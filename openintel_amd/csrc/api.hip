@@ -1144,7 +1144,8 @@ int prepare_pools(oi_ctx *ctx, uint32_t B, uint64_t cos_alloc_stride, uint64_t c
 // small); each later chunk is 8x the one before.  OI_FIRST_CHUNK_MULT scales it (A/B runs).
 static uint64_t oi_first_chunk_rows(uint32_t depth) {
     static const uint64_t mult = oi_ablation_env("OI_FIRST_CHUNK_MULT") ? std::max(1, atoi(oi_ablation_env("OI_FIRST_CHUNK_MULT"))) : 1;
-    return std::max<uint64_t>(8192, 32ull * depth) * mult;
+    static const uint64_t div = oi_ablation_env("OI_FIRST_CHUNK_DIV") ? std::max(1, atoi(oi_ablation_env("OI_FIRST_CHUNK_DIV"))) : 1; // (A/B)
+    return std::max<uint64_t>(std::max<uint64_t>(8192, 32ull * depth) * mult / div, 2ull * depth);
 }
 // The screen's first chunk (round 4): a whole number of ROUNDS of the persistent grid -- 7/8 of the CUs x 4 waves x 32-row tiles
 // (cosine_prefilter.hip: oi_cosine_screen_geometry) -- so that no wave of the two short first launches runs one tile more than
@@ -1217,17 +1218,18 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                            bm25_mode_of(idx) == 1 ? idx->n_blocks : 0, depth, &P, screen_words, &screen_state));
 
     // Speculative thresholds of the screen (cosine_prefilter.hip, pf_spec_kernel; oi_set_screen_speculation).  Decided here because
-    // the chunk schedule depends on it: with a predicted threshold after the first chunk the second can be large (growth 128: 28 672
-    // rows, then as many as the pool takes -- 10M rows 2.64 -> 2.54 ms, a 1.25M-row shard 0.574 -> 0.540; tools/r05_spec_sched.sh),
-    // with proven thresholds it must stay small (growth 8).  Off: oi_set_screen_speculation(ctx, 0); with graph replay (the host
+    // the chunk schedule depends on it: with a predicted threshold after the first chunk the second can be as large as the pool takes
+    // (10M rows 2.64 -> 2.54 ms, a 1.25M-row shard 0.574 -> 0.540 -> 0.523 with the short first chunk; tools/r05_spec_sched.sh), with
+    // proven thresholds it must grow slowly (x 8).  Off: oi_set_screen_speculation(ctx, 0); with graph replay (the host
     // decides per call); for batches of <= 8 queries (their survivors cost next to nothing, the extra launches 11 us of 0.34 ms);
     // for spec_skip searches after a failed check.  OI_NO_SPEC=1, OI_SPEC_GROWTH (ablation builds): A/B.
     bool spec_on = false;
-    uint64_t screen_growth = oi_chunk_growth(B);
+    uint64_t screen_growth = oi_chunk_growth(B), screen_first = oi_screen_first_chunk_rows(ctx, depth);
     if (cos_s && idx->rows && !idx->rows_bf16 && B > 8 && idx->screen_ok && oi_cosine_screen_supported(idx->dim) &&
         (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY || ctx->cosine_mode == OI_COSINE_SCREEN_STREAM)) {
         static const bool spec_env_off = oi_ablation_env("OI_NO_SPEC") != nullptr;
         static const uint64_t spec_growth = oi_ablation_env("OI_SPEC_GROWTH") ? std::max(2, atoi(oi_ablation_env("OI_SPEC_GROWTH"))) : 128;
+        static const uint64_t spec_first_div = oi_ablation_env("OI_SPEC_FIRST_DIV") ? std::max(1, atoi(oi_ablation_env("OI_SPEC_FIRST_DIV"))) : 4;
         if (ctx->spec_fail_host && *ctx->spec_fail_host) { // a batch since the last look failed its check: back off
             *ctx->spec_fail_host = 0;
             ++ctx->spec_failures;
@@ -1243,9 +1245,17 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                 spec_on = false; // (no way to hear of a failed check: no speculation)
             } else *ctx->spec_fail_host = 0;
         }
-        if (spec_on) { // does the rank after the FIRST chunk qualify (pf_spec_kernel is launched when 2 r <= k')?  then the long second chunk
-            const uint64_t first = std::min<uint64_t>(n, oi_screen_first_chunk_rows(ctx, depth));
-            if (n && 2 * ((3ull * depth * first + n - 1) / n + 12) <= depth) screen_growth = spec_growth;
+        if (spec_on && n) { // does the rank after the FIRST chunk qualify (pf_spec_kernel is launched when 2 r <= k')?
+            const uint64_t pool_max = pf_stride > pf_carry + pf_slack ? pf_stride - pf_carry - pf_slack : 0; // rows one launch may take
+            // a SHORT first chunk (a quarter of the proven schedule's, >= 8192 rows, >= 8 k': its only job is the sample the
+            // prediction is read from) when everything after it fits ONE launch -- a shard: 8 192 rows, then the rest
+            // (1.25M rows: 0.540 -> 0.523 ms against 28 672 + the rest); a corpus that needs three launches anyway keeps the
+            // regular first chunk and grows x 128 (10M: 28 672, 3.67M, 6.3M rows; a short first chunk measured the same there)
+            const uint64_t first_short = std::min<uint64_t>(n, std::max<uint64_t>(std::max<uint64_t>(8192, 8ull * depth), screen_first / spec_first_div));
+            if (n - first_short <= pool_max && 2 * ((3ull * depth * first_short + n - 1) / n + 12) <= depth) {
+                screen_growth = spec_growth;
+                screen_first = first_short;
+            } else if (2 * ((3ull * depth * std::min<uint64_t>(n, screen_first) + n - 1) / n + 12) <= depth) screen_growth = spec_growth;
         }
     }
 
@@ -1434,10 +1444,10 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             (ctx->cosine_mode == OI_COSINE_SCREEN || ctx->cosine_mode == OI_COSINE_SCREEN_COPY || ctx->cosine_mode == OI_COSINE_SCREEN_STREAM) && B > 8 && idx->screen_ok &&
             oi_cosine_screen_supported(idx->dim) && pf_stride > pf_carry + pf_slack) {
             const uint64_t mc = pf_stride - pf_carry - pf_slack; // the screen's own schedule (cosine_leg below), dry
-            uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth), r = 0, last = 0;
+            uint64_t chunk = screen_first, r = 0, last = 0;
             while (r < n) {
                 if (chunk > mc) chunk = mc;
-                const uint64_t e = oi_chunk_end(r, chunk, n, mc, chunk * screen_growth);
+                const uint64_t e = oi_chunk_end(r, chunk, n, mc, r == 0 ? 0 : chunk * screen_growth);
                 last = e - r;
                 r = e;
                 chunk *= screen_growth;
@@ -1559,11 +1569,11 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
             // the proven threshold and a prediction from the rows seen so far, checked at the end (a failed check opens the gate).
             const bool spec = spec_on;
             bool spec_next = false, spec_any = false;
-            uint64_t chunk = oi_screen_first_chunk_rows(ctx, depth);
+            uint64_t chunk = screen_first;
             uint64_t r = 0;
             while (r < n) {
                 if (chunk > pf_max_chunk) chunk = pf_max_chunk;
-                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, chunk * screen_growth);
+                const uint64_t e = oi_chunk_end(r, chunk, n, pf_max_chunk, r == 0 ? 0 : chunk * screen_growth); // (r == 0: the threshold-less first chunk is never stretched)
                 // the same products, the same bound: only where bf16(x) comes from differs (converted on the fly from the
                 // f32 rows, 4 d bytes per row -- or read from the copy, 2 d bytes per row)
                 if (late_pending && e == n) OI_HIP_CHECK(hipEventRecord(ctx->ev_fork, st)); // (before the last chunk's launch)

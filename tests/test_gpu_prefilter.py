@@ -685,7 +685,7 @@ def test_speculative_thresholds_leave_the_lists_alone(ctx, O, n, dim, B, depth):
 
 def test_a_failed_speculation_opens_the_gate_and_backs_off(ctx, O):
     """A corpus whose FIRST rows are not a fair sample: 60 near-copies of every query sit in the first chunk, none after it.  The
-    predicted threshold (the 3 k' m / n + 12 = 21st best of the first 28 672 rows at k' = 100, n = 1M) then sits near 1 while only 60
+    predicted threshold (the 3 k' m / n + 12 = 15th best of the first 8 192 rows at k' = 100, n = 1M) then sits near 1 while only 60
     rows of the million reach it: the check at the end fails, the gate opens, the exact pipeline delivers the lists -- still the
     exact scorer's -- and the ctx stops speculating for the next 16 searches (which are screened with proven thresholds, no gate)."""
     from openintel_amd import synth
