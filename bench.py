@@ -393,6 +393,9 @@ def main():
     ap.add_argument("--text-cpu-sample", type=int, default=2_000_000, help="posts / titles the CPU oracle is timed on")
     ap.add_argument("--settle-steps", type=int, default=0,
                     help="untimed steps (x the number of ranks) before the warm-up (an experiment: no effect measured, round 4); 0 = none")
+    ap.add_argument("--placements", type=int, default=4,
+                    help="N > 1, torch exchange: fresh streams tried for each further lane (HIP maps streams to hardware queues "
+                         "round-robin; 8 were measured no better than 4; every rank tries the same number)")
     ap.add_argument("--no-speculation", action="store_true",
                     help="screen with proven thresholds only (oi_set_screen_speculation(ctx, 0): rounds 2-4's behaviour; A/B runs)")
     ap.add_argument("--no-stream-side", action="store_true", help="skip the f32-stream screen's side measurement (f32_stream_scorer)")
@@ -607,7 +610,7 @@ def main():
                 return c
             if args.lane_bm25 == "inline":
                 pipe.lane0_ctx.set_overlap(False)
-            pipe.calibrate(batches, make_lane_ctx, reps=16, placements=4, max_lanes=args.lanes)
+            pipe.calibrate(batches, make_lane_ctx, reps=16, placements=args.placements, max_lanes=args.lanes)
         lane_ctxs = [index.ctx for index, _ in pipe.lanes]   # every lane scores on a context of its own (lane 0 too)
 
     def step():
