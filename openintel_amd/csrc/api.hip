@@ -1597,12 +1597,12 @@ int search_lists_device(oi_index *idx, const float *d_qv, const uint32_t *d_qt, 
                     }
                 }
             }
-            if (spec_any) {
-                OI_CHECK(oi_launch_spec_check(ctx, pf_tau, spec_max, B, gate, ctx->spec_fail_host));
-                ++ctx->spec_searches;
-            }
+            if (spec_any) ++ctx->spec_searches;
+            // (the check of the speculative thresholds against the proven final ones rides in the rescoring launch; the gated exact
+            // pipeline is enqueued after it)
             OI_CHECK(oi_launch_rescore(ctx, idx->rows, n, idx->dim, idx->doc_id_base, d_qv, B, PF, RS,
-                                       idx->n_long ? idx->long_list.as<uint32_t>() : nullptr, idx->n_long));
+                                       idx->n_long ? idx->long_list.as<uint32_t>() : nullptr, idx->n_long,
+                                       spec_any ? spec_max : nullptr, pf_tau, gate, ctx->spec_fail_host));
             RS.n_segs = 0;
             OI_CHECK(oi_launch_select(ctx, RS, B, depth, false, cos_s, cos_d, cos_c, depth));
             ctx->run_gate = gate;

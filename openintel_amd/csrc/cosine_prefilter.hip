@@ -553,7 +553,15 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
                                                          const uint64_t *__restrict__ in_pools, const uint32_t *__restrict__ in_cnt,
                                                          uint64_t in_stride, uint32_t cap, uint64_t *out_pools,
                                                          uint32_t *out_cnt, uint64_t out_stride,
-                                                         const uint32_t *__restrict__ extra_docs, uint32_t n_extra) {
+                                                         const uint32_t *__restrict__ extra_docs, uint32_t n_extra,
+                                                         const uint32_t *__restrict__ spec_max, const uint32_t *__restrict__ tau_final,
+                                                         uint32_t *gate, uint32_t *fail_host) {
+    // spec_max != null: the check of the speculative thresholds rides along (spec_max[q] > tau_final[q] voids the batch's screen; no launch of its own): the
+    // gated exact pipeline is enqueued after this kernel
+    if (spec_max && blockIdx.x == 0 && threadIdx.x == 0 && spec_max[blockIdx.y] > tau_final[blockIdx.y]) {
+        gate[0] = 1u;
+        if (fail_host) *fail_host = 1u;
+    }
     // extra_docs: the index's LONG rows (local row numbers, pf_row_norm_class_kernel) -- scored for every query after its
     // survivors, whatever the screen made of them
     const uint32_t q = blockIdx.y, lane = threadIdx.x & 63;
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256) void pf_rescore_kernel(const float *__restrict
 // if they are a fair sample, the k'-th best of n sits near the (k' m / n)-th best of m.  pf_spec_kernel takes the r-th best screen
 // score so far, r = 3 k' m / n + 12 (three times the expected rank plus twelve: for rows in any exchangeable order the chance
 // that fewer than k' of the n rows reach it is < 1e-9 whatever m), lowers it by the same 2 eps, and hands the LARGER of it and the
-// proven threshold to the next chunk.  A prediction is not a bound -- so it is CHECKED: pf_spec_check_kernel compares the largest
+// proven threshold to the next chunk.  A prediction is not a bound -- so it is CHECKED: pf_rescore_kernel (first thing) compares the largest
 // speculative threshold used for a query with the proven one at the end, tau~_n - 2 eps.  T_spec <= tau~_n - 2 eps means every row
 // the speculation dropped (s~ < T_spec) would have been dropped by the final proven threshold as well: the survivor set still
 // holds every row of the exact list, the lists are the proven screen's.  Otherwise (a corpus whose first rows are not a fair
@@ -669,31 +677,12 @@ __global__ __launch_bounds__(256) void pf_spec_kernel(const uint64_t *__restrict
         if (st > tau && st > spec_max[q]) spec_max[q] = st;
     }
 }
-// After the last margin select: tau_final[q] = key(tau~_n - 2 eps).  A speculative threshold above it voids the batch's screen.
-__global__ __launch_bounds__(256) void pf_spec_check_kernel(const uint32_t *__restrict__ tau_final, const uint32_t *__restrict__ spec_max,
-                                                            uint32_t n_queries, uint32_t *gate, uint32_t *fail_host) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < n_queries && spec_max[q] > tau_final[q]) {
-        gate[0] = 1u;
-        if (fail_host) *fail_host = 1u; // (pinned host memory: read by the next search, no synchronisation)
-    }
-}
-
 int oi_launch_spec_threshold(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t r, const float *eps2, uint32_t *spec_tau,
                              uint32_t *spec_max) {
     if (n_queries == 0) return OI_OK;
     ProfScope ps(ctx, "spec");
     hipLaunchKernelGGL(pf_spec_kernel, dim3(n_queries), dim3(256), 0, ctx->stream, pool.keys, pool.carry_cnt, pool.stride, pool.carry_cap, r,
                        eps2, pool.tau_keys, spec_tau, spec_max);
-    OI_HIP_CHECK(hipGetLastError());
-    return OI_OK;
-}
-int oi_launch_spec_check(oi_ctx *ctx, const uint32_t *tau_final, const uint32_t *spec_max, uint32_t n_queries, uint32_t *gate,
-                         uint32_t *fail_host) {
-    if (n_queries == 0) return OI_OK;
-    ProfScope ps(ctx, "spec");
-    hipLaunchKernelGGL(pf_spec_check_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, ctx->stream, tau_final, spec_max, n_queries, gate,
-                       fail_host);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }
@@ -804,13 +793,14 @@ int oi_launch_cosine_screen_chunk(oi_ctx *ctx, const float *rows, uint64_t row_b
 // Exact scores of the screen's survivors: in.carry region (in.carry_cnt keys per query) -> out.carry region.
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
                       const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out,
-                      const uint32_t *extra_docs, uint32_t n_extra) {
+                      const uint32_t *extra_docs, uint32_t n_extra, const uint32_t *spec_max, const uint32_t *tau_final,
+                      uint32_t *gate, uint32_t *fail_host) {
     if (n_queries == 0) return OI_OK;
     OI_REQUIRE(out.carry_cap >= in.carry_cap + n_extra, "rescore: output pool too small");
     ProfScope ps(ctx, "rescore");
     hipLaunchKernelGGL(pf_rescore_kernel, dim3(64, n_queries), dim3(256), 0, ctx->stream, rows, dim, doc_id_base, n_rows,
                        d_queries, in.keys, in.carry_cnt, in.stride, in.carry_cap, out.keys, out.carry_cnt, out.stride, extra_docs,
-                       n_extra);
+                       n_extra, spec_max, tau_final, gate, fail_host);
     OI_HIP_CHECK(hipGetLastError());
     return OI_OK;
 }

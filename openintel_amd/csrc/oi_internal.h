@@ -126,7 +126,7 @@ struct oi_ctx {
     // speculation failed its check (the device writes *spec_fail_host) switches them off for spec_backoff searches, doubling up to 1024
     bool speculate = true;
     uint32_t spec_skip = 0, spec_backoff = 0;
-    uint32_t *spec_fail_host = nullptr;    // 4 bytes of pinned host memory, written by pf_spec_check_kernel
+    uint32_t *spec_fail_host = nullptr;    // 4 bytes of pinned host memory, written by pf_rescore_kernel when a check fails
     uint64_t spec_searches = 0, spec_failures = 0; // (diagnostics: profile "spec_state")
     int cosine_mode = 2;                   // oi_set_cosine_mode: 0 exact-f32 MFMA, 1 split-precision products, 2 screen + rescore (default),
                                            // 3 = 2 + make a missing screening copy on first use, 4 = 2 but never read the copy
@@ -314,14 +314,14 @@ int oi_launch_cosine_screen_copy_chunk(oi_ctx *ctx, const uint16_t *copy_rows, u
 int oi_launch_screen_probe(oi_ctx *ctx, const float *rows, uint64_t row_begin, uint32_t n_rows, uint32_t dim,
                            const uint16_t *q_bf16, uint32_t n_queries, float *d_out);
 // speculative thresholds of the screen (cosine_prefilter.hip): the r-th best screen score so far - 2 eps, if above the proven
-// threshold, for the NEXT chunk (spec_tau), the largest one used per query (spec_max); and the check against the final one
+// threshold, for the NEXT chunk (spec_tau), the largest one used per query (spec_max); the check against the final one rides in
+// oi_launch_rescore (spec_max, tau_final, gate, fail_host)
 int oi_launch_spec_threshold(oi_ctx *ctx, const PoolView &pool, uint32_t n_queries, uint32_t r, const float *eps2, uint32_t *spec_tau,
                              uint32_t *spec_max);
-int oi_launch_spec_check(oi_ctx *ctx, const uint32_t *tau_final, const uint32_t *spec_max, uint32_t n_queries, uint32_t *gate,
-                         uint32_t *fail_host);
 int oi_launch_rescore(oi_ctx *ctx, const float *rows, uint64_t n_rows, uint32_t dim, uint32_t doc_id_base,
                       const float *d_queries, uint32_t n_queries, const PoolView &in, const PoolView &out,
-                      const uint32_t *extra_docs = nullptr, uint32_t n_extra = 0);
+                      const uint32_t *extra_docs = nullptr, uint32_t n_extra = 0, const uint32_t *spec_max = nullptr,
+                      const uint32_t *tau_final = nullptr, uint32_t *gate = nullptr, uint32_t *fail_host = nullptr);
 #define OI_LONG_ROWS_MAX 1024u // rows the two-class margin may set aside (more: one class, the corpus maxima, as before)
 int oi_launch_row_norm_classes(oi_ctx *ctx, const float *rows, uint64_t n, uint32_t dim, float X0, float E0, uint32_t *cls,
                                uint32_t *bitmap, uint32_t *list, uint32_t cap);
